@@ -1,0 +1,354 @@
+/*
+ * hiprz.h — C-ABI of the MI355X (gfx950) path-tracing backend for RayZath.
+ *
+ * This is the drop-in boundary for ONE path of the reference: what
+ * `RayZath::Engine::Engine::renderWorld` (RayZath/rayzath.cpp:64-94) dispatches to a
+ * backend — `CPU::Engine::renderWorld` (RayZath/cpu_engine.hpp:17-22) /
+ * `Cuda::Engine::renderWorld` (RayZath/cuda_engine.cuh:34-39) — i.e. the per-pixel
+ * integration loop of RayZath/cpu_engine_kernel.cpp, plus the device-side scene
+ * mirror the CUDA backend keeps (RayZath/cuda_world.cuh, cuda_bvh.cuh,
+ * cuda_instance.cuh, cuda_material.cuh, cuda_camera.cuh).
+ *
+ * Everything crossing this boundary is plain-old-data: pointers, sizes, fixed-layout
+ * structs.  No C++ types, no torch types, no exceptions.  Every call returns an int
+ * (HIPRZ_OK == 0); the message of the last failure is available from
+ * hiprz_last_error().  A RayZath-side adapter walks the host
+ * `World`, fills a `hiprz_scene`, and converts non-zero returns into
+ * `RayZath::Exception` (RayZath/rzexception.hpp:11-26), including the deferred-throw
+ * contract of the CUDA backend (RayZath/cuda_engine_core.cu:41).
+ *
+ * The context is NOT re-entrant: callers serialise calls per context exactly as the
+ * reference serialises `renderWorld` with a mutex (RayZath/cpu_engine_core.cpp:15,
+ * RayZath/cuda_engine_core.cu:38).
+ */
+#ifndef HIPRZ_H
+#define HIPRZ_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIPRZ_OK 0
+#define HIPRZ_ERR_INVALID 1   /* bad argument / inconsistent scene (checked on the host before any launch) */
+#define HIPRZ_ERR_DEVICE 2    /* a hip* call failed */
+#define HIPRZ_ERR_STATE 3     /* call order violated (e.g. render before scene+camera upload) */
+
+/* ---------------------------------------------------------------------------------
+ * Flattened scene snapshot (SoA of fixed-size POD records; all float = IEEE fp32).
+ * Replaces the CUDA backend's AoS device mirror (RayZath/cuda_bvh_tree_node.cuh:8-54
+ * 48-B nodes, cuda_render_parts.cuh:996-1003 144-B triangles, cuda_instance.cuh:167-176
+ * ~640-B instances with 64 material pointers).
+ * ------------------------------------------------------------------------------- */
+
+#define HIPRZ_NODE_LEAF 0x80000000u       /* meta bit 31: node is a leaf                  */
+#define HIPRZ_NODE_PTYPE_SHIFT 29         /* meta bits 29..30: partition type of an inner */
+#define HIPRZ_NODE_COUNT_MASK 0x1FFFFFFFu /* node (X=2,Y=1,Z=0,Size=3; bvh_tree_node.hpp:22-28) */
+
+/* One BVH node, 32 B.  The world-level tree over instances (RayZath/bvh.hpp:29-53) and
+ * every per-mesh tree over triangles (RayZath/component_container.hpp:145-363) live in
+ * ONE array.  Inner node: children are nodes[begin] (first) and nodes[begin+1] (second).
+ * Leaf: primitives [begin, begin+count) — indices into tlas_order[] for the world tree,
+ * into tris[] (already in leaf order, de-indexed) for a mesh tree. */
+typedef struct hiprz_node {
+    float bb_min[3];
+    float bb_max[3];
+    uint32_t begin;
+    uint32_t meta; /* count | ptype << 29 | HIPRZ_NODE_LEAF */
+} hiprz_node;
+
+#define HIPRZ_TRI_HAS_TEXCRDS 0x40000000u
+#define HIPRZ_TRI_HAS_NORMALS 0x80000000u
+#define HIPRZ_TRI_MATERIAL_MASK 0x00FFFFFFu
+
+/* Intersection record of one triangle, 48 B (three 16-B loads).  Vertices are stored
+ * de-indexed in the order the reference reads them, v1 v2 v3
+ * (RayZath/mesh_component.cpp:52-57). */
+typedef struct hiprz_tri {
+    float v1[3];
+    uint32_t material_flags; /* material_id | HIPRZ_TRI_HAS_* (mesh_component.hpp:27-33) */
+    float v2[3];
+    uint32_t source_index; /* index of the triangle in its mesh before leaf reordering */
+    float v3[3];
+    uint32_t pad0;
+} hiprz_tri;
+
+/* Shading record of one triangle, 96 B, read once per hit
+ * (RayZath/cpu_engine_kernel.cpp:354-395). */
+typedef struct hiprz_tri_attr {
+    float n1[3];
+    float pad0;
+    float n2[3];
+    float pad1;
+    float n3[3];
+    float pad2;
+    float face_normal[3]; /* normalize(cross(v2-v3, v2-v1)), mesh_component.cpp:19-26 */
+    float pad3;
+    float t1[2];
+    float t2[2];
+    float t3[2];
+    float pad4[2];
+} hiprz_tri_attr;
+
+/* One instance, 112 B (RayZath/instance.hpp:17-24, render_parts.hpp:39-69). */
+typedef struct hiprz_instance {
+    float position[3];
+    uint32_t blas_root; /* node index of the mesh tree's root */
+    float scale[3];
+    uint32_t material_base; /* first entry in inst_materials[] */
+    float x_axis[3];
+    uint32_t material_count; /* entries in inst_materials[] (<= 64, instance.hpp:17) */
+    float y_axis[3];
+    uint32_t pad0;
+    float z_axis[3];
+    uint32_t pad1;
+    float bb_min[3]; /* world-space box, instance.cpp:117-155 */
+    uint32_t pad2;
+    float bb_max[3];
+    uint32_t pad3;
+} hiprz_instance;
+
+#define HIPRZ_MATERIAL_WORLD 0u   /* materials[0] = World::material()        (world.cpp:33-38) */
+#define HIPRZ_MATERIAL_DEFAULT 1u /* materials[1] = World::defaultMaterial() (world.cpp:39-43) */
+
+/* One material, 48 B (RayZath/material.hpp:119-160).  Map fields index textures[], -1 = none. */
+typedef struct hiprz_material {
+    uint8_t color[4]; /* Graphics::Color r,g,b,a (a = opacity, 255 opaque) */
+    float metalness;
+    float roughness;
+    float emission;
+    float ior;
+    float scattering;
+    int32_t texture;
+    int32_t normal_map;
+    int32_t metalness_map;
+    int32_t roughness_map;
+    int32_t emission_map;
+    uint32_t pad0;
+} hiprz_material;
+
+#define HIPRZ_TEX_RGBA8 0u /* Texture / NormalMap (Graphics::Color)   */
+#define HIPRZ_TEX_R8 1u    /* MetalnessMap / RoughnessMap (uint8_t)   */
+#define HIPRZ_TEX_R32F 2u  /* EmissionMap (float)                     */
+
+/* One texture descriptor, 48 B (RayZath/render_parts.hpp:113-222).  Texels are
+ * row-major, top row first, at texels + offset. cos/sin of the rotation are hoisted to
+ * the host (the reference evaluates them inside vec2::Rotate on every fetch). */
+typedef struct hiprz_texture {
+    uint32_t kind;
+    uint32_t width;
+    uint32_t height;
+    uint32_t offset; /* byte offset into the texel pool, 4-B aligned */
+    float scale[2];
+    float translation[2];
+    float rotation;
+    float cos_rotation;
+    float sin_rotation;
+    uint32_t pad0;
+} hiprz_texture;
+
+/* Spot light, 48 B (RayZath/spot_light.hpp). cos_angle = cosf(angle) hoisted to the host. */
+typedef struct hiprz_spot_light {
+    float position[3];
+    float size;
+    float direction[3]; /* normalised, spot_light.cpp:27-32 */
+    float emission;
+    uint8_t color[4];
+    float angle;
+    float cos_angle;
+    uint32_t pad0;
+} hiprz_spot_light;
+
+/* Direct light, 32 B (RayZath/direct_light.hpp). */
+typedef struct hiprz_direct_light {
+    float direction[3]; /* normalised, direct_light.cpp:22-27 */
+    float emission;
+    uint8_t color[4];
+    float angular_size;
+    float cos_angular_size; /* cosf(angular_size), hoisted to the host */
+    uint32_t pad0;
+} hiprz_direct_light;
+
+typedef struct hiprz_scene {
+    uint32_t n_nodes;
+    const hiprz_node* nodes;
+    uint32_t tlas_root; /* node index of the world tree's root; ignored if n_tlas_order == 0 */
+    uint32_t n_tlas_order;
+    const uint32_t* tlas_order; /* instance ids in leaf order */
+    uint32_t n_tris;
+    const hiprz_tri* tris;
+    const hiprz_tri_attr* tri_attrs;
+    uint32_t n_instances;
+    const hiprz_instance* instances;
+    uint32_t n_inst_materials;
+    const int32_t* inst_materials; /* material index, -1 = unset (=> default material) */
+    uint32_t n_materials;          /* >= 2: [0] world, [1] default */
+    const hiprz_material* materials;
+    uint32_t n_textures;
+    const hiprz_texture* textures;
+    size_t texel_bytes;
+    const uint8_t* texels;
+    uint32_t n_spot_lights;
+    const hiprz_spot_light* spot_lights;
+    uint32_t n_direct_lights;
+    const hiprz_direct_light* direct_lights;
+} hiprz_scene;
+
+/* Camera (RayZath/camera.hpp:127-161, camera.cpp). tan_half_fov = tanf(fov*0.5f) is
+ * hoisted to the host (cpu_engine_kernel.cpp:186,214 evaluates it per pixel). */
+typedef struct hiprz_camera {
+    float position[3];
+    float x_axis[3];
+    float y_axis[3];
+    float z_axis[3];
+    uint32_t width;
+    uint32_t height;
+    float fov;
+    float tan_half_fov;
+    float aspect_ratio; /* float(width) / float(height), camera.cpp:53 */
+    float near_far[2];
+    float focal_distance;
+    float aperture;
+    float exposure_time;
+} hiprz_camera;
+
+/* RenderConfig (RayZath/engine_parts.hpp:76-128) + the deterministic seeding the
+ * harness adds (the CPU renderer seeds from std::random_device,
+ * cpu_engine_renderer.cpp:143-145, so a fixed convention is ours: SURVEY.md §8 a1). */
+typedef struct hiprz_config {
+    uint32_t max_depth;      /* Tracing::maxDepth, u8 in the reference (1..254) */
+    uint32_t rpp;            /* Tracing::rpp: cumulative passes per render call */
+    uint32_t spot_samples;   /* LightSampling::spotLight   (>= 1) */
+    uint32_t direct_samples; /* LightSampling::directLight (>= 1) */
+    uint32_t seed;           /* base of the per-pass 256-entry seed table */
+} hiprz_config;
+
+/* Work counters of the traversal (the figures the algorithmic byte
+ * count is built from).  Filled only by hiprz_render_counted(). */
+typedef struct hiprz_counters {
+    uint64_t segments;      /* path segments traced (= rays, cpu_engine_renderer.cpp:173) */
+    uint64_t box_tests;     /* BoundingBox::rayIntersection calls, closest + shadow */
+    uint64_t tri_tests;     /* Triangle::closest/anyIntersection calls */
+    uint64_t hits;          /* segments whose closest-hit search found a surface */
+    uint64_t shadow_rays;   /* anyIntersection(ray) calls */
+    uint64_t light_samples; /* light samples evaluated (NEE loop iterations) */
+    uint64_t texel_fetches; /* TextureBuffer::fetch calls */
+    uint64_t finished;      /* paths finished (alpha increments, cpu_engine_kernel.cpp:82) */
+} hiprz_counters;
+
+typedef struct hiprz_ctx hiprz_ctx;
+
+/* --- lifecycle (replaces Cuda::Engine ctor/dtor, RayZath/cuda_engine.cu:8-21) --- */
+int hiprz_create(hiprz_ctx** out, int device_id);
+int hiprz_destroy(hiprz_ctx* ctx);
+/* message of the last non-OK return on this context (ctx may be NULL for create failures) */
+const char* hiprz_last_error(const hiprz_ctx* ctx);
+
+/* --- host→device mirroring (replaces Cuda::World::reconstruct*, cuda_world.cu:28-57) --- */
+int hiprz_upload_scene(hiprz_ctx* ctx, const hiprz_scene* scene);   /* validates, copies; caller keeps ownership */
+int hiprz_upload_camera(hiprz_ctx* ctx, const hiprz_camera* camera); /* (re)allocates per-pixel state on resize */
+int hiprz_set_config(hiprz_ctx* ctx, const hiprz_config* config);
+/* Own only the 32x8-pixel tiles t with t % world == rank (global pixel ids and seeds are
+ * unchanged, so results are identical for any world size).  Default rank 0 of 1. */
+int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
+
+/* Tree-walk variant of the pass kernel: 0 = threaded (skip links, no stack; default),
+ * 1 = per-lane stack in LDS.  Both visit the same nodes in the same order. */
+int hiprz_set_traversal_mode(hiprz_ctx* ctx, int mode);
+
+/* --- rendering (replaces Renderer::renderFunction, cuda_engine_renderer.cu:73-262) --- */
+/* Restart accumulation: the next hiprz_render starts with renderFirstPass
+ * (CameraContext::reset, cpu_engine_renderer.cpp:32-39). */
+int hiprz_reset(hiprz_ctx* ctx);
+/* Trace n_passes passes (one path segment per owned pixel each): the first after a
+ * reset is renderFirstPass (cpu_engine_kernel.cpp:15-57), the rest renderCumulativePass
+ * (:58-101).  Asynchronous on the context's stream. */
+int hiprz_render(hiprz_ctx* ctx, uint32_t n_passes);
+/* Same, with the work counters enabled (instrumented kernel; synchronous). */
+int hiprz_render_counted(hiprz_ctx* ctx, uint32_t n_passes, hiprz_counters* out);
+/* Tone-map the accumulator into the RGBA8 image (cpu_engine_renderer.cpp:224-235). */
+int hiprz_tonemap(hiprz_ctx* ctx);
+int hiprz_sync(hiprz_ctx* ctx);
+
+/* --- device→host readback (replaces EngineCore::CopyRenderToHost, cuda_engine_core.cu:129-242).
+ * Row-major W*H images of the full frame; pixels not owned by this shard are zero. --- */
+int hiprz_read_rgba8(hiprz_ctx* ctx, uint8_t* dst, size_t bytes);    /* W*H*4      */
+int hiprz_read_depth(hiprz_ctx* ctx, float* dst, size_t bytes);      /* W*H*4      */
+int hiprz_read_accum(hiprz_ctx* ctx, float* dst, size_t bytes);      /* W*H*16 RGBA32F, alpha = finished paths */
+/* Per-pixel path state (CameraContext, cpu_engine_kernel.hpp:29-51) for parity tests:
+ * origin[3], direction[3], color[3] as W*H*9 floats; material id u16 and depth u8 widened to u32 pairs. */
+int hiprz_read_state(hiprz_ctx* ctx, float* ray9, uint32_t* material_depth2, size_t n_pixels);
+int hiprz_ray_count(hiprz_ctx* ctx, uint64_t* out); /* Camera::rayCount, camera.hpp:113-114 */
+int hiprz_pass_count(hiprz_ctx* ctx, uint32_t* out);
+
+/* --- multi-GPU hand-off: tile-major device buffers for an RCCL gather.
+ * Layout: owned tile lt (global tile lt*world+rank), 256 pixels each (4 waves of 8x8). --- */
+int hiprz_local_pixel_capacity(hiprz_ctx* ctx, size_t* out);          /* owned tiles * 256 */
+int hiprz_export_accum_tiles(hiprz_ctx* ctx, void* dst_device, size_t bytes);  /* float4 per local pixel, D2D on ctx stream */
+/* Scatter tile-major float4 tiles of shard (rank, world) into a row-major W*H*16 device image. */
+int hiprz_untile_accum(hiprz_ctx* ctx, const void* src_device_tiles, uint32_t rank, uint32_t world,
+                       void* dst_device_image);
+/* Tone-map a row-major W*H float4 device image into W*H RGBA8 (device pointers). */
+int hiprz_tonemap_image(hiprz_ctx* ctx, const void* src_device_image, void* dst_device_rgba8);
+void* hiprz_stream(hiprz_ctx* ctx); /* the hipStream_t all of the above are enqueued on */
+
+/* --- picking (Kernel::rayCast, cpu_engine_kernel.cpp:102-111, 483-501) --- */
+int hiprz_pick(hiprz_ctx* ctx, uint32_t x, uint32_t y, int32_t* instance_out, int32_t* material_out);
+
+/* --- timing (TimeTable, engine_parts.hpp:34-74; Engine::debugInfo, rayzath.cpp:96-113) --- */
+int hiprz_timings(hiprz_ctx* ctx, char* buf, size_t len);
+/* Average device time of the pass kernel since the last call, from hip events recorded on the
+ * context's stream around every hiprz_render() batch. */
+int hiprz_kernel_time_ms(hiprz_ctx* ctx, double* total_ms, uint64_t* launches);
+
+/* ---------------------------------------------------------------------------------
+ * Host-side tree builders (pure CPU; no device needed).  They restate the reference's
+ * builders — TreeNode::construct (RayZath/bvh_tree_node.hpp:117-215) and
+ * ComponentTreeNode::construct (RayZath/component_container.hpp:259-363) — and emit the
+ * flattened layout above.  A RayZath-side adapter would instead flatten the trees the
+ * host World already built; these exist so the backend is usable
+ * without the un-vendored host library.
+ * ------------------------------------------------------------------------------- */
+typedef struct hiprz_mesh_desc {
+    uint32_t n_vertices;
+    const float* vertices; /* xyz */
+    uint32_t n_texcrds;
+    const float* texcrds; /* uv */
+    uint32_t n_normals;
+    const float* normals; /* xyz */
+    uint32_t n_triangles;
+    const uint32_t* tri_vertices;  /* 3 per triangle */
+    const uint32_t* tri_texcrds;   /* 3 per triangle, 0xFFFFFFFF = unused; may be NULL */
+    const uint32_t* tri_normals;   /* 3 per triangle, 0xFFFFFFFF = unused; may be NULL */
+    const uint32_t* tri_materials; /* 1 per triangle; may be NULL (=0) */
+} hiprz_mesh_desc;
+
+/* Builds the per-mesh tree.  Writes at most max_nodes nodes (node.begin of inner nodes is
+ * relative to nodes_out[0]; leaf begin is relative to tris_out[0]) and exactly n_triangles
+ * tris/attrs in leaf order.  Returns HIPRZ_OK and *n_nodes_out, or HIPRZ_ERR_INVALID if
+ * max_nodes is too small (2*n_triangles+1 always suffices). */
+int hiprz_build_mesh_tree(const hiprz_mesh_desc* mesh, hiprz_node* nodes_out, uint32_t max_nodes,
+                          uint32_t* n_nodes_out, hiprz_tri* tris_out, hiprz_tri_attr* attrs_out);
+/* Builds the world tree over instance boxes (bb_min/bb_max of each instance; has_mesh[i]==0
+ * instances are left out, bvh.hpp:40-47).  order_out receives instance ids in leaf order. */
+int hiprz_build_world_tree(const hiprz_instance* instances, const uint8_t* has_mesh, uint32_t n_instances,
+                           hiprz_node* nodes_out, uint32_t max_nodes, uint32_t* n_nodes_out,
+                           uint32_t* order_out, uint32_t* n_order_out);
+/* Instance::calculateBoundingBox (instance.cpp:117-155) for an instance without group. */
+int hiprz_instance_bounds(const float* vertices, uint32_t n_vertices, hiprz_instance* inst);
+/* CoordSystem::applyRotation (RotatedXYZ; render_parts.cpp:51-56) and ::lookAt (:57-62). */
+void hiprz_axes_from_rotation(const float rotation[3], float x_axis[3], float y_axis[3], float z_axis[3]);
+void hiprz_axes_look_at(const float rotation[3], float x_axis[3], float y_axis[3], float z_axis[3]);
+
+/* seed table entry i (0..255) of pass `pass` for base seed `seed`: uniform in [-10, 10)
+ * (distribution of RayZath/cuda_kernel_data.cu:10-18, made deterministic). */
+float hiprz_seed_value(uint32_t seed, uint32_t pass, uint32_t i);
+
+const char* hiprz_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPRZ_H */

@@ -1,0 +1,932 @@
+// hiprz_api.hip — kernels + the device half of the C-ABI declared in include/hiprz.h.
+//
+// Replaces, for the HIPGPU backend, what the reference's CUDA backend does in
+// cuda_engine_core.cu (host<->device mirroring, readback), cuda_engine_renderer.cu
+// (launch sequence) and cuda_render_kernel.cu / cuda_postprocess_kernel.cu (kernels).
+// Written for gfx950 only: wave64, 256-thread workgroups = one 32x8-pixel tile.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hiprz.h"
+#include "hiprz_device.hpp"
+
+using namespace hiprz;
+
+// =======================================================================================
+// Kernels
+// =======================================================================================
+
+// One pass = one path segment per owned pixel: renderFirstPass (cpu_engine_kernel.cpp:15-57)
+// when FIRST, else renderCumulativePass (:58-101), with traceRay (:113-178) inlined.
+template <bool FIRST, bool COUNT, int MODE>
+__global__ void __launch_bounds__(256) rz_pass_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f) {
+    extern __shared__ uint32_t rz_lds[];
+    uint32_t* lds_column = rz_lds + threadIdx.x;
+    const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
+    Counters cnt;
+    if (p.active) {
+        const uint32_t pass = FIRST ? 0u : *f.pass;
+        const uint32_t pixel_idx = p.y * cam.width + p.x;
+
+        Ray ray;
+        col4 ray_color;
+        uint32_t ray_material;
+        uint32_t depth;
+        if constexpr (FIRST) {
+            generate_simple_ray(cam, ray, p.x, p.y);
+            ray_color = splat(1.0f);
+            ray_material = HIPRZ_MATERIAL_WORLD;
+            depth = 0u;
+        } else {
+            const float4 s0 = f.st0[p.local], s1 = f.st1[p.local];
+            const float2 s2 = f.st2[p.local];
+            const uint32_t bits = __float_as_uint(s2.y);
+            ray.o = V3(s0.x, s0.y, s0.z);
+            ray.d = normalized(V3(s0.w, s1.x, s1.y));  // SceneRay ctor normalises (cpu_render_utils.hpp:41-46)
+            ray.near_ = 0.0f, ray.far_ = RZ_FLT_MAX;
+            ray_color = col4{s1.z, s1.w, s2.x, 1.0f};
+            ray_material = bits & 0xFFFFu;
+            depth = (bits >> 16) & 0xFFu;
+            if (depth == 0u) ray.near_ = cam.near_, ray.far_ = cam.far_;
+        }
+        Rng rng(float(p.x) / float(cam.width), float(p.y) / float(cam.height),
+                seed_value(cfg.seed, pass, (pixel_idx + depth) & 255u));
+
+        // ---- traceRay ----
+        col4 final_color = splat(0.0f);
+        Surface sf;
+        sf.surface_material = sf.behind_material = HIPRZ_MATERIAL_WORLD;
+        sf.u = sf.v = 0.0f;
+        sf.normal = sf.mapped_normal = V3(0.0f, 0.0f, 0.0f);
+        sf.fresnel = 1.0f, sf.reflectance = 0.0f, sf.tint_factor = 0.0f, sf.refr_x = sf.refr_y = 0.0f;
+        sf.metalness = sf.roughness = 0.0f;
+
+        Hit hit;
+        const int found = closest_hit<MODE, COUNT>(s, lds_column, ray, hit, cnt);
+        Material m;
+        if (found == 2) {
+            analyze_intersection<COUNT>(s, hit, sf, m, cnt);
+        } else {
+            m = load_material(s, HIPRZ_MATERIAL_WORLD);
+            if (found == 1) {  // texcrd of the sky sphere (cpu_engine_kernel.cpp:292-295)
+                sf.u = -(0.5f + (RZ_ATAN2F(ray.d.z, ray.d.x) / (RZ_PI_F * 2.0f)));
+                sf.v = 0.5f + (RZ_ASINF(ray.d.y) / RZ_PI_F);
+            }
+        }
+        sf.surface_scattering = m.scattering;
+        // fetchColor / fetchEmission (:505-512, 523-528)
+        sf.color = from_u8(m.color);
+        if (m.texture >= 0) sf.color = fetch_rgba8<COUNT>(s, m.texture, sf.u, sf.v, cnt);
+        sf.color.a = 1.0f - sf.color.a;
+        sf.emission = m.emission_map >= 0 ? fetch_r32f<COUNT>(s, m.emission_map, sf.u, sf.v, cnt) : m.emission;
+        if (sf.emission > 0.0f) final_color = final_color + (ray_color * sf.color) * sf.emission;
+
+        v3 point = V3(0.0f, 0.0f, 0.0f), next_direction = V3(0.0f, 0.0f, 0.0f);
+        const float hit_distance = ray.far_;
+        if (found != 2) {
+            depth = 255u;  // TracingState::endPath
+        } else {
+            RZ_COUNT(hits);
+            depth += 1u;
+            sf.metalness = m.metalness_map >= 0 ? fetch_r8<COUNT>(s, m.metalness_map, sf.u, sf.v, cnt) : m.metalness;
+            sf.roughness = m.roughness_map >= 0 ? fetch_r8<COUNT>(s, m.roughness_map, sf.u, sf.v, cnt) : m.roughness;
+            sf.fresnel = fresnel_specular_ratio(sf.mapped_normal, ray.d, material_ior(s, ray_material),
+                                                material_ior(s, sf.behind_material), sf.refr_x, sf.refr_y);
+            sf.reflectance = lerpf(sf.fresnel, 1.0f, sf.metalness);
+
+            const uint32_t incoming_material = ray_material;
+            next_direction = sample_direction(ray.d, ray_material, sf, rng);
+            point = (ray.o + ray.d * ray.far_) + sf.normal * (0.0001f * ray.far_);
+            (void)incoming_material;
+
+            const col4 direct = direct_illumination<MODE, COUNT>(s, cfg, lds_column, ray.d, ray_material, point,
+                                                                 next_direction, sf, rng, cnt);
+            final_color = final_color + (direct * ray_color) * lerp(splat(1.0f), sf.color, sf.metalness);
+            ray_color = lerp(ray_color, ray_color * sf.color, sf.tint_factor);  // ColorF::Blend
+        }
+        const bool path_continues = depth < cfg.max_depth;
+
+        // ---- accumulate ----
+        col4 value;
+        if constexpr (FIRST) {
+            f.depth[p.local] = hit_distance;
+            value = col4{final_color.r, final_color.g, final_color.b, float(!path_continues)};
+        } else {
+            const float4 acc = f.accum[p.local];
+            value = col4{acc.x + final_color.r, acc.y + final_color.g, acc.z + final_color.b, acc.w + float(!path_continues)};
+        }
+        f.accum[p.local] = make_float4(value.r, value.g, value.b, value.a);
+
+        // ---- next segment ----
+        if (path_continues) {  // TracingResult::repositionRay
+            ray.o = point;
+            ray.d = next_direction;
+        } else {
+            RZ_COUNT(finished);
+            generate_antialiased_ray(cam, ray, p.x, p.y, rng);
+            ray_material = HIPRZ_MATERIAL_WORLD;
+            ray_color = splat(1.0f);
+            depth = 0u;
+        }
+        f.st0[p.local] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
+        f.st1[p.local] = make_float4(ray.d.y, ray.d.z, ray_color.r, ray_color.g);
+        f.st2[p.local] = make_float2(ray_color.b, __uint_as_float((ray_material & 0xFFFFu) | (depth << 16)));
+    }
+    if constexpr (COUNT) {
+        uint32_t v[8] = {p.active ? 1u : 0u, cnt.box_tests,     cnt.tri_tests,     cnt.hits,
+                         cnt.shadow_rays,    cnt.light_samples, cnt.texel_fetches, cnt.finished};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t x = v[k];
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+            if ((threadIdx.x & 63u) == 0u && x) atomicAdd(&f.counters[k], (unsigned long long)x);
+        }
+    }
+}
+
+// passUpdate / segmentUpdate (cuda_postprocess_kernel.cu:95-104, cuda_render_kernel.cu:122-129):
+// the pass index lives on the device so a captured graph replays without new arguments.
+__global__ void rz_pass_update_kernel(uint32_t* pass) { *pass += 1u; }
+__global__ void rz_pass_reset_kernel(uint32_t* pass) { *pass = 0u; }
+
+// toneMap (cuda_postprocess_kernel.cu:38-93; CPU: cpu_engine_renderer.cpp:224-235)
+__global__ void __launch_bounds__(256) rz_tonemap_tiles_kernel(const float4* accum, uint32_t* rgba8, uint32_t n, float aperture,
+                                                               float exposure_time) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = accum[i];
+    rgba8[i] = tonemap(col4{a.x, a.y, a.z, a.w}, aperture, exposure_time);
+}
+__global__ void __launch_bounds__(256) rz_tonemap_image_kernel(const float4* image, uint32_t* rgba8, uint32_t n, float aperture,
+                                                               float exposure_time) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = image[i];
+    rgba8[i] = tonemap(col4{a.x, a.y, a.z, a.w}, aperture, exposure_time);
+}
+
+// tile-major (owned tiles of shard rank/world) -> row-major full frame
+template <typename T>
+__global__ void __launch_bounds__(256) rz_untile_kernel(const T* tiles, T* image, uint32_t width, uint32_t height,
+                                                        uint32_t tiles_x, uint32_t rank, uint32_t world) {
+    const uint32_t tile = blockIdx.x * world + rank;
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    if (x < width && y < height) image[size_t(y) * width + x] = tiles[size_t(blockIdx.x) * 256u + threadIdx.x];
+}
+__global__ void __launch_bounds__(256) rz_untile_state_kernel(const float4* st0, const float4* st1, const float2* st2, float* ray9,
+                                                              uint32_t* md2, uint32_t width, uint32_t height, uint32_t tiles_x,
+                                                              uint32_t rank, uint32_t world) {
+    const uint32_t tile = blockIdx.x * world + rank;
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    if (x >= width || y >= height) return;
+    const size_t i = size_t(blockIdx.x) * 256u + threadIdx.x, o = size_t(y) * width + x;
+    const float4 a = st0[i], b = st1[i];
+    const float2 c = st2[i];
+    float* r = ray9 + 9 * o;
+    r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w, r[8] = c.x;
+    const uint32_t bits = __float_as_uint(c.y);
+    md2[2 * o] = bits & 0xFFFFu;
+    md2[2 * o + 1] = (bits >> 16) & 0xFFu;
+}
+
+// Kernel::rayCast (cpu_engine_kernel.cpp:102-111, 483-501): one thread.
+__global__ void rz_pick_kernel(const DScene s, const DCamera cam, uint32_t x, uint32_t y, float depth, int32_t* out2) {
+    extern __shared__ uint32_t rz_lds[];
+    Ray ray;
+    generate_simple_ray(cam, ray, x, y);
+    ray.near_ = depth * 0.99f;
+    ray.far_ = depth * 1.01f;
+    Hit hit;
+    Counters cnt;
+    out2[0] = out2[1] = -1;
+    if (closest_hit<0, false>(s, rz_lds, ray, hit, cnt) == 2) {
+        const uint32_t inst = uint32_t(hit.instance);
+        const uint32_t material_base = __float_as_uint(s.instances[7 * inst + 1].w);
+        const uint32_t material_count = __float_as_uint(s.instances[7 * inst + 2].w);
+        uint32_t slot = __float_as_uint(s.tris[3 * hit.triangle].w) & HIPRZ_TRI_MATERIAL_MASK;
+        if (slot > 63u) slot = 63u;
+        out2[0] = hit.instance;
+        out2[1] = slot < material_count ? s.inst_materials[material_base + slot] : -1;
+    }
+}
+
+// =======================================================================================
+// Host side of the context
+// =======================================================================================
+namespace {
+
+thread_local std::string g_create_error;
+
+// Timer/TimeTable of the reference (engine_parts.hpp:34-74): last + EMA(0.05) per stage.
+struct TimeTable {
+    struct Entry {
+        std::string name;
+        double last_ms = 0, avg_ms = 0;
+        bool seen = false;
+    };
+    std::vector<Entry> entries;
+    void set(const char* name, double ms) {
+        for (auto& e : entries)
+            if (e.name == name) {
+                e.last_ms = ms;
+                e.avg_ms = e.seen ? e.avg_ms + (ms - e.avg_ms) * 0.05 : ms;
+                e.seen = true;
+                return;
+            }
+        entries.push_back({name, ms, ms, true});
+    }
+    std::string str() const {
+        std::string out;
+        char line[160];
+        for (const auto& e : entries) {
+            std::snprintf(line, sizeof line, "%-22s %9.3fms (avg %9.3fms)\n", e.name.c_str(), e.last_ms, e.avg_ms);
+            out += line;
+        }
+        return out;
+    }
+};
+struct StageTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+template <typename T>
+struct DeviceArray {
+    T* ptr = nullptr;
+    size_t count = 0;
+    hipError_t assign(const T* src, size_t n, hipStream_t stream) {
+        if (n > count || !ptr) {
+            if (ptr) (void)hipFree(ptr);
+            ptr = nullptr;
+            count = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), sizeof(T) * (n ? n : 1));
+            if (e != hipSuccess) return e;
+            count = n ? n : 1;
+        }
+        if (n) return hipMemcpyAsync(ptr, src, sizeof(T) * n, hipMemcpyHostToDevice, stream);
+        return hipSuccess;
+    }
+    hipError_t resize(size_t n) {
+        if (n <= count && ptr) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), sizeof(T) * (n ? n : 1));
+        if (e == hipSuccess) count = n ? n : 1;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+};
+
+}  // namespace
+
+struct hiprz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    TimeTable timings;
+
+    // scene mirror
+    DeviceArray<hiprz_node> nodes;
+    DeviceArray<uint32_t> skip;
+    DeviceArray<uint32_t> tlas_order;
+    DeviceArray<hiprz_tri> tris;
+    DeviceArray<hiprz_tri_attr> tri_attrs;
+    DeviceArray<hiprz_instance> instances;
+    DeviceArray<int32_t> inst_materials;
+    DeviceArray<hiprz_material> materials;
+    DeviceArray<hiprz_texture> textures;
+    DeviceArray<uint8_t> texels;
+    DeviceArray<hiprz_spot_light> spot_lights;
+    DeviceArray<hiprz_direct_light> direct_lights;
+    DScene dscene{};
+    bool have_scene = false;
+    uint32_t stack_entries = 2;  // LDS stack entries per lane the trees need (MODE 1)
+
+    // camera + per-pixel state
+    hiprz_camera camera{};
+    DCamera dcamera{};
+    bool have_camera = false;
+    uint32_t rank = 0, world = 1;
+    uint32_t tiles_x = 0, tiles_y = 0, n_local_tiles = 0;
+    uint64_t owned_pixels = 0;
+    DeviceArray<float4> st0, st1, accum;
+    DeviceArray<float2> st2;
+    DeviceArray<float> depth;
+    DeviceArray<uint32_t> rgba8;
+    DeviceArray<float4> image_f4;  // row-major staging for readback
+    DeviceArray<uint32_t> state_md;
+    DeviceArray<float> state_ray;
+    DeviceArray<uint32_t> pass_dev;
+    DeviceArray<unsigned long long> counters_dev;
+    DeviceArray<int32_t> pick_dev;
+
+    hiprz_config config{8u, 8u, 1u, 1u, 20240501u};
+    bool reset_pending = true;
+    uint32_t passes = 0;
+    uint64_t ray_count = 0;
+    int traversal_mode = 0;
+
+    // kernel timing (hip events on `stream` around each render batch)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    std::vector<uint32_t> pending_launches;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+int fail(hiprz_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+#define RZ_HIP(ctx, call)                                                                                       \
+    do {                                                                                                        \
+        hipError_t rz_e = (call);                                                                               \
+        if (rz_e != hipSuccess)                                                                                 \
+            return fail(ctx, HIPRZ_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(rz_e));           \
+    } while (0)
+
+struct TreeCheck {
+    const hiprz_scene* sc;
+    std::vector<uint32_t>& skip;
+    std::vector<uint8_t> visited;
+    uint32_t max_depth = 0;
+    std::string error;
+
+    // Walks one tree from `root`, verifies every index it will make the kernel follow, fills
+    // the skip links, returns false on the first violation.  `is_world`: leaves index tlas_order.
+    bool walk(uint32_t root, bool is_world) {
+        struct Item {
+            uint32_t node, skip, depth;
+        };
+        std::vector<Item> stack{{root, RZ_END, 1u}};
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            if (it.node >= sc->n_nodes) return err("node index out of range");
+            if (visited[it.node]) return err("node reachable twice (trees must be disjoint and acyclic)");
+            visited[it.node] = 1;
+            skip[it.node] = it.skip;
+            if (it.depth > max_depth) max_depth = it.depth;
+            if (it.depth > 64u) return err("tree deeper than 64 levels");
+            const hiprz_node& n = sc->nodes[it.node];
+            if (n.meta & HIPRZ_NODE_LEAF) {
+                const uint64_t end = uint64_t(n.begin) + (n.meta & HIPRZ_NODE_COUNT_MASK);
+                if (end > (is_world ? sc->n_tlas_order : sc->n_tris)) return err("leaf range out of bounds");
+            } else {
+                if (uint64_t(n.begin) + 1 >= sc->n_nodes) return err("child index out of range");
+                stack.push_back({n.begin + 1, it.skip, it.depth + 1});
+                stack.push_back({n.begin, n.begin + 1, it.depth + 1});
+            }
+        }
+        return true;
+    }
+    bool err(const char* m) {
+        error = m;
+        return false;
+    }
+};
+
+void release_frame(hiprz_ctx* c) {
+    c->st0.release(), c->st1.release(), c->st2.release(), c->accum.release(), c->depth.release(), c->rgba8.release();
+    c->image_f4.release(), c->state_md.release(), c->state_ray.release();
+}
+
+int allocate_frame(hiprz_ctx* c) {
+    const uint32_t W = c->camera.width, H = c->camera.height;
+    c->tiles_x = (W + 31u) / 32u;
+    c->tiles_y = (H + 7u) / 8u;
+    const uint32_t n_tiles = c->tiles_x * c->tiles_y;
+    c->n_local_tiles = c->rank < n_tiles ? (n_tiles - c->rank + c->world - 1u) / c->world : 0u;
+    // owned active pixels (ray counter of this shard)
+    uint64_t owned = 0;
+    for (uint32_t lt = 0; lt < c->n_local_tiles; ++lt) {
+        const uint32_t t = lt * c->world + c->rank, tx = t % c->tiles_x, ty = t / c->tiles_x;
+        const uint32_t w = std::min(32u, W - tx * 32u), h = std::min(8u, H - ty * 8u);
+        owned += uint64_t(w) * h;
+    }
+    c->owned_pixels = owned;
+    const size_t n = size_t(c->n_local_tiles) * 256u;
+    RZ_HIP(c, c->st0.resize(n));
+    RZ_HIP(c, c->st1.resize(n));
+    RZ_HIP(c, c->st2.resize(n));
+    RZ_HIP(c, c->accum.resize(n));
+    RZ_HIP(c, c->depth.resize(n));
+    RZ_HIP(c, c->rgba8.resize(n));
+    RZ_HIP(c, c->image_f4.resize(size_t(W) * H));
+    if (n) {
+        RZ_HIP(c, hipMemsetAsync(c->accum.ptr, 0, n * sizeof(float4), c->stream));
+        RZ_HIP(c, hipMemsetAsync(c->depth.ptr, 0, n * sizeof(float), c->stream));
+        RZ_HIP(c, hipMemsetAsync(c->rgba8.ptr, 0, n * sizeof(uint32_t), c->stream));
+        RZ_HIP(c, hipMemsetAsync(c->st0.ptr, 0, n * sizeof(float4), c->stream));
+        RZ_HIP(c, hipMemsetAsync(c->st1.ptr, 0, n * sizeof(float4), c->stream));
+        RZ_HIP(c, hipMemsetAsync(c->st2.ptr, 0, n * sizeof(float2), c->stream));
+    }
+    return HIPRZ_OK;
+}
+
+DFrame make_frame(hiprz_ctx* c, bool counted) {
+    DFrame f{};
+    f.st0 = c->st0.ptr, f.st1 = c->st1.ptr, f.st2 = c->st2.ptr;
+    f.accum = c->accum.ptr, f.depth = c->depth.ptr, f.rgba8 = c->rgba8.ptr;
+    f.pass = c->pass_dev.ptr;
+    f.counters = counted ? c->counters_dev.ptr : nullptr;
+    f.tiles_x = c->tiles_x, f.rank = c->rank, f.world = c->world, f.n_local_tiles = c->n_local_tiles;
+    return f;
+}
+
+DConfig make_config(const hiprz_ctx* c) {
+    return DConfig{c->config.max_depth, c->config.spot_samples, c->config.direct_samples, c->config.seed};
+}
+
+template <bool FIRST, bool COUNT>
+void launch_pass(hiprz_ctx* c, const DFrame& f) {
+    const dim3 grid(c->n_local_tiles), block(256);
+    const DConfig cfg = make_config(c);
+    if (c->traversal_mode == 1) {
+        const size_t lds = size_t(c->stack_entries) * 256u * sizeof(uint32_t);
+        hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 1>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
+    } else {
+        hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 0>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f);
+    }
+}
+
+hipEvent_t take_event(hiprz_ctx* c) {
+    if (!c->event_pool.empty()) {
+        hipEvent_t e = c->event_pool.back();
+        c->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
+    if (!c->have_scene || !c->have_camera) return fail(c, HIPRZ_ERR_STATE, "render before scene and camera upload");
+    if (n_passes == 0 || c->n_local_tiles == 0) return HIPRZ_OK;
+    StageTimer timer;
+    const DFrame f = make_frame(c, counted);
+    hipEvent_t e0 = take_event(c), e1 = take_event(c);
+    RZ_HIP(c, hipEventRecord(e0, c->stream));
+    for (uint32_t i = 0; i < n_passes; ++i) {
+        if (c->reset_pending) {
+            hipLaunchKernelGGL(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+            if (counted) launch_pass<true, true>(c, f);
+            else launch_pass<true, false>(c, f);
+            c->reset_pending = false;
+            c->passes = 0;
+            c->ray_count = 0;
+        } else {
+            if (counted) launch_pass<false, true>(c, f);
+            else launch_pass<false, false>(c, f);
+        }
+        hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+        c->passes += 1;
+        c->ray_count += c->owned_pixels;  // traced_rays += W*H per pass (cpu_engine_renderer.cpp:173), per shard
+    }
+    RZ_HIP(c, hipEventRecord(e1, c->stream));
+    RZ_HIP(c, hipGetLastError());
+    if (c->pending_events.size() >= 4096) {  // nobody is collecting timings: recycle the oldest pair
+        c->event_pool.push_back(c->pending_events.front().first);
+        c->event_pool.push_back(c->pending_events.front().second);
+        c->pending_events.erase(c->pending_events.begin());
+        c->pending_launches.erase(c->pending_launches.begin());
+    }
+    c->pending_events.emplace_back(e0, e1);
+    c->pending_launches.push_back(n_passes);
+    c->timings.set("render (enqueue)", timer.ms());
+    return HIPRZ_OK;
+}
+
+template <typename T>
+int read_untiled(hiprz_ctx* c, const T* tiles, T* dst, size_t bytes, const char* what) {
+    if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "readback before camera upload");
+    const size_t n = size_t(c->camera.width) * c->camera.height;
+    if (!dst || bytes != n * sizeof(T)) return fail(c, HIPRZ_ERR_INVALID, std::string(what) + ": destination size mismatch");
+    StageTimer timer;
+    T* image = reinterpret_cast<T*>(c->image_f4.ptr);
+    RZ_HIP(c, hipMemsetAsync(image, 0, bytes, c->stream));
+    if (c->n_local_tiles)
+        hipLaunchKernelGGL((rz_untile_kernel<T>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, tiles, image,
+                           c->camera.width, c->camera.height, c->tiles_x, c->rank, c->world);
+    RZ_HIP(c, hipMemcpyAsync(dst, image, bytes, hipMemcpyDeviceToHost, c->stream));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    c->timings.set(what, timer.ms());
+    return HIPRZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hiprz_create(hiprz_ctx** out, int device_id) {
+    if (!out) return fail(nullptr, HIPRZ_ERR_INVALID, "hiprz_create: out is null");
+    *out = nullptr;
+    int n_devices = 0;
+    hipError_t e = hipGetDeviceCount(&n_devices);
+    if (e != hipSuccess || n_devices == 0)
+        return fail(nullptr, HIPRZ_ERR_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n_devices) return fail(nullptr, HIPRZ_ERR_INVALID, "hiprz_create: device id out of range");
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) return fail(nullptr, HIPRZ_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return fail(nullptr, HIPRZ_ERR_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, HIPRZ_ERR_DEVICE, std::string("hiprz is built for gfx950 only, device is ") + prop.gcnArchName);
+    auto* c = new hiprz_ctx();
+    c->device = device_id;
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = c->pass_dev.resize(1);
+    if (e == hipSuccess) e = c->counters_dev.resize(8);
+    if (e == hipSuccess) e = c->pick_dev.resize(2);
+    if (e == hipSuccess) e = hipMemsetAsync(c->pass_dev.ptr, 0, sizeof(uint32_t), c->stream);
+    if (e != hipSuccess) {
+        const std::string msg = std::string("context setup: ") + hipGetErrorString(e);
+        hiprz_destroy(c);
+        return fail(nullptr, HIPRZ_ERR_DEVICE, msg);
+    }
+    *out = c;
+    return HIPRZ_OK;
+}
+
+int hiprz_destroy(hiprz_ctx* c) {
+    if (!c) return HIPRZ_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->pending_events) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    c->nodes.release(), c->skip.release(), c->tlas_order.release(), c->tris.release(), c->tri_attrs.release();
+    c->instances.release(), c->inst_materials.release(), c->materials.release(), c->textures.release();
+    c->texels.release(), c->spot_lights.release(), c->direct_lights.release();
+    release_frame(c);
+    c->pass_dev.release(), c->counters_dev.release(), c->pick_dev.release();
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return HIPRZ_OK;
+}
+
+const char* hiprz_last_error(const hiprz_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!sc) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: scene is null");
+    StageTimer timer;
+    // ---- validate everything the kernels will dereference, on the host, before any launch ----
+    if (sc->n_materials < 2 || !sc->materials) return fail(c, HIPRZ_ERR_INVALID, "scene needs materials[0]=world, [1]=default");
+    if (sc->n_materials > 65536u) return fail(c, HIPRZ_ERR_INVALID, "more than 65536 materials");
+    if ((sc->n_nodes && !sc->nodes) || (sc->n_tris && (!sc->tris || !sc->tri_attrs)) || (sc->n_instances && !sc->instances) ||
+        (sc->n_tlas_order && !sc->tlas_order) || (sc->n_inst_materials && !sc->inst_materials) ||
+        (sc->n_textures && !sc->textures) || (sc->texel_bytes && !sc->texels) || (sc->n_spot_lights && !sc->spot_lights) ||
+        (sc->n_direct_lights && !sc->direct_lights))
+        return fail(c, HIPRZ_ERR_INVALID, "upload_scene: null array with non-zero count");
+    for (uint32_t i = 0; i < sc->n_textures; ++i) {
+        const hiprz_texture& t = sc->textures[i];
+        const uint64_t texel = t.kind == HIPRZ_TEX_R8 ? 1u : 4u;
+        if (t.kind > HIPRZ_TEX_R32F || t.width == 0 || t.height == 0 || (t.offset & 3u) ||
+            uint64_t(t.offset) + texel * t.width * t.height > sc->texel_bytes)
+            return fail(c, HIPRZ_ERR_INVALID, "texture " + std::to_string(i) + ": bad kind/size/offset");
+    }
+    auto tex_ok = [&](int32_t t, uint32_t kind) { return t < 0 || (uint32_t(t) < sc->n_textures && sc->textures[t].kind == kind); };
+    for (uint32_t i = 0; i < sc->n_materials; ++i) {
+        const hiprz_material& m = sc->materials[i];
+        if (!tex_ok(m.texture, HIPRZ_TEX_RGBA8) || !tex_ok(m.normal_map, HIPRZ_TEX_RGBA8) ||
+            !tex_ok(m.metalness_map, HIPRZ_TEX_R8) || !tex_ok(m.roughness_map, HIPRZ_TEX_R8) ||
+            !tex_ok(m.emission_map, HIPRZ_TEX_R32F))
+            return fail(c, HIPRZ_ERR_INVALID, "material " + std::to_string(i) + ": map index/kind invalid");
+    }
+    for (uint32_t i = 0; i < sc->n_inst_materials; ++i)
+        if (sc->inst_materials[i] >= int32_t(sc->n_materials))
+            return fail(c, HIPRZ_ERR_INVALID, "inst_materials[" + std::to_string(i) + "] out of range");
+    for (uint32_t i = 0; i < sc->n_tlas_order; ++i)
+        if (sc->tlas_order[i] >= sc->n_instances) return fail(c, HIPRZ_ERR_INVALID, "tlas_order entry out of range");
+    for (uint32_t i = 0; i < sc->n_instances; ++i) {
+        const hiprz_instance& in = sc->instances[i];
+        if (in.material_count > 64u || uint64_t(in.material_base) + in.material_count > sc->n_inst_materials)
+            return fail(c, HIPRZ_ERR_INVALID, "instance " + std::to_string(i) + ": material table out of range");
+    }
+    std::vector<uint32_t> skip(sc->n_nodes ? sc->n_nodes : 1, RZ_END);
+    TreeCheck check{sc, skip, std::vector<uint8_t>(sc->n_nodes ? sc->n_nodes : 1, 0)};
+    uint32_t world_depth = 0, mesh_depth = 0;
+    if (sc->n_instances) {
+        if (!check.walk(sc->tlas_root, true)) return fail(c, HIPRZ_ERR_INVALID, "world tree: " + check.error);
+        world_depth = check.max_depth;
+        std::vector<uint8_t> root_seen(sc->n_nodes, 0);
+        for (uint32_t i = 0; i < sc->n_tlas_order; ++i) {
+            const uint32_t root = sc->instances[sc->tlas_order[i]].blas_root;
+            if (root >= sc->n_nodes) return fail(c, HIPRZ_ERR_INVALID, "instance mesh root out of range");
+            if (root_seen[root]) continue;
+            root_seen[root] = 1;
+            check.max_depth = 0;
+            if (!check.walk(root, false)) return fail(c, HIPRZ_ERR_INVALID, "mesh tree: " + check.error);
+            mesh_depth = std::max(mesh_depth, check.max_depth);
+        }
+    }
+    c->stack_entries = world_depth + mesh_depth + 2u;
+
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, c->nodes.assign(sc->nodes, sc->n_nodes, c->stream));
+    RZ_HIP(c, c->skip.assign(skip.data(), sc->n_nodes, c->stream));
+    RZ_HIP(c, c->tlas_order.assign(sc->tlas_order, sc->n_tlas_order, c->stream));
+    RZ_HIP(c, c->tris.assign(sc->tris, sc->n_tris, c->stream));
+    RZ_HIP(c, c->tri_attrs.assign(sc->tri_attrs, sc->n_tris, c->stream));
+    RZ_HIP(c, c->instances.assign(sc->instances, sc->n_instances, c->stream));
+    RZ_HIP(c, c->inst_materials.assign(sc->inst_materials, sc->n_inst_materials, c->stream));
+    RZ_HIP(c, c->materials.assign(sc->materials, sc->n_materials, c->stream));
+    RZ_HIP(c, c->textures.assign(sc->textures, sc->n_textures, c->stream));
+    RZ_HIP(c, c->texels.assign(sc->texels, sc->texel_bytes, c->stream));
+    RZ_HIP(c, c->spot_lights.assign(sc->spot_lights, sc->n_spot_lights, c->stream));
+    RZ_HIP(c, c->direct_lights.assign(sc->direct_lights, sc->n_direct_lights, c->stream));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));  // `skip` and the caller's arrays may go away after return
+
+    DScene& d = c->dscene;
+    d.nodes = reinterpret_cast<const float4*>(c->nodes.ptr);
+    d.skip = c->skip.ptr;
+    d.tlas_order = c->tlas_order.ptr;
+    d.tris = reinterpret_cast<const float4*>(c->tris.ptr);
+    d.tri_attrs = reinterpret_cast<const float4*>(c->tri_attrs.ptr);
+    d.instances = reinterpret_cast<const float4*>(c->instances.ptr);
+    d.inst_materials = c->inst_materials.ptr;
+    d.materials = reinterpret_cast<const float4*>(c->materials.ptr);
+    d.textures = reinterpret_cast<const float4*>(c->textures.ptr);
+    d.texels = c->texels.ptr;
+    d.spot_lights = reinterpret_cast<const float4*>(c->spot_lights.ptr);
+    d.direct_lights = reinterpret_cast<const float4*>(c->direct_lights.ptr);
+    d.n_instances = sc->n_instances;
+    d.tlas_root = sc->tlas_root;
+    d.n_spot_lights = sc->n_spot_lights;
+    d.n_direct_lights = sc->n_direct_lights;
+    c->have_scene = true;
+    c->reset_pending = true;  // world changed => accumulation restarts (cpu_engine_renderer.cpp:108-112)
+    c->timings.set("upload scene", timer.ms());
+    return HIPRZ_OK;
+}
+
+int hiprz_upload_camera(hiprz_ctx* c, const hiprz_camera* cam) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!cam) return fail(c, HIPRZ_ERR_INVALID, "upload_camera: camera is null");
+    if (cam->width == 0 || cam->height == 0 || cam->width > 32768u || cam->height > 32768u)
+        return fail(c, HIPRZ_ERR_INVALID, "upload_camera: resolution must be 1..32768");
+    StageTimer timer;
+    (void)hipSetDevice(c->device);
+    const bool resized = !c->have_camera || cam->width != c->camera.width || cam->height != c->camera.height;
+    c->camera = *cam;
+    DCamera& d = c->dcamera;
+    std::memcpy(d.position, cam->position, 12);
+    std::memcpy(d.x_axis, cam->x_axis, 12);
+    std::memcpy(d.y_axis, cam->y_axis, 12);
+    std::memcpy(d.z_axis, cam->z_axis, 12);
+    d.width = cam->width, d.height = cam->height;
+    d.tan_half_fov = cam->tan_half_fov, d.aspect_ratio = cam->aspect_ratio;
+    d.near_ = cam->near_far[0], d.far_ = cam->near_far[1];
+    d.focal_distance = cam->focal_distance, d.aperture = cam->aperture, d.exposure_time = cam->exposure_time;
+    c->have_camera = true;
+    if (resized) {
+        const int rc = allocate_frame(c);
+        if (rc != HIPRZ_OK) return rc;
+    }
+    c->reset_pending = true;  // camera changed => context.reset (cpu_engine_renderer.cpp:108-112)
+    c->timings.set("upload camera", timer.ms());
+    return HIPRZ_OK;
+}
+
+int hiprz_set_config(hiprz_ctx* c, const hiprz_config* cfg) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!cfg) return fail(c, HIPRZ_ERR_INVALID, "set_config: config is null");
+    if (cfg->max_depth == 0 || cfg->max_depth > 254u) return fail(c, HIPRZ_ERR_INVALID, "max_depth must be 1..254 (u8, 255 = path ended)");
+    // The CPU kernel divides by sample_count/light_count and yields NaN for 0 samples
+    // (cpu_engine_kernel.cpp:742-743, 789-790); the CUDA backend clamps to >= 1 (cuda_kernel_data.cu:23-31).
+    if (cfg->spot_samples == 0 || cfg->direct_samples == 0 || cfg->spot_samples > 255u || cfg->direct_samples > 255u)
+        return fail(c, HIPRZ_ERR_INVALID, "light sample counts must be 1..255");
+    c->config = *cfg;
+    return HIPRZ_OK;
+}
+
+int hiprz_set_shard(hiprz_ctx* c, uint32_t rank, uint32_t world) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (world == 0 || rank >= world) return fail(c, HIPRZ_ERR_INVALID, "set_shard: need rank < world");
+    const bool changed = rank != c->rank || world != c->world;
+    c->rank = rank, c->world = world;
+    if (changed && c->have_camera) {
+        (void)hipSetDevice(c->device);
+        const int rc = allocate_frame(c);
+        if (rc != HIPRZ_OK) return rc;
+        c->reset_pending = true;
+    }
+    return HIPRZ_OK;
+}
+
+int hiprz_set_traversal_mode(hiprz_ctx* c, int mode) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (mode != 0 && mode != 1) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: 0 = threaded, 1 = LDS stack");
+    c->traversal_mode = mode;
+    return HIPRZ_OK;
+}
+
+int hiprz_reset(hiprz_ctx* c) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    c->reset_pending = true;
+    return HIPRZ_OK;
+}
+
+int hiprz_render(hiprz_ctx* c, uint32_t n_passes) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    return render_impl(c, n_passes, false);
+}
+
+int hiprz_render_counted(hiprz_ctx* c, uint32_t n_passes, hiprz_counters* out) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!out) return fail(c, HIPRZ_ERR_INVALID, "render_counted: out is null");
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, hipMemsetAsync(c->counters_dev.ptr, 0, 8 * sizeof(unsigned long long), c->stream));
+    const int rc = render_impl(c, n_passes, true);
+    if (rc != HIPRZ_OK) return rc;
+    unsigned long long v[8];
+    RZ_HIP(c, hipMemcpyAsync(v, c->counters_dev.ptr, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    out->segments = v[0], out->box_tests = v[1], out->tri_tests = v[2], out->hits = v[3];
+    out->shadow_rays = v[4], out->light_samples = v[5], out->texel_fetches = v[6], out->finished = v[7];
+    return HIPRZ_OK;
+}
+
+int hiprz_tonemap(hiprz_ctx* c) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "tonemap before camera upload");
+    (void)hipSetDevice(c->device);
+    const uint32_t n = c->n_local_tiles * 256u;
+    if (n)
+        hipLaunchKernelGGL(rz_tonemap_tiles_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->accum.ptr, c->rgba8.ptr, n,
+                           c->camera.aperture, c->camera.exposure_time);
+    RZ_HIP(c, hipGetLastError());
+    return HIPRZ_OK;
+}
+
+int hiprz_sync(hiprz_ctx* c) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    return HIPRZ_OK;
+}
+
+int hiprz_read_rgba8(hiprz_ctx* c, uint8_t* dst, size_t bytes) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    return read_untiled<uint32_t>(c, c->rgba8.ptr, reinterpret_cast<uint32_t*>(dst), bytes, "read rgba8");
+}
+int hiprz_read_depth(hiprz_ctx* c, float* dst, size_t bytes) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    return read_untiled<float>(c, c->depth.ptr, dst, bytes, "read depth");
+}
+int hiprz_read_accum(hiprz_ctx* c, float* dst, size_t bytes) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    return read_untiled<float4>(c, c->accum.ptr, reinterpret_cast<float4*>(dst), bytes, "read accum");
+}
+
+int hiprz_read_state(hiprz_ctx* c, float* ray9, uint32_t* md2, size_t n_pixels) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "readback before camera upload");
+    const size_t n = size_t(c->camera.width) * c->camera.height;
+    if (!ray9 || !md2 || n_pixels != n) return fail(c, HIPRZ_ERR_INVALID, "read_state: destination size mismatch");
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, c->state_ray.resize(9 * n));
+    RZ_HIP(c, c->state_md.resize(2 * n));
+    RZ_HIP(c, hipMemsetAsync(c->state_ray.ptr, 0, 9 * n * sizeof(float), c->stream));
+    RZ_HIP(c, hipMemsetAsync(c->state_md.ptr, 0, 2 * n * sizeof(uint32_t), c->stream));
+    if (c->n_local_tiles)
+        hipLaunchKernelGGL(rz_untile_state_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->st0.ptr, c->st1.ptr,
+                           c->st2.ptr, c->state_ray.ptr, c->state_md.ptr, c->camera.width, c->camera.height, c->tiles_x, c->rank,
+                           c->world);
+    RZ_HIP(c, hipMemcpyAsync(ray9, c->state_ray.ptr, 9 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RZ_HIP(c, hipMemcpyAsync(md2, c->state_md.ptr, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    return HIPRZ_OK;
+}
+
+int hiprz_ray_count(hiprz_ctx* c, uint64_t* out) {
+    if (!c || !out) return HIPRZ_ERR_INVALID;
+    *out = c->ray_count;
+    return HIPRZ_OK;
+}
+int hiprz_pass_count(hiprz_ctx* c, uint32_t* out) {
+    if (!c || !out) return HIPRZ_ERR_INVALID;
+    *out = c->passes;
+    return HIPRZ_OK;
+}
+
+int hiprz_local_pixel_capacity(hiprz_ctx* c, size_t* out) {
+    if (!c || !out) return HIPRZ_ERR_INVALID;
+    *out = size_t(c->n_local_tiles) * 256u;
+    return HIPRZ_OK;
+}
+int hiprz_export_accum_tiles(hiprz_ctx* c, void* dst_device, size_t bytes) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    const size_t need = size_t(c->n_local_tiles) * 256u * sizeof(float4);
+    if (!dst_device || bytes < need) return fail(c, HIPRZ_ERR_INVALID, "export_accum_tiles: destination too small");
+    (void)hipSetDevice(c->device);
+    if (need) RZ_HIP(c, hipMemcpyAsync(dst_device, c->accum.ptr, need, hipMemcpyDeviceToDevice, c->stream));
+    return HIPRZ_OK;
+}
+int hiprz_untile_accum(hiprz_ctx* c, const void* src_tiles, uint32_t rank, uint32_t world, void* dst_image) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "untile before camera upload");
+    if (!src_tiles || !dst_image || world == 0 || rank >= world) return fail(c, HIPRZ_ERR_INVALID, "untile_accum: bad arguments");
+    (void)hipSetDevice(c->device);
+    const uint32_t n_tiles = c->tiles_x * c->tiles_y;
+    const uint32_t n_local = rank < n_tiles ? (n_tiles - rank + world - 1u) / world : 0u;
+    if (n_local)
+        hipLaunchKernelGGL((rz_untile_kernel<float4>), dim3(n_local), dim3(256), 0, c->stream,
+                           reinterpret_cast<const float4*>(src_tiles), reinterpret_cast<float4*>(dst_image), c->camera.width,
+                           c->camera.height, c->tiles_x, rank, world);
+    RZ_HIP(c, hipGetLastError());
+    return HIPRZ_OK;
+}
+int hiprz_tonemap_image(hiprz_ctx* c, const void* src_image, void* dst_rgba8) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "tonemap before camera upload");
+    if (!src_image || !dst_rgba8) return fail(c, HIPRZ_ERR_INVALID, "tonemap_image: null pointer");
+    (void)hipSetDevice(c->device);
+    const uint32_t n = c->camera.width * c->camera.height;
+    hipLaunchKernelGGL(rz_tonemap_image_kernel, dim3((n + 255u) / 256u), dim3(256), 0, c->stream,
+                       reinterpret_cast<const float4*>(src_image), reinterpret_cast<uint32_t*>(dst_rgba8), n, c->camera.aperture,
+                       c->camera.exposure_time);
+    RZ_HIP(c, hipGetLastError());
+    return HIPRZ_OK;
+}
+void* hiprz_stream(hiprz_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
+
+int hiprz_pick(hiprz_ctx* c, uint32_t x, uint32_t y, int32_t* instance_out, int32_t* material_out) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!c->have_scene || !c->have_camera) return fail(c, HIPRZ_ERR_STATE, "pick before scene and camera upload");
+    if (!instance_out || !material_out) return fail(c, HIPRZ_ERR_INVALID, "pick: null output");
+    // Camera::rayCastPixel clamps (camera.cpp:161-167)
+    if (x >= c->camera.width) x = c->camera.width - 1;
+    if (y >= c->camera.height) y = c->camera.height - 1;
+    (void)hipSetDevice(c->device);
+    // depth of the pixel: only the shard that owns it can answer
+    const uint32_t tile = (y / 8u) * c->tiles_x + (x / 32u);
+    *instance_out = *material_out = -1;
+    if (tile % c->world != c->rank) return HIPRZ_OK;
+    const uint32_t lt = tile / c->world, in_tile = ((x % 32u) / 8u) * 64u + (y % 8u) * 8u + (x % 8u);
+    float depth = 0.0f;
+    RZ_HIP(c, hipMemcpyAsync(&depth, c->depth.ptr + size_t(lt) * 256u + in_tile, sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    hipLaunchKernelGGL(rz_pick_kernel, dim3(1), dim3(1), 0, c->stream, c->dscene, c->dcamera, x, y, depth, c->pick_dev.ptr);
+    int32_t out2[2] = {-1, -1};
+    RZ_HIP(c, hipMemcpyAsync(out2, c->pick_dev.ptr, sizeof out2, hipMemcpyDeviceToHost, c->stream));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    *instance_out = out2[0], *material_out = out2[1];
+    return HIPRZ_OK;
+}
+
+int hiprz_timings(hiprz_ctx* c, char* buf, size_t len) {
+    if (!c || !buf || len == 0) return HIPRZ_ERR_INVALID;
+    const std::string s = c->timings.str();
+    std::snprintf(buf, len, "%s", s.c_str());
+    return HIPRZ_OK;
+}
+
+int hiprz_kernel_time_ms(hiprz_ctx* c, double* total_ms, uint64_t* launches) {
+    if (!c || !total_ms || !launches) return HIPRZ_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    double total = 0;
+    uint64_t n = 0;
+    for (size_t i = 0; i < c->pending_events.size(); ++i) {
+        float ms = 0;
+        RZ_HIP(c, hipEventElapsedTime(&ms, c->pending_events[i].first, c->pending_events[i].second));
+        total += ms;
+        n += c->pending_launches[i];
+        c->event_pool.push_back(c->pending_events[i].first);
+        c->event_pool.push_back(c->pending_events[i].second);
+    }
+    c->pending_events.clear();
+    c->pending_launches.clear();
+    *total_ms = total, *launches = n;
+    if (n) c->timings.set("pass kernel (device)", total / double(n));
+    return HIPRZ_OK;
+}
+
+}  // extern "C"

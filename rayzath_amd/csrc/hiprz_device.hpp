@@ -1,0 +1,836 @@
+// hiprz_device.hpp — gfx950 device code of the path-tracing pass.
+//
+// One thread = one pixel = one path segment per pass, as in the reference
+// (RayZath/cpu_engine_kernel.cpp:15-101; RayZath/cuda_render_kernel.cu:7-121), but on a
+// flattened SoA scene (include/hiprz.h) and with a stack-free threaded walk of the two
+// trees (or, as a selectable variant, an LDS stack).  All arithmetic is fp32 and is spelled
+// operation by operation in the order of the CPU reference, compiled with
+// -ffp-contract=off, so that everything except libm-vs-ocml transcendentals is bit-equal
+// to the CPU result.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hiprz.h"
+
+namespace hiprz {
+
+#define RZ_DEV __device__ __forceinline__
+#define RZ_PI_F 3.14159265358979323846f
+#define RZ_END 0xFFFFFFFFu
+#define RZ_FLT_MAX 3.402823466e+38f
+
+#ifdef HIPRZ_PORTABLE_MATH
+#include "hiprz_portable_math.h"
+#define RZ_SINF(x) hiprz_pm_sinf(x)
+#define RZ_COSF(x) hiprz_pm_cosf(x)
+#define RZ_ACOSF(x) hiprz_pm_acosf(x)
+#define RZ_ASINF(x) hiprz_pm_asinf(x)
+#define RZ_ATAN2F(y, x) hiprz_pm_atan2f(y, x)
+#define RZ_POWF(x, y) hiprz_pm_powf(x, y)
+#define RZ_EXPF(x) hiprz_pm_expf(x)
+#else
+#define RZ_SINF(x) sinf(x)
+#define RZ_COSF(x) cosf(x)
+#define RZ_ACOSF(x) acosf(x)
+#define RZ_ASINF(x) asinf(x)
+#define RZ_ATAN2F(y, x) atan2f(y, x)
+#define RZ_POWF(x, y) powf(x, y)
+#define RZ_EXPF(x) expf(x)
+#endif
+
+// ---------------------------------------------------------------------------------------
+// Device-side views.  Every record array is addressed as float4 so a record is fetched
+// with 16-byte loads (node = 2, triangle = 3, triangle attributes = 6, instance = 7,
+// material = 3, texture = 3, spot light = 3, direct light = 2 float4).
+// ---------------------------------------------------------------------------------------
+struct DScene {
+    const float4* nodes;
+    const uint32_t* skip;  // threaded-walk link per node (derived on upload, see hiprz_api.hip)
+    const uint32_t* tlas_order;
+    const float4* tris;
+    const float4* tri_attrs;
+    const float4* instances;
+    const int32_t* inst_materials;
+    const float4* materials;
+    const float4* textures;
+    const uint8_t* texels;
+    const float4* spot_lights;
+    const float4* direct_lights;
+    uint32_t n_instances;
+    uint32_t tlas_root;
+    uint32_t n_spot_lights;
+    uint32_t n_direct_lights;
+};
+
+struct DCamera {
+    float position[3];
+    float x_axis[3], y_axis[3], z_axis[3];
+    uint32_t width, height;
+    float tan_half_fov, aspect_ratio;
+    float near_, far_;
+    float focal_distance, aperture, exposure_time;
+};
+
+struct DConfig {
+    uint32_t max_depth, spot_samples, direct_samples, seed;
+};
+
+// Per-pixel persistent state (CameraContext, cpu_engine_kernel.hpp:29-51), tile-major:
+// local pixel i = owned_tile * 256 + thread.  40 B of path state + 16 B accumulator.
+struct DFrame {
+    float4* st0;      // origin.xyz, direction.x
+    float4* st1;      // direction.yz, color.rg
+    float2* st2;      // color.b, bits(material | depth << 16)
+    float4* accum;    // RGBA32F, alpha = finished paths
+    float* depth;     // first-hit distance (first pass)
+    uint32_t* rgba8;  // tone-mapped output
+    const uint32_t* pass;  // device-resident pass index
+    unsigned long long* counters;  // 8 x u64 (hiprz_counters) or nullptr
+    uint32_t tiles_x;      // 32x8-pixel tiles per row
+    uint32_t rank, world;  // tile sharding
+    uint32_t n_local_tiles;
+};
+
+struct v3 {
+    float x, y, z;
+};
+struct col4 {
+    float r, g, b, a;
+};
+
+RZ_DEV v3 V3(float x, float y, float z) { return v3{x, y, z}; }
+RZ_DEV v3 ld3(const float* p) { return v3{p[0], p[1], p[2]}; }
+RZ_DEV v3 xyz(float4 f) { return v3{f.x, f.y, f.z}; }
+RZ_DEV v3 operator+(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RZ_DEV v3 operator-(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RZ_DEV v3 operator*(v3 a, v3 b) { return v3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RZ_DEV v3 operator/(v3 a, v3 b) { return v3{a.x / b.x, a.y / b.y, a.z / b.z}; }
+RZ_DEV v3 operator*(v3 a, float s) { return v3{a.x * s, a.y * s, a.z * s}; }
+RZ_DEV v3 operator/(v3 a, float s) { return v3{a.x / s, a.y / s, a.z / s}; }
+RZ_DEV v3 operator-(v3 a) { return v3{-a.x, -a.y, -a.z}; }
+RZ_DEV float dot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RZ_DEV v3 cross(v3 a, v3 b) { return v3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RZ_DEV float magnitude(v3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+RZ_DEV float rcp_magnitude(v3 a) { return 1.0f / magnitude(a); }
+RZ_DEV v3 normalized(v3 a) { return a * rcp_magnitude(a); }
+RZ_DEV float similarity(v3 a, v3 b) { return dot(a, b) * (rcp_magnitude(a) * rcp_magnitude(b)); }
+
+RZ_DEV col4 splat(float v) { return col4{v, v, v, v}; }
+RZ_DEV col4 from_u8(uint32_t rgba) {
+    return col4{float(rgba & 255u) / 255.0f, float((rgba >> 8) & 255u) / 255.0f, float((rgba >> 16) & 255u) / 255.0f,
+                float(rgba >> 24) / 255.0f};
+}
+RZ_DEV col4 operator+(col4 a, col4 b) { return col4{a.r + b.r, a.g + b.g, a.b + b.b, a.a + b.a}; }
+RZ_DEV col4 operator-(col4 a, col4 b) { return col4{a.r - b.r, a.g - b.g, a.b - b.b, a.a - b.a}; }
+RZ_DEV col4 operator*(col4 a, col4 b) { return col4{a.r * b.r, a.g * b.g, a.b * b.b, a.a * b.a}; }
+RZ_DEV col4 operator*(col4 a, float s) { return col4{a.r * s, a.g * s, a.b * s, a.a * s}; }
+RZ_DEV col4 div_scalar(col4 a, float s) { return a * (1.0f / s); }  // ColorF / float: reciprocal multiply
+RZ_DEV col4 operator/(col4 a, col4 b) { return col4{a.r / b.r, a.g / b.g, a.b / b.b, a.a / b.a}; }
+RZ_DEV float lerpf(float a, float b, float t) { return a + (b - a) * t; }
+RZ_DEV col4 lerp(col4 a, col4 b, float t) { return a + (b - a) * t; }
+
+// --- RNG: cpu_render_utils.cpp:8-27 -----------------------------------------------------
+struct Rng {
+    float a, b;
+    RZ_DEV Rng(float sx, float sy, float r) : a(sx + sy), b(r * 245.310913f) {}
+    RZ_DEV float unsignedUniform() {
+        const float af = (a + 0.2311362f) * (b + 13.054377f);
+        const float bf = (a + 251.78431f) + (b - 73.054312f);
+        a = af - float(int32_t(af));
+        b = bf - float(int32_t(bf));
+        return fabsf(b);
+    }
+    RZ_DEV float signedUniform() { return unsignedUniform() * 2.0f - 1.0f; }
+};
+RZ_DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+// entry i of the pass's 256-entry seed table (hiprz.h: hiprz_seed_value), computed in place
+RZ_DEV float seed_value(uint32_t seed, uint32_t pass, uint32_t i) {
+    uint32_t h = mix32(seed ^ mix32(pass + 0x9E3779B9u));
+    h = mix32(h ^ (i * 0x85EBCA6Bu + 1u));
+    return float(h >> 8) * (20.0f / 16777216.0f) - 10.0f;
+}
+
+struct Ray {
+    v3 o, d;
+    float near_, far_;
+};
+
+struct Counters {
+    uint32_t box_tests = 0, tri_tests = 0, hits = 0, shadow_rays = 0, light_samples = 0, texel_fetches = 0, finished = 0;
+};
+#define RZ_COUNT(field) \
+    if constexpr (COUNT) cnt.field++
+
+// --- BoundingBox::rayIntersection: render_parts.cpp:197-217 -----------------------------
+RZ_DEV float min_lt(float a, float b) { return a < b ? a : b; }
+RZ_DEV float max_gt(float a, float b) { return a > b ? a : b; }
+RZ_DEV bool box_hit(v3 mn, v3 mx, const Ray& r) {
+    const float t1 = (mn.x - r.o.x) / r.d.x;
+    const float t2 = (mx.x - r.o.x) / r.d.x;
+    const float t3 = (mn.y - r.o.y) / r.d.y;
+    const float t4 = (mx.y - r.o.y) / r.d.y;
+    const float t5 = (mn.z - r.o.z) / r.d.z;
+    const float t6 = (mx.z - r.o.z) / r.d.z;
+    const float tmin = max_gt(max_gt(min_lt(t1, t2), min_lt(t3, t4)), min_lt(t5, t6));
+    const float tmax = min_lt(min_lt(max_gt(t1, t2), max_gt(t3, t4)), max_gt(t5, t6));
+    return !(tmax < r.near_ || tmin > tmax || tmin > r.far_);
+}
+
+// --- Moller-Trumbore: mesh_component.cpp:52-114 -----------------------------------------
+RZ_DEV bool tri_hit(v3 v1, v3 v2, v3 vv3, const Ray& r, float& t_out, float& b1_out, float& b2_out, float& det_out) {
+    const v3 edge1 = v2 - v1;
+    const v3 edge2 = vv3 - v1;
+    const v3 pvec = cross(r.d, edge2);
+    float det = dot(edge1, pvec);
+    det += float(uint32_t(det > -1.0e-7f) & uint32_t(det < 1.0e-7f)) * 1.0e-7f;
+    const float inv_det = 1.0f / det;
+    const v3 tvec = r.o - v1;
+    const float b1 = dot(tvec, pvec) * inv_det;
+    if (b1 < 0.0f || b1 > 1.0f) return false;
+    const v3 qvec = cross(tvec, edge1);
+    const float b2 = dot(r.d, qvec) * inv_det;
+    if (b2 < 0.0f || b1 + b2 > 1.0f) return false;
+    const float t = dot(edge2, qvec) * inv_det;
+    if (t <= r.near_ || t >= r.far_) return false;
+    t_out = t, b1_out = b1, b2_out = b2, det_out = det;
+    return true;
+}
+
+struct Instance {
+    v3 position, scale, xa, ya, za, bb_min, bb_max;
+    uint32_t blas_root, material_base, material_count;
+};
+RZ_DEV void load_instance_box(const DScene& s, uint32_t i, v3& mn, v3& mx) {
+    mn = xyz(s.instances[7 * i + 5]);
+    mx = xyz(s.instances[7 * i + 6]);
+}
+struct InstanceXform {
+    v3 position, scale, xa, ya, za;
+    uint32_t blas_root;
+};
+RZ_DEV InstanceXform load_instance_xform(const DScene& s, uint32_t i) {
+    const float4 a = s.instances[7 * i + 0], b = s.instances[7 * i + 1], c = s.instances[7 * i + 2],
+                 d = s.instances[7 * i + 3], e = s.instances[7 * i + 4];
+    InstanceXform x;
+    x.position = xyz(a), x.blas_root = __float_as_uint(a.w);
+    x.scale = xyz(b);
+    x.xa = xyz(c), x.ya = xyz(d), x.za = xyz(e);
+    return x;
+}
+// CoordSystem::transformForward / transformBackward: render_parts.cpp:42-50
+RZ_DEV v3 transform_forward(v3 xa, v3 ya, v3 za, v3 v) { return xa * v.x + ya * v.y + za * v.z; }
+RZ_DEV v3 transform_backward(v3 xa, v3 ya, v3 za, v3 v) {
+    return v3{xa.x * v.x + xa.y * v.y + xa.z * v.z, ya.x * v.x + ya.y * v.y + ya.z * v.z,
+              za.x * v.x + za.y * v.y + za.z * v.z};
+}
+// Transformation::transformG2L (render_parts.cpp:117-125) + the range rescale of
+// cpu_engine_kernel.cpp:307-312 / :442-445.  Returns the length factor.
+RZ_DEV float to_local(const InstanceXform& x, const Ray& g, Ray& l) {
+    l.o = g.o - x.position;
+    l.o = transform_backward(x.xa, x.ya, x.za, l.o);
+    l.o = l.o / x.scale;
+    l.d = transform_backward(x.xa, x.ya, x.za, g.d);
+    l.d = l.d / x.scale;
+    const float len = magnitude(l.d);
+    l.near_ = g.near_ * len;
+    l.far_ = g.far_ * len;
+    l.d = normalized(l.d);
+    return len;
+}
+
+// ---------------------------------------------------------------------------------------
+// Tree walk.  The reference descends depth-first, first child then second, testing a
+// node's box when it is entered (cpu_engine_kernel.cpp:254-277, 331-352) — a FIXED order,
+// so the walk needs no stack: every node carries a `skip` link to the node that follows
+// its subtree in that order.  MODE 0 = threaded (skip links, registers only);
+// MODE 1 = explicit stack in LDS (one column per lane, level-major so lanes on the same
+// level hit distinct banks).  Both visit the same nodes in the same order.
+// ---------------------------------------------------------------------------------------
+template <int MODE>
+struct Walk {
+    uint32_t* stack;  // LDS column of this lane (MODE 1)
+    uint32_t sp;
+    RZ_DEV explicit Walk(uint32_t* lds_column) : stack(lds_column), sp(0) {}
+    RZ_DEV uint32_t mark() const { return sp; }
+    // subtree of n finished (box missed or leaf done): next node in depth-first order
+    RZ_DEV uint32_t next(const DScene& s, uint32_t n, uint32_t base) {
+        if constexpr (MODE == 0) {
+            (void)base;
+            return s.skip[n];
+        } else {
+            (void)n;
+            if (sp == base) return RZ_END;
+            sp -= 1;
+            return stack[sp * blockDim.x];
+        }
+    }
+    // enter inner node: go to first child, remember the second
+    RZ_DEV uint32_t descend(uint32_t first_child) {
+        if constexpr (MODE == 1) {
+            stack[sp * blockDim.x] = first_child + 1u;
+            sp += 1;
+        }
+        return first_child;
+    }
+};
+
+struct Hit {
+    int32_t instance;  // -1 = none
+    uint32_t triangle;
+    float bx, by;
+    bool external;
+};
+
+// closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352
+template <int MODE, bool COUNT>
+RZ_DEV bool closest_in_mesh(const DScene& s, Walk<MODE>& w, uint32_t root, Ray& lr, Hit& hit, Counters& cnt) {
+    bool found = false;
+    const uint32_t base = w.mark();
+    uint32_t n = root;
+    while (n != RZ_END) {
+        const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
+        RZ_COUNT(box_tests);
+        if (box_hit(xyz(n0), v3{n0.w, n1.x, n1.y}, lr)) {
+            const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+            if (!(meta & HIPRZ_NODE_LEAF)) {
+                n = w.descend(begin);
+                continue;
+            }
+            const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
+            for (uint32_t i = begin; i < end; ++i) {
+                const float4 a = s.tris[3 * i], b = s.tris[3 * i + 1], c = s.tris[3 * i + 2];
+                float t, b1, b2, det;
+                RZ_COUNT(tri_tests);
+                if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
+                    lr.far_ = t;
+                    hit.triangle = i;
+                    hit.external = det > 0.0f;
+                    hit.bx = b1, hit.by = b2;
+                    found = true;
+                }
+            }
+        }
+        n = w.next(s, n, base);
+    }
+    return found;
+}
+
+// traverseWorld + closestIntersection(instance): cpu_engine_kernel.cpp:254-330.
+// Returns 0 = no instances / root box missed (the reference returns before it computes the
+// sky texcrd, :282-283), 1 = walked, nothing hit (sky texcrd is computed, :292-295), 2 = hit.
+template <int MODE, bool COUNT>
+RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit, Counters& cnt) {
+    hit.instance = -1;
+    hit.triangle = 0;
+    hit.bx = hit.by = 0.0f;
+    hit.external = true;
+    if (s.n_instances == 0) return 0;
+    Walk<MODE> w(lds_column);
+    uint32_t n = s.tlas_root;
+    while (n != RZ_END) {
+        const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
+        RZ_COUNT(box_tests);
+        if (box_hit(xyz(n0), v3{n0.w, n1.x, n1.y}, ray)) {
+            const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+            if (!(meta & HIPRZ_NODE_LEAF)) {
+                n = w.descend(begin);
+                continue;
+            }
+            const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
+            for (uint32_t i = begin; i < end; ++i) {
+                const uint32_t inst = s.tlas_order[i];
+                v3 mn, mx;
+                load_instance_box(s, inst, mn, mx);
+                RZ_COUNT(box_tests);
+                if (!box_hit(mn, mx, ray)) continue;
+                const InstanceXform x = load_instance_xform(s, inst);
+                Ray lr;
+                const float len = to_local(x, ray, lr);
+                if (closest_in_mesh<MODE, COUNT>(s, w, x.blas_root, lr, hit, cnt)) {
+                    hit.instance = int32_t(inst);
+                    ray.near_ = lr.near_ / len;
+                    ray.far_ = lr.far_ / len;
+                }
+            }
+        } else if (n == s.tlas_root) {
+            return 0;  // root box missed (cpu_engine_kernel.cpp:283)
+        }
+        n = w.next(s, n, 0u);
+    }
+    return hit.instance >= 0 ? 2 : 1;
+}
+
+// anyIntersection: cpu_engine_kernel.cpp:398-481.  The mask is 1 or 0 ("TODO: texture
+// fetch" :465), so a bool is carried: true = occluded.  Returns the mask alpha.
+template <int MODE, bool COUNT>
+RZ_DEV float any_hit(const DScene& s, uint32_t* lds_column, const Ray& ray, Counters& cnt) {
+    RZ_COUNT(shadow_rays);
+    if (s.n_instances == 0) return 0.0f;
+    Walk<MODE> w(lds_column);
+    uint32_t n = s.tlas_root;
+    while (n != RZ_END) {
+        const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
+        RZ_COUNT(box_tests);
+        if (box_hit(xyz(n0), v3{n0.w, n1.x, n1.y}, ray)) {
+            const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+            if (!(meta & HIPRZ_NODE_LEAF)) {
+                n = w.descend(begin);
+                continue;
+            }
+            const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
+            for (uint32_t i = begin; i < end; ++i) {
+                const uint32_t inst = s.tlas_order[i];
+                v3 mn, mx;
+                load_instance_box(s, inst, mn, mx);
+                RZ_COUNT(box_tests);
+                if (!box_hit(mn, mx, ray)) continue;
+                const InstanceXform x = load_instance_xform(s, inst);
+                Ray lr;
+                to_local(x, ray, lr);
+                // anyIntersection(const Mesh&, ...) :450-481
+                const uint32_t base = w.mark();
+                uint32_t m = x.blas_root;
+                while (m != RZ_END) {
+                    const float4 m0 = s.nodes[2 * m], m1 = s.nodes[2 * m + 1];
+                    RZ_COUNT(box_tests);
+                    if (box_hit(xyz(m0), v3{m0.w, m1.x, m1.y}, lr)) {
+                        const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
+                        if (!(mmeta & HIPRZ_NODE_LEAF)) {
+                            m = w.descend(mbegin);
+                            continue;
+                        }
+                        const uint32_t mend = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
+                        for (uint32_t j = mbegin; j < mend; ++j) {
+                            const float4 a = s.tris[3 * j], b = s.tris[3 * j + 1], c = s.tris[3 * j + 2];
+                            float t, b1, b2, det;
+                            RZ_COUNT(tri_tests);
+                            if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) return 0.0f;
+                        }
+                    }
+                    m = w.next(s, m, base);
+                }
+            }
+        } else if (n == s.tlas_root) {
+            return 1.0f;  // root box missed (:402)
+        }
+        n = w.next(s, n, 0u);
+    }
+    return 1.0f;
+}
+
+// --- materials and textures -------------------------------------------------------------
+struct Material {
+    uint32_t color;
+    float metalness, roughness, emission, ior, scattering;
+    int32_t texture, normal_map, metalness_map, roughness_map, emission_map;
+};
+RZ_DEV Material load_material(const DScene& s, uint32_t i) {
+    const float4 a = s.materials[3 * i], b = s.materials[3 * i + 1], c = s.materials[3 * i + 2];
+    Material m;
+    m.color = __float_as_uint(a.x), m.metalness = a.y, m.roughness = a.z, m.emission = a.w;
+    m.ior = b.x, m.scattering = b.y, m.texture = __float_as_int(b.z), m.normal_map = __float_as_int(b.w);
+    m.metalness_map = __float_as_int(c.x), m.roughness_map = __float_as_int(c.y), m.emission_map = __float_as_int(c.z);
+    return m;
+}
+RZ_DEV float material_ior(const DScene& s, uint32_t i) { return s.materials[3 * i + 1].x; }
+RZ_DEV float material_scattering(const DScene& s, uint32_t i) { return s.materials[3 * i + 1].y; }
+
+// TextureBuffer::fetch: render_parts.hpp:209-221 — returns the byte offset of the texel
+template <bool COUNT>
+RZ_DEV size_t texel_offset(const DScene& s, int32_t tex, float u, float v, uint32_t texel_size, Counters& cnt) {
+    const float4 a = s.textures[3 * tex], b = s.textures[3 * tex + 1], c = s.textures[3 * tex + 2];
+    const uint32_t width = __float_as_uint(a.y), height = __float_as_uint(a.z), offset = __float_as_uint(a.w);
+    u += b.z;  // translation
+    v += b.w;
+    {
+        const float xx = u * c.y - v * c.z;  // cos, sin of the rotation (hoisted)
+        const float yy = u * c.z + v * c.y;
+        u = xx, v = yy;
+    }
+    u *= b.x;  // scale
+    v *= b.y;
+    u = fmodf(fmodf(u, 1.0f) + 1.0f, 1.0f);
+    v = 1.0f - fmodf(fmodf(v, 1.0f) + 1.0f, 1.0f);
+    uint32_t x = uint32_t(u * float(width));
+    uint32_t y = uint32_t(v * float(height));
+    if (x > width - 1u) x = width - 1u;
+    if (y > height - 1u) y = height - 1u;
+    RZ_COUNT(texel_fetches);
+    return size_t(offset) + size_t(texel_size) * (size_t(y) * width + x);
+}
+template <bool COUNT>
+RZ_DEV col4 fetch_rgba8(const DScene& s, int32_t tex, float u, float v, Counters& cnt) {
+    return from_u8(*reinterpret_cast<const uint32_t*>(s.texels + texel_offset<COUNT>(s, tex, u, v, 4u, cnt)));
+}
+template <bool COUNT>
+RZ_DEV float fetch_r8(const DScene& s, int32_t tex, float u, float v, Counters& cnt) {
+    return float(s.texels[texel_offset<COUNT>(s, tex, u, v, 1u, cnt)]) / 255.0f;
+}
+template <bool COUNT>
+RZ_DEV float fetch_r32f(const DScene& s, int32_t tex, float u, float v, Counters& cnt) {
+    return *reinterpret_cast<const float*>(s.texels + texel_offset<COUNT>(s, tex, u, v, 4u, cnt));
+}
+
+struct Surface {
+    uint32_t surface_material, behind_material;
+    float u, v;
+    v3 normal, mapped_normal;
+    col4 color;
+    float metalness, roughness, emission;
+    float fresnel, reflectance, tint_factor;
+    float refr_x, refr_y;
+    float surface_scattering;  // surface_material->scattering(), read with the material
+};
+
+// analyzeIntersection: cpu_engine_kernel.cpp:354-395; mesh_component.cpp:115-167
+template <bool COUNT>
+RZ_DEV void analyze_intersection(const DScene& s, const Hit& hit, Surface& sf, Material& m, Counters& cnt) {
+    const uint32_t inst = uint32_t(hit.instance);
+    const float4 i0 = s.instances[7 * inst + 0], i1 = s.instances[7 * inst + 1], i2 = s.instances[7 * inst + 2],
+                 i3 = s.instances[7 * inst + 3], i4 = s.instances[7 * inst + 4];
+    const v3 scale = xyz(i1), xa = xyz(i2), ya = xyz(i3), za = xyz(i4);
+    const uint32_t material_base = __float_as_uint(i1.w), material_count = __float_as_uint(i2.w);
+
+    const float4 ta = s.tris[3 * hit.triangle], tb = s.tris[3 * hit.triangle + 1], tc = s.tris[3 * hit.triangle + 2];
+    const uint32_t flags = __float_as_uint(ta.w);
+    const float4* at = s.tri_attrs + 6 * size_t(hit.triangle);
+
+    uint32_t slot = flags & HIPRZ_TRI_MATERIAL_MASK;
+    if (slot > 63u) slot = 63u;
+    int32_t mat = -1;
+    if (slot < material_count) mat = s.inst_materials[material_base + slot];
+    sf.surface_material = mat < 0 ? HIPRZ_MATERIAL_DEFAULT : uint32_t(mat);
+    sf.behind_material = hit.external ? sf.surface_material : HIPRZ_MATERIAL_WORLD;
+    m = load_material(s, sf.surface_material);
+
+    const bool has_texcrds = (flags & HIPRZ_TRI_HAS_TEXCRDS) != 0;
+    float4 uv12 = make_float4(0, 0, 0, 0), uv3 = make_float4(0, 0, 0, 0);
+    if (has_texcrds) {
+        uv12 = at[4], uv3 = at[5];
+        const float b3 = 1.0f - hit.bx - hit.by;
+        sf.u = uv12.x * b3 + uv12.z * hit.bx + uv3.x * hit.by;
+        sf.v = uv12.y * b3 + uv12.w * hit.bx + uv3.y * hit.by;
+    }
+    const float external_factor = float(hit.external) * 2.0f - 1.0f;
+    const v3 face_normal = xyz(at[3]);
+    if (flags & HIPRZ_TRI_HAS_NORMALS) {
+        const v3 n1 = xyz(at[0]), n2 = xyz(at[1]), n3 = xyz(at[2]);
+        sf.mapped_normal = normalized(n1 * (1.0f - hit.bx - hit.by) + n2 * hit.bx + n3 * hit.by);
+    } else {
+        sf.mapped_normal = face_normal;
+    }
+    if (m.normal_map >= 0 && has_texcrds) {  // Triangle::mapNormal, mesh_component.cpp:132-167
+        const col4 map_color = fetch_rgba8<COUNT>(s, m.normal_map, sf.u, sf.v, cnt);
+        const v3 v1 = xyz(ta), v2 = xyz(tb), vv3 = xyz(tc);
+        const v3 edge1 = (v2 - v1) * scale;
+        const v3 edge2 = (vv3 - v1) * scale;
+        const float duv1x = uv12.z - uv12.x, duv1y = uv12.w - uv12.y;
+        const float duv2x = uv3.x - uv12.x, duv2y = uv3.y - uv12.y;
+        v3 mn = sf.mapped_normal / scale;
+        const float f = 1.0f / (duv1x * duv2y - duv2x * duv1y);
+        v3 tangent = normalized((edge1 * duv2y - edge2 * duv1y) * f);
+        tangent = normalized(tangent - mn * dot(tangent, mn));
+        const v3 bitangent = cross(tangent, mn);
+        const v3 map_n = V3(map_color.r, map_color.g, map_color.b) * 2.0f - V3(1.0f, 1.0f, 1.0f);
+        mn = mn * map_n.z + tangent * map_n.x + bitangent * map_n.y;
+        sf.mapped_normal = transform_forward(xa, ya, za, mn);  // transformL2GNoScale
+    } else {
+        sf.mapped_normal = transform_forward(xa, ya, za, sf.mapped_normal / scale);  // transformL2G
+    }
+    sf.mapped_normal = normalized(sf.mapped_normal);
+    sf.mapped_normal = sf.mapped_normal * external_factor;
+
+    sf.normal = face_normal * external_factor;
+    sf.normal = transform_forward(xa, ya, za, sf.normal / scale);
+    sf.normal = normalized(sf.normal);
+}
+
+// --- helpers: cpu_render_utils.cpp:29-170 -----------------------------------------------
+RZ_DEV v3 reflect_vector(v3 vI, v3 vN) { return (vN * -2.0f) * dot(vN, vI) + vI; }
+RZ_DEV v3 halfway_vector(v3 vI, v3 vR) { return normalized((-vI) + vR); }
+RZ_DEV void local_coordinate(v3 vN, v3& vX, v3& vY) {
+    const bool b = fabsf(vN.x) > fabsf(vN.y);
+    vX = v3{float(!b), float(b), 0.0f};
+    vY = cross(vN, vX);
+    vX = cross(vN, vY);
+}
+RZ_DEV v3 cosine_sample_hemisphere(float r1, float r2, v3 vN) {
+    v3 vX, vY;
+    local_coordinate(vN, vX, vY);
+    const float phi = r1 * 6.283185f;
+    const float theta = r2;
+    const float sqrt_theta = sqrtf(theta);
+    const v3 a = (vX * sqrt_theta) * RZ_COSF(phi);
+    const v3 b = (vY * sqrt_theta) * RZ_SINF(phi);
+    const v3 c = vN * sqrtf(1.0f - theta);
+    return (a + b) + c;
+}
+RZ_DEV v3 sample_sphere(float r1, float r2, v3 vN) {
+    v3 vX, vY;
+    local_coordinate(vN, vX, vY);
+    const float phi = r1 * 6.283185f;
+    const float theta = RZ_ACOSF(1.0f - 2.0f * r2);
+    const float sin_theta = RZ_SINF(theta);
+    const v3 a = (vX * sin_theta) * RZ_COSF(phi);
+    const v3 b = (vY * sin_theta) * RZ_SINF(phi);
+    const v3 c = vN * RZ_COSF(theta);
+    return (a + b) + c;
+}
+RZ_DEV v3 sample_hemisphere(float r1, float r2, v3 vN) { return sample_sphere(r1, r2 * 0.5f, vN); }
+RZ_DEV v3 sample_disk(float r1, float r2, v3 vN, float radius) {
+    v3 vX, vY;
+    local_coordinate(vN, vX, vY);
+    const float phi = r1 * 2.0f * RZ_PI_F;
+    const float mag = sqrtf(r2);
+    return ((vX * RZ_SINF(phi) + vY * RZ_COSF(phi)) * mag) * radius;
+}
+RZ_DEV float fresnel_specular_ratio(v3 vN, v3 vI, float n1, float n2, float& fx, float& fy) {
+    const float ratio = n1 / n2;
+    const float cosi = fabsf(dot(vI, vN));
+    const float sin2_t = ratio * ratio * (1.0f - cosi * cosi);
+    if (sin2_t >= 1.0f) return 1.0f;
+    const float cost = sqrtf(1.0f - sin2_t);
+    const float Rp = ((n1 * cosi) - (n2 * cost)) / ((n1 * cosi) + (n2 * cost));
+    const float Rs = ((n2 * cosi) - (n1 * cost)) / ((n2 * cosi) + (n1 * cost));
+    fx = ratio;
+    fy = ratio * cosi - cost;
+    return (Rs * Rs + Rp * Rp) / 2.0f;
+}
+
+// --- BRDF: cpu_engine_kernel.cpp:556-594 ------------------------------------------------
+RZ_DEV float ndf(v3 vN, v3 vH, float roughness) {
+    const float d = dot(vN, vH);
+    const float b = (d * d) * (roughness - 1.0f) + 1.0001f;
+    return (roughness + 1.0e-5f) / (b * b);
+}
+RZ_DEV float attenuation(float cos_angle, float roughness) {
+    return cos_angle / ((cos_angle * (1.0f - roughness)) + roughness);
+}
+RZ_DEV float brdf(v3 ray_d, const Surface& sf, v3 vPL) {
+    if (sf.surface_scattering > 0.0f) return 1.0f;
+    const float vN_dot_vO = dot(sf.mapped_normal, vPL);
+    if (vN_dot_vO <= 0.0f) return 0.0f;
+    const float vN_dot_vI = dot(sf.mapped_normal, -ray_d);
+    if (vN_dot_vI <= 0.0f) return 0.0f;
+    const v3 vH = halfway_vector(ray_d, vPL);
+    const float nd = ndf(sf.mapped_normal, vH, sf.roughness);
+    const float atten_i = attenuation(vN_dot_vI, sf.roughness);
+    const float atten_o = attenuation(vN_dot_vO, sf.roughness);
+    const float atten = atten_i * atten_o;
+    const float diffuse = vN_dot_vO * float(sf.color.a == 0.0f);
+    const float specular = nd * atten / (vN_dot_vI * vN_dot_vO);
+    return lerpf(diffuse, specular * vN_dot_vO, sf.reflectance);
+}
+RZ_DEV col4 brdf_color(const Surface& sf) { return lerp(sf.color, splat(1.0f), sf.reflectance); }
+
+// --- direction sampling: cpu_engine_kernel.cpp:596-687 ----------------------------------
+RZ_DEV v3 sample_direction(v3 ray_d, uint32_t& ray_material, Surface& sf, Rng& rng) {
+    if (sf.color.a > 0.0f) {
+        if (sf.surface_scattering > 0.0f) {
+            const float u1 = rng.unsignedUniform();
+            const float u2 = rng.unsignedUniform();
+            const v3 vO = sample_sphere(u1, u2, ray_d);
+            sf.tint_factor = sf.metalness;
+            return vO;
+        }
+        if (sf.fresnel < rng.unsignedUniform()) {
+            const v3 vO = ray_d * sf.refr_x + sf.mapped_normal * sf.refr_y;
+            ray_material = sf.behind_material;
+            sf.normal = -sf.normal;
+            sf.tint_factor = 1.0f;
+            return vO;
+        }
+        v3 vO = reflect_vector(ray_d, sf.mapped_normal);
+        const float d = dot(vO, sf.normal);
+        if (d < 0.0f) vO = vO + (sf.normal * -2.0f) * d;
+        sf.tint_factor = sf.metalness;
+        return vO;
+    }
+    if (rng.unsignedUniform() > sf.reflectance) {
+        const float u1 = rng.unsignedUniform();
+        const float u2 = rng.unsignedUniform();
+        v3 vO = cosine_sample_hemisphere(u1, u2, sf.mapped_normal);
+        const float d = similarity(vO, sf.normal);
+        if (d < 0.0f) vO = vO + (sf.normal * -2.0f) * d;
+        sf.tint_factor = 1.0f;
+        return vO;
+    }
+    const float u1 = rng.unsignedUniform();
+    const float u2 = rng.unsignedUniform();
+    const v3 vH = sample_hemisphere(u1, 1.0f - RZ_POWF(u2 + 1.0e-5f, sf.roughness), sf.mapped_normal);
+    v3 vO = reflect_vector(ray_d, vH);
+    const float d = similarity(vO, sf.normal);
+    if (d < 0.0f) vO = vO + (sf.normal * -2.0f) * d;
+    sf.tint_factor = sf.metalness;
+    return vO;
+}
+
+// --- next-event estimation: cpu_engine_kernel.cpp:690-865 -------------------------------
+template <int MODE, bool COUNT>
+RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, uint32_t* lds_column, v3 ray_d, uint32_t ray_material,
+                                v3 point, v3 next_dir, const Surface& sf, Rng& rng, Counters& cnt) {
+    const float vS_pdf = brdf(ray_d, sf, next_dir);
+    col4 direct_total = splat(0.0f);
+    if (s.n_direct_lights != 0) {  // directLightSampling :745-791
+        for (uint32_t i = 0; i < cfg.direct_samples; ++i) {
+            uint32_t li = uint32_t(rng.unsignedUniform() * float(s.n_direct_lights));
+            if (li >= s.n_direct_lights) li = s.n_direct_lights - 1u;
+            const float4 l0 = s.direct_lights[2 * li], l1 = s.direct_lights[2 * li + 1];
+            RZ_COUNT(light_samples);
+            const v3 ldir = xyz(l0);
+            const float emission = l0.w, cos_angle = l1.z;
+            float Se = 0.0f;
+            v3 vPL;
+            const float d = dot(next_dir, -ldir);
+            if (d > cos_angle) {
+                Se = emission;
+                vPL = next_dir;
+            } else {
+                const float u1 = rng.unsignedUniform();
+                const float u2 = rng.unsignedUniform();
+                vPL = sample_sphere(u1, u2 * 0.5f * (1.0f - cos_angle), -ldir);
+            }
+            const float b = brdf(ray_d, sf, normalized(vPL));
+            const col4 bc = brdf_color(sf);
+            const float solid_angle = 2.0f * RZ_PI_F * (1.0f - cos_angle);
+            const float L_pdf = 1.0f / solid_angle;
+            const float vSw = vS_pdf / (vS_pdf + L_pdf);
+            const float Lw = 1.0f - vSw;
+            const float Le = emission * solid_angle * b;
+            const float radiance = (Le * Lw + Se * vSw);
+            if (radiance < 1.0e-4f) continue;
+            Ray sr;
+            sr.o = point, sr.d = normalized(vPL), sr.near_ = 0.0f, sr.far_ = RZ_FLT_MAX;
+            const float V = any_hit<MODE, COUNT>(s, lds_column, sr, cnt);
+            const col4 V_PL = splat(V);
+            direct_total = direct_total + (((from_u8(__float_as_uint(l1.x)) * bc) * radiance) * V_PL) * V_PL.a;
+        }
+        const float pdf = float(cfg.direct_samples) / float(s.n_direct_lights);
+        direct_total = div_scalar(direct_total, pdf);
+    }
+    col4 spot_total = splat(0.0f);
+    if (s.n_spot_lights != 0) {  // spotLightSampling :690-744
+        for (uint32_t i = 0; i < cfg.spot_samples; ++i) {
+            uint32_t li = uint32_t(rng.unsignedUniform() * float(s.n_spot_lights));
+            if (li >= s.n_spot_lights) li = s.n_spot_lights - 1u;
+            const float4 l0 = s.spot_lights[3 * li], l1 = s.spot_lights[3 * li + 1], l2 = s.spot_lights[3 * li + 2];
+            RZ_COUNT(light_samples);
+            const v3 lpos = xyz(l0), ldir = xyz(l1);
+            const float size = l0.w, emission = l1.w, cos_angle = l2.z;
+            float Se = 0.0f;
+            v3 vPL;
+            {  // spotLightSampleDirection :805-828, rayPointCalculation cpu_render_utils.cpp:48-72
+                const v3 rd = normalized(next_dir);
+                const v3 vOP = lpos - point;
+                const float dOP = magnitude(vOP);
+                const float vOP_dot_vD = dot(vOP, rd);
+                const float dPQ = sqrtf(dOP * dOP - vOP_dot_vD * vOP_dot_vD);
+                if (dPQ < size && vOP_dot_vD > 0.0f) {
+                    Se = emission;
+                    const float dOQ = sqrtf(dOP * dOP - dPQ * dPQ);
+                    vPL = next_dir * fmaxf(dOQ, 1.0e-4f);
+                } else {
+                    const float u1 = rng.unsignedUniform();
+                    const float u2 = rng.unsignedUniform();
+                    vPL = (sample_disk(u1, u2, vOP / dOP, size) + lpos) - point;
+                }
+            }
+            const float dPL = magnitude(vPL);
+            const float b = brdf(ray_d, sf, vPL / dPL);
+            if (b < 1.0e-4f) continue;
+            const col4 bc = brdf_color(sf);
+            const float A = size * size * RZ_PI_F;
+            const float d1 = dPL + 1.0f;
+            const float solid_angle = A / (d1 * d1);
+            const float sctr_factor = RZ_EXPF(-dPL * material_scattering(s, ray_material));
+            const float beam = float(cos_angle < similarity(-vPL, ldir));
+            if (beam < 1.0e-4f) continue;
+            const float L_pdf = 1.0f / solid_angle;
+            const float vSw = vS_pdf / (vS_pdf + L_pdf);
+            const float Lw = 1.0f - vSw;
+            const float Le = emission * solid_angle * b;
+            const float radiance = (Le * Lw + Se * vSw) * sctr_factor * beam;
+            if (radiance < 1.0e-4f) continue;
+            Ray sr;
+            sr.o = point, sr.d = normalized(vPL), sr.near_ = 0.0f, sr.far_ = dPL;
+            const float V = any_hit<MODE, COUNT>(s, lds_column, sr, cnt);
+            const col4 V_PL = splat(V);
+            spot_total = spot_total + (((from_u8(__float_as_uint(l2.x)) * bc) * radiance) * V_PL) * V_PL.a;
+        }
+        const float pdf = float(cfg.spot_samples) / float(s.n_spot_lights);
+        spot_total = div_scalar(spot_total, pdf);
+    }
+    return direct_total + spot_total;
+}
+
+// --- camera rays: cpu_engine_kernel.cpp:180-252 -----------------------------------------
+RZ_DEV void screen_direction(const DCamera& c, uint32_t px, uint32_t py, float& dx, float& dy) {
+    const float tana = c.tan_half_fov;
+    dx = (((float(px) + 0.5f) / float(c.width)) - 0.5f) * tana;
+    dy = (((float(py) + 0.5f) / float(c.height)) - 0.5f) * (-tana / c.aspect_ratio);
+}
+RZ_DEV void generate_simple_ray(const DCamera& c, Ray& ray, uint32_t px, uint32_t py) {
+    float dx, dy;
+    screen_direction(c, px, py, dx, dy);
+    const v3 xa = ld3(c.x_axis), ya = ld3(c.y_axis), za = ld3(c.z_axis);
+    ray.o = transform_forward(xa, ya, za, V3(0.0f, 0.0f, 0.0f)) + ld3(c.position);
+    ray.d = normalized(transform_forward(xa, ya, za, V3(dx, dy, 1.0f)));
+    ray.near_ = c.near_, ray.far_ = c.far_;
+}
+RZ_DEV void generate_antialiased_ray(const DCamera& c, Ray& ray, uint32_t px, uint32_t py, Rng& rng) {
+    float dx, dy;
+    screen_direction(c, px, py, dx, dy);
+    v3 dir = V3(dx, dy, 1.0f);
+    dir.x += ((0.5f / float(c.width)) * rng.signedUniform());
+    dir.y += ((0.5f / float(c.width)) * rng.signedUniform());  // (sic) cpu_engine_kernel.cpp:227-228
+    const v3 focal_point = dir * c.focal_distance;
+    const float aperture_angle = rng.unsignedUniform() * 2.0f * RZ_PI_F;
+    const float aperture_sample = sqrtf(rng.unsignedUniform()) * c.aperture;
+    const v3 origin = V3(aperture_sample * RZ_SINF(aperture_angle), aperture_sample * RZ_COSF(aperture_angle), 0.0f);
+    dir = focal_point - origin;
+    const v3 xa = ld3(c.x_axis), ya = ld3(c.y_axis), za = ld3(c.z_axis);
+    ray.o = transform_forward(xa, ya, za, origin) + ld3(c.position);
+    ray.d = normalized(transform_forward(xa, ya, za, dir));
+    ray.near_ = c.near_, ray.far_ = c.far_;
+}
+
+// Tone map: cpu_engine_renderer.cpp:224-235
+RZ_DEV uint32_t tonemap(col4 color, float aperture, float exposure_time) {
+    const float aperture_area = aperture * aperture * RZ_PI_F;
+    color = div_scalar(color, color.a == 0.0f ? 1.0f : color.a);
+    color = color * aperture_area;
+    color = color * exposure_time;
+    color = color * 1.0e5f;
+    color = color / (color + splat(1.0f));
+    const uint32_t r = uint32_t(uint8_t(color.r * 255.0f)), g = uint32_t(uint8_t(color.g * 255.0f)),
+                   b = uint32_t(uint8_t(color.b * 255.0f));
+    return r | (g << 8) | (b << 16) | 0xFF000000u;
+}
+
+// thread -> pixel.  A block is one 32x8 tile (4 waves of 8x8 pixels); owned tile `lt` of
+// shard (rank, world) is global tile lt*world + rank.
+struct PixelId {
+    uint32_t x, y, local;
+    bool active;
+};
+RZ_DEV PixelId pixel_of_thread(const DFrame& f, const DCamera& c, uint32_t block, uint32_t tid) {
+    const uint32_t tile = block * f.world + f.rank;
+    const uint32_t tx = tile % f.tiles_x, ty = tile / f.tiles_x;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    PixelId p;
+    p.x = tx * 32u + wave * 8u + (lane & 7u);
+    p.y = ty * 8u + (lane >> 3);
+    p.local = block * 256u + tid;
+    p.active = p.x < c.width && p.y < c.height;
+    return p;
+}
+
+}  // namespace hiprz

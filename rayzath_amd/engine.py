@@ -1,0 +1,201 @@
+"""Python host side of the HIPGPU backend, above the C-ABI.
+
+`Engine` mirrors the reference's backend interface — `renderWorld(World&, const
+RenderConfig&, bool block, bool sync)` and `timingsString()` (RayZath/cpu_engine.hpp:17-22,
+RayZath/cuda_engine.cuh:34-39) — and `RenderConfig/LightSampling/Tracing` mirror
+RayZath/engine_parts.hpp:76-128.  `Context` is a thin handle around `hiprz_ctx`.
+All compute happens in libhiprz.so; there is no CPU path here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi, _lib
+from ._lib import HiprzError
+from .scene import HostBackend, camera_struct, flatten
+
+
+class LightSampling:
+    def __init__(self, spot_light=1, direct_light=1):
+        self.spot_light, self.direct_light = int(spot_light), int(direct_light)
+
+
+class Tracing:
+    def __init__(self, max_depth=16, rpp=8):
+        self.max_depth, self.rpp = int(max_depth), int(rpp)
+
+
+class RenderConfig:
+    def __init__(self, light_sampling=None, tracing=None, seed=20240501):
+        self.light_sampling = light_sampling or LightSampling()
+        self.tracing = tracing or Tracing()
+        self.seed = int(seed)
+
+    def struct(self):
+        return _abi.Config(self.tracing.max_depth, self.tracing.rpp, self.light_sampling.spot_light,
+                           self.light_sampling.direct_light, self.seed & 0xFFFFFFFF)
+
+
+class Context:
+    """Owns one hiprz_ctx (one GPU, one stream)."""
+
+    def __init__(self, device=0):
+        self.lib = _lib.load()
+        self._ctx = C.c_void_p()
+        rc = self.lib.hiprz_create(C.byref(self._ctx), int(device))
+        if rc != _abi.OK:
+            raise HiprzError(rc, (self.lib.hiprz_last_error(None) or b"").decode())
+        self.width = self.height = 0
+
+    def close(self):
+        if self._ctx:
+            self.lib.hiprz_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != _abi.OK:
+            raise HiprzError(rc, (self.lib.hiprz_last_error(self._ctx) or b"").decode())
+
+    # --- uploads ---
+    def upload_scene(self, flat_scene):
+        self._check(self.lib.hiprz_upload_scene(self._ctx, C.byref(flat_scene.struct)))
+
+    def upload_camera(self, camera_struct_):
+        self._check(self.lib.hiprz_upload_camera(self._ctx, C.byref(camera_struct_)))
+        self.width, self.height = camera_struct_.width, camera_struct_.height
+
+    def set_config(self, config_struct):
+        self._check(self.lib.hiprz_set_config(self._ctx, C.byref(config_struct)))
+
+    def set_shard(self, rank, world):
+        self._check(self.lib.hiprz_set_shard(self._ctx, rank, world))
+
+    def set_traversal_mode(self, mode):
+        self._check(self.lib.hiprz_set_traversal_mode(self._ctx, mode))
+
+    # --- rendering ---
+    def reset(self):
+        self._check(self.lib.hiprz_reset(self._ctx))
+
+    def render(self, n_passes):
+        self._check(self.lib.hiprz_render(self._ctx, n_passes))
+
+    def render_counted(self, n_passes):
+        out = _abi.Counters()
+        self._check(self.lib.hiprz_render_counted(self._ctx, n_passes, C.byref(out)))
+        return out.as_dict()
+
+    def tonemap(self):
+        self._check(self.lib.hiprz_tonemap(self._ctx))
+
+    def sync(self):
+        self._check(self.lib.hiprz_sync(self._ctx))
+
+    # --- readback ---
+    def read_rgba8(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        self._check(self.lib.hiprz_read_rgba8(self._ctx, out.ctypes.data, out.nbytes))
+        return out
+
+    def read_depth(self):
+        out = np.zeros((self.height, self.width), dtype=np.float32)
+        self._check(self.lib.hiprz_read_depth(self._ctx, out.ctypes.data, out.nbytes))
+        return out
+
+    def read_accum(self):
+        out = np.zeros((self.height, self.width, 4), dtype=np.float32)
+        self._check(self.lib.hiprz_read_accum(self._ctx, out.ctypes.data, out.nbytes))
+        return out
+
+    def read_state(self):
+        n = self.width * self.height
+        ray = np.zeros((self.height, self.width, 9), dtype=np.float32)
+        md = np.zeros((self.height, self.width, 2), dtype=np.uint32)
+        self._check(self.lib.hiprz_read_state(self._ctx, ray.ctypes.data, md.ctypes.data, n))
+        return dict(origin=ray[..., 0:3], direction=ray[..., 3:6], color=ray[..., 6:9], material=md[..., 0], depth=md[..., 1])
+
+    def ray_count(self):
+        v = C.c_uint64()
+        self._check(self.lib.hiprz_ray_count(self._ctx, C.byref(v)))
+        return v.value
+
+    def pass_count(self):
+        v = C.c_uint32()
+        self._check(self.lib.hiprz_pass_count(self._ctx, C.byref(v)))
+        return v.value
+
+    def pick(self, x, y):
+        i, m = C.c_int32(), C.c_int32()
+        self._check(self.lib.hiprz_pick(self._ctx, x, y, C.byref(i), C.byref(m)))
+        return i.value, m.value
+
+    def timings(self):
+        buf = C.create_string_buffer(4096)
+        self._check(self.lib.hiprz_timings(self._ctx, buf, len(buf)))
+        return buf.value.decode()
+
+    def kernel_time_ms(self):
+        """(total device ms, passes) of the pass kernel since the last call (hip events on the ctx stream)."""
+        t, n = C.c_double(), C.c_uint64()
+        self._check(self.lib.hiprz_kernel_time_ms(self._ctx, C.byref(t), C.byref(n)))
+        return t.value, n.value
+
+    # --- multi-GPU hand-off (device pointers) ---
+    def local_pixel_capacity(self):
+        v = C.c_size_t()
+        self._check(self.lib.hiprz_local_pixel_capacity(self._ctx, C.byref(v)))
+        return v.value
+
+    def export_accum_tiles(self, dst_ptr, nbytes):
+        self._check(self.lib.hiprz_export_accum_tiles(self._ctx, dst_ptr, nbytes))
+
+    def untile_accum(self, src_ptr, rank, world, dst_ptr):
+        self._check(self.lib.hiprz_untile_accum(self._ctx, src_ptr, rank, world, dst_ptr))
+
+    def tonemap_image(self, src_ptr, dst_ptr):
+        self._check(self.lib.hiprz_tonemap_image(self._ctx, src_ptr, dst_ptr))
+
+    def stream(self):
+        return self.lib.hiprz_stream(self._ctx)
+
+
+class Engine:
+    """HIPGPU peer of CPU::Engine / Cuda::Engine.  Writes its results into the world's camera
+    like the reference backends do (imageBuffer / depthBuffer / rayCount, camera.hpp:50-56,113-119)."""
+
+    def __init__(self, device=0):
+        self.context = Context(device)
+        self.backend = HostBackend(self.context.lib)
+        self._world_key = None
+        self._camera_key = None
+
+    def renderWorld(self, world, render_config, block=True, sync=True):
+        ctx = self.context
+        # the backend re-mirrors what changed and restarts accumulation then (cpu_engine_renderer.cpp:108-112)
+        world_key = getattr(world, "_version", None), id(world)
+        if self._world_key != world_key or getattr(world, "_dirty", True):
+            self._flat = flatten(world, self.backend)
+            ctx.upload_scene(self._flat)
+            self._world_key = world_key
+            world._dirty = False
+        cam = world.camera
+        cam_key = (cam.width, cam.height, cam.position.tobytes(), cam.rotation.tobytes(), cam.fov, cam.near_far,
+                   cam.focal_distance, cam.aperture, cam.exposure_time)
+        if self._camera_key != cam_key:
+            ctx.upload_camera(camera_struct(cam, self.backend))
+            self._camera_key = cam_key
+        ctx.set_config(render_config.struct())
+        ctx.render(max(render_config.tracing.rpp, 1))
+        ctx.tonemap()
+        cam.image_buffer = ctx.read_rgba8()  # synchronises
+        cam.depth_buffer = ctx.read_depth()
+        cam.ray_count = ctx.ray_count()
+
+    def timingsString(self):
+        return self.context.timings()
