@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s of the HIPGPU path-tracing backend on BASELINE.json's config B
+(Cornell box 1920x1080, max depth 8), 1..8 GPUs of one node.
+
+A *step* is one `renderWorld`-equivalent: `rpp` = 8 passes (engine_parts.hpp:84 default;
+every pass traces one path segment per pixel), a tone map, and — for N > 1 — the gather
+of the accumulators to rank 0 over RCCL.  rays = path segments, exactly the reference's own
+counter (`traced_rays += W*H` per pass, cpu_engine_renderer.cpp:173; shadow rays are not
+counted).  value = steps * rpp * W * H / seconds / 1e6 over the whole job; the frame is
+fixed, so more GPUs split the same work ("strong" scaling).
+
+Extra objects on the JSON line:
+  roofline      HBM roofline of the pass kernel: algorithmic bytes per launch (SURVEY.md §8d
+                formula on the work counters of an instrumented run of the same kernel) divided by
+                the average launch duration measured with hip events on the render stream.
+  cpu_baseline  the CPU oracle (oracle/, a port of cpu_engine_kernel) timed on this host's cores
+                on a bounded sample of the same workload.  Reported baseline only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RPP = 8
+PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling ~6.3 TB/s
+
+
+def algorithmic_bytes(c):
+    """B = 146*segments + 32*box tests + 36*triangle tests + 64*hits + 4*texel
+    fetches + 64*light samples (state+accumulator read and written once per segment; 32-B
+    node, 36-B triangle, 64-B shading record, 64-B light record)."""
+    return (146 * c["segments"] + 32 * c["box_tests"] + 36 * c["tri_tests"] + 64 * c["hits"] + 4 * c["texel_fetches"]
+            + 64 * c["light_samples"])
+
+
+def cpu_baseline(flat, cam, cfg, budget_s=12.0):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+
+    cores = len(os.sched_getaffinity(0))
+    try:  # the GPU box gives this job a CPU share smaller than the host (cgroup v2 quota)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    ref = oracle.OracleRenderer(flat, cam, cfg)
+    ref.render(1, threads=cores)  # first pass (warm-up, as headless.cpp:203 does)
+    passes, t0 = 0, time.perf_counter()
+    while True:
+        ref.render(1, threads=cores)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or passes >= 64:
+            break
+    rays = passes * cam.width * cam.height
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{passes} cumulative passes of the same {cam.width}x{cam.height} depth-{cfg.max_depth} frame "
+                      f"({rays} path segments, {dt:.1f} s) after one warm-up pass"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="B", help="scene preset of rayzath_amd/scenes.py (B = the quoted config)")
+    ap.add_argument("--traversal", type=int, default=1, help="1 nested walk with LDS stack (default), 0 threaded walk")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+
+    from rayzath_amd import scenes
+    from rayzath_amd.distributed import ShardedFrame
+    from rayzath_amd.engine import Context, RenderConfig, Tracing
+    from rayzath_amd.scene import camera_struct, flatten
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    preset = scenes.CONFIGS[args.config]
+    scene_world = preset["build"]()
+    flat, cam = flatten(scene_world), camera_struct(scene_world.camera)
+    cfg = RenderConfig(tracing=Tracing(preset["max_depth"], RPP)).struct()
+    W, H = cam.width, cam.height
+
+    ctx = Context(local_rank)
+    ctx.set_traversal_mode(args.traversal)
+    ctx.set_shard(rank, world)
+    ctx.upload_scene(flat)
+    ctx.upload_camera(cam)
+    ctx.set_config(cfg)
+    frame = ShardedFrame(ctx, rank, world, W, H, dist if world > 1 else None, torch.device("cuda", local_rank))
+
+    def step():
+        ctx.render(RPP)
+        if world > 1:
+            frame.gather()
+        else:
+            ctx.tonemap()
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.render(1)  # renderFirstPass; the timed steps are cumulative passes, as in steady-state rendering
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.kernel_time_ms()  # drop the warm-up launches from the event log
+    alpha_before = None
+    if rank == 0 and world == 1:
+        alpha_before = float(ctx.read_accum()[..., 3].sum())
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    kernel_ms, launches = ctx.kernel_time_ms()
+    rays = args.steps * RPP * W * H
+    result = None
+    if rank == 0:
+        spp_per_s = None
+        if alpha_before is not None:
+            spp_per_s = (float(ctx.read_accum()[..., 3].sum()) - alpha_before) / (W * H) / elapsed
+        # work counters of the same kernel, same state, outside the timed region
+        counters = ctx.render_counted(RPP)
+        ctx.kernel_time_ms()
+        bytes_per_launch = algorithmic_bytes(counters) / RPP
+        avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
+        achieved = bytes_per_launch / avg_kernel_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
+        if os.path.exists(tpath) and world == 1:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        result = {
+            "metric": "Mrays/s (path segments, primary+secondary) at 1920x1080 depth 8" if args.config == "B" else f"Mrays/s config {args.config}",
+            "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": preset["note"], "resolution": [W, H], "max_depth": preset["max_depth"], "passes_per_step": RPP,
+                       "triangles": int(len(flat.tris)), "instances": int(len(flat.instances)),
+                       "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
+                       "traversal": "threaded" if args.traversal == 0 else "lds-stack"},
+            "spp_per_s": spp_per_s,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
+                         "traffic": traffic, "kernel": "rz_pass_kernel<cumulative>", "avg_launch_us": avg_kernel_s * 1e6,
+                         "algorithmic_bytes_per_launch": bytes_per_launch, "segments_per_launch": counters["segments"] / RPP,
+                         "box_tests_per_segment": counters["box_tests"] / max(counters["segments"], 1),
+                         "tri_tests_per_segment": counters["tri_tests"] / max(counters["segments"], 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(flat, cam, cfg)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -254,9 +254,15 @@ int hiprz_set_config(hiprz_ctx* ctx, const hiprz_config* config);
  * unchanged, so results are identical for any world size).  Default rank 0 of 1. */
 int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
 
-/* Tree-walk variant of the pass kernel: 0 = threaded (skip links, no stack; default),
- * 1 = per-lane stack in LDS.  Both visit the same nodes in the same order. */
+/* Tree-walk variant of the pass kernel: 1 = nested loops with a per-lane stack in LDS (default),
+ * 0 = threaded (skip links + instance pseudo-nodes, no stack).  Both visit the same boxes and
+ * triangles in the same order and give identical results. */
 int hiprz_set_traversal_mode(hiprz_ctx* ctx, int mode);
+
+/* Stage the scene's geometry + shading records into LDS in every workgroup (ds_read instead of
+ * dependent global loads): -1 = automatic (when the records fit three workgroups per CU), 0 = never,
+ * 1 = whenever they fit one workgroup.  Results are identical either way. */
+int hiprz_set_lds_scene(hiprz_ctx* ctx, int mode);
 
 /* --- rendering (replaces Renderer::renderFunction, cuda_engine_renderer.cu:73-262) --- */
 /* Restart accumulation: the next hiprz_render starts with renderFirstPass
@@ -296,6 +302,10 @@ void* hiprz_stream(hiprz_ctx* ctx); /* the hipStream_t all of the above are enqu
 
 /* --- picking (Kernel::rayCast, cpu_engine_kernel.cpp:102-111, 483-501) --- */
 int hiprz_pick(hiprz_ctx* ctx, uint32_t x, uint32_t y, int32_t* instance_out, int32_t* material_out);
+
+/* Device self-test of the kernels' exact-arithmetic shortcuts (shared-reciprocal division must
+ * equal the correctly rounded quotient): runs 262144 * cases_per_thread random cases. */
+int hiprz_selftest(hiprz_ctx* ctx, uint32_t cases_per_thread, uint32_t seed, uint64_t* mismatches, uint64_t* tested);
 
 /* --- timing (TimeTable, engine_parts.hpp:34-74; Engine::debugInfo, rayzath.cpp:96-113) --- */
 int hiprz_timings(hiprz_ctx* ctx, char* buf, size_t len);

@@ -107,6 +107,7 @@ ENTRY_POINTS = {
     "hiprz_set_config": (C.c_int, [P, C.POINTER(Config)]),
     "hiprz_set_shard": (C.c_int, [P, U32, U32]),
     "hiprz_set_traversal_mode": (C.c_int, [P, C.c_int]),
+    "hiprz_set_lds_scene": (C.c_int, [P, C.c_int]),
     "hiprz_reset": (C.c_int, [P]),
     "hiprz_render": (C.c_int, [P, U32]),
     "hiprz_render_counted": (C.c_int, [P, U32, C.POINTER(Counters)]),
@@ -124,6 +125,7 @@ ENTRY_POINTS = {
     "hiprz_tonemap_image": (C.c_int, [P, P, P]),
     "hiprz_stream": (P, [P]),
     "hiprz_pick": (C.c_int, [P, U32, U32, C.POINTER(I32), C.POINTER(I32)]),
+    "hiprz_selftest": (C.c_int, [P, U32, U32, C.POINTER(U64), C.POINTER(U64)]),
     "hiprz_timings": (C.c_int, [P, C.c_char_p, SZ]),
     "hiprz_kernel_time_ms": (C.c_int, [P, C.POINTER(C.c_double), C.POINTER(U64)]),
     "hiprz_build_mesh_tree": (C.c_int, [C.POINTER(MeshDesc), P, U32, C.POINTER(U32), P, P]),

@@ -10,7 +10,7 @@ import os
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libhiprz.so")
+LIB_PATH = os.environ.get("HIPRZ_LIB") or os.path.join(_HERE, "csrc", "libhiprz.so")  # HIPRZ_LIB: A/B builds (tools/ab_variants.sh)
 _lib = None
 
 

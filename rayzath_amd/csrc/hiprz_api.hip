@@ -24,10 +24,24 @@ using namespace hiprz;
 
 // One pass = one path segment per owned pixel: renderFirstPass (cpu_engine_kernel.cpp:15-57)
 // when FIRST, else renderCumulativePass (:58-101), with traceRay (:113-178) inlined.
-template <bool FIRST, bool COUNT, int MODE>
-__global__ void __launch_bounds__(256) rz_pass_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f) {
-    extern __shared__ uint32_t rz_lds[];
-    uint32_t* lds_column = rz_lds + threadIdx.x;
+//
+// LDS_SCENE: the workgroup first stages the scene's hot blob (geometry + shading records) into LDS
+// and every traversal / shading fetch becomes a ds_read instead of a dependent global load — the
+// walk is a chain of dependent fetches, so their latency, not bandwidth, bounds the kernel.
+template <bool FIRST, bool COUNT, int MODE, bool LDS_SCENE>
+__global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
+    DScene s = scene_in;
+    uint32_t stack_offset = 0;
+    if constexpr (LDS_SCENE) {
+        float4* dst = reinterpret_cast<float4*>(rz_lds);
+        const uint32_t n16 = s.hot_bytes >> 4;
+        for (uint32_t i = threadIdx.x; i < n16; i += 256u) dst[i] = s.hot[i];
+        __syncthreads();
+        repoint_hot(s, rz_lds);
+        stack_offset = s.hot_bytes;
+    }
+    uint32_t* lds_column = reinterpret_cast<uint32_t*>(rz_lds + stack_offset) + threadIdx.x;
     const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
     Counters cnt;
     if (p.active) {
@@ -70,6 +84,12 @@ __global__ void __launch_bounds__(256) rz_pass_kernel(const DScene s, const DCam
         Hit hit;
         const int found = closest_hit<MODE, COUNT>(s, lds_column, ray, hit, cnt);
         Material m;
+#ifdef RZ_EXP_TRAVERSAL_ONLY
+        if (found == 2) {
+            f.accum[p.local] = make_float4(ray.far_, hit.bx, hit.by, float(hit.triangle));
+        }
+        if (found != 77) return;
+#endif
         if (found == 2) {
             analyze_intersection<COUNT>(s, hit, sf, m, cnt);
         } else {
@@ -201,7 +221,7 @@ __global__ void __launch_bounds__(256) rz_untile_state_kernel(const float4* st0,
 
 // Kernel::rayCast (cpu_engine_kernel.cpp:102-111, 483-501): one thread.
 __global__ void rz_pick_kernel(const DScene s, const DCamera cam, uint32_t x, uint32_t y, float depth, int32_t* out2) {
-    extern __shared__ uint32_t rz_lds[];
+    uint32_t* rz_lds = nullptr;
     Ray ray;
     generate_simple_ray(cam, ray, x, y);
     ray.near_ = depth * 0.99f;
@@ -218,6 +238,29 @@ __global__ void rz_pick_kernel(const DScene s, const DCamera cam, uint32_t x, ui
         out2[0] = hit.instance;
         out2[1] = slot < material_count ? s.inst_materials[material_base + slot] : -1;
     }
+}
+
+// Device self-test: div_shared() must equal the correctly rounded `/` bit for bit over its
+// whole stated operand range.  out[0] = mismatches, out[1] = cases tested.
+__global__ void __launch_bounds__(256) rz_selftest_div_kernel(uint32_t n_per_thread, uint32_t seed, unsigned long long* out) {
+    uint32_t h = mix32(seed ^ (blockIdx.x * 256u + threadIdx.x) * 0x9E3779B9u);
+    uint32_t bad = 0, tested = 0;
+    for (uint32_t i = 0; i < n_per_thread; ++i) {
+        h = mix32(h + i);
+        // d: random sign/mantissa, exponent in [-40, 2); n: zero or exponent in [-84, 41)
+        const uint32_t de = 127u - 40u + (h >> 8) % 42u;
+        const float d = __uint_as_float((h & 0x80000000u) | (de << 23) | (mix32(h) & 0x7FFFFFu));
+        const uint32_t g = mix32(h ^ 0xA5A5A5A5u);
+        const uint32_t ne = 127u - 84u + (g >> 8) % 125u;
+        float n = __uint_as_float((g & 0x80000000u) | (ne << 23) | (mix32(g) & 0x7FFFFFu));
+        if ((g & 0xFFu) == 0u) n = 0.0f;
+        const float y = refined_rcp(d);
+        const float fast = div_shared(n, d, y), exact = n / d;
+        tested += 1;
+        if (__float_as_uint(fast) != __float_as_uint(exact) && !(fast == 0.0f && exact == 0.0f)) bad += 1;
+    }
+    atomicAdd(&out[0], (unsigned long long)bad);
+    atomicAdd(&out[1], (unsigned long long)tested);
 }
 
 // =======================================================================================
@@ -301,14 +344,9 @@ struct hiprz_ctx {
     TimeTable timings;
 
     // scene mirror
-    DeviceArray<hiprz_node> nodes;
-    DeviceArray<uint32_t> skip;
-    DeviceArray<uint32_t> tlas_order;
-    DeviceArray<hiprz_tri> tris;
-    DeviceArray<hiprz_tri_attr> tri_attrs;
-    DeviceArray<hiprz_instance> instances;
-    DeviceArray<int32_t> inst_materials;
-    DeviceArray<hiprz_material> materials;
+    DeviceArray<uint8_t> hot;  // nodes | tlas_order | instances | tris | tri_attrs | materials | inst_materials
+    DeviceArray<hiprz_node> wnodes;
+    DeviceArray<uint32_t> wskip;
     DeviceArray<hiprz_texture> textures;
     DeviceArray<uint8_t> texels;
     DeviceArray<hiprz_spot_light> spot_lights;
@@ -316,6 +354,8 @@ struct hiprz_ctx {
     DScene dscene{};
     bool have_scene = false;
     uint32_t stack_entries = 2;  // LDS stack entries per lane the trees need (MODE 1)
+    bool lds_scene = false;      // hot blob is staged into LDS by every workgroup
+    int lds_scene_override = -1; // -1 auto, 0 never, 1 always (if it fits at all)
 
     // camera + per-pixel state
     hiprz_camera camera{};
@@ -339,7 +379,7 @@ struct hiprz_ctx {
     bool reset_pending = true;
     uint32_t passes = 0;
     uint64_t ray_count = 0;
-    int traversal_mode = 0;
+    int traversal_mode = 1;
 
     // kernel timing (hip events on `stream` around each render batch)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
@@ -368,6 +408,7 @@ struct TreeCheck {
     std::vector<uint8_t> visited;
     uint32_t max_depth = 0;
     std::string error;
+    std::vector<uint32_t> world_leaves;
 
     // Walks one tree from `root`, verifies every index it will make the kernel follow, fills
     // the skip links, returns false on the first violation.  `is_world`: leaves index tlas_order.
@@ -389,6 +430,7 @@ struct TreeCheck {
             if (n.meta & HIPRZ_NODE_LEAF) {
                 const uint64_t end = uint64_t(n.begin) + (n.meta & HIPRZ_NODE_COUNT_MASK);
                 if (end > (is_world ? sc->n_tlas_order : sc->n_tris)) return err("leaf range out of bounds");
+                if (is_world) world_leaves.push_back(it.node);
             } else {
                 if (uint64_t(n.begin) + 1 >= sc->n_nodes) return err("child index out of range");
                 stack.push_back({n.begin + 1, it.skip, it.depth + 1});
@@ -455,15 +497,27 @@ DConfig make_config(const hiprz_ctx* c) {
     return DConfig{c->config.max_depth, c->config.spot_samples, c->config.direct_samples, c->config.seed};
 }
 
+constexpr size_t kLdsSceneLimit = 52u * 1024u;  // per workgroup: 3 x 52 KiB < 160 KiB per CU
+
+bool use_lds_scene(const hiprz_ctx* c) {
+    if (c->lds_scene_override == 0) return false;
+    if (c->lds_scene_override == 1) return size_t(c->dscene.hot_bytes) + size_t(c->stack_entries) * 1024u <= 160u * 1024u;
+    return c->lds_scene;
+}
+
 template <bool FIRST, bool COUNT>
 void launch_pass(hiprz_ctx* c, const DFrame& f) {
     const dim3 grid(c->n_local_tiles), block(256);
     const DConfig cfg = make_config(c);
+    const bool lds_scene = use_lds_scene(c);
+    const size_t blob = lds_scene ? c->dscene.hot_bytes : 0u;
     if (c->traversal_mode == 1) {
-        const size_t lds = size_t(c->stack_entries) * 256u * sizeof(uint32_t);
-        hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 1>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
+        const size_t lds = blob + size_t(c->stack_entries) * 256u * sizeof(uint32_t);
+        if (lds_scene) hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 1, true>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
+        else hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 1, false>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
     } else {
-        hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 0>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f);
+        if (lds_scene) hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 0, true>), grid, block, blob, c->stream, c->dscene, c->dcamera, cfg, f);
+        else hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 0, false>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f);
     }
 }
 
@@ -576,8 +630,7 @@ int hiprz_destroy(hiprz_ctx* c) {
         (void)hipEventDestroy(p.second);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    c->nodes.release(), c->skip.release(), c->tlas_order.release(), c->tris.release(), c->tri_attrs.release();
-    c->instances.release(), c->inst_materials.release(), c->materials.release(), c->textures.release();
+    c->hot.release(), c->wnodes.release(), c->wskip.release(), c->textures.release();
     c->texels.release(), c->spot_lights.release(), c->direct_lights.release();
     release_frame(c);
     c->pass_dev.release(), c->counters_dev.release(), c->pick_dev.release();
@@ -644,30 +697,84 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     }
     c->stack_entries = world_depth + mesh_depth + 2u;
 
+    // ---- walk graph of the threaded traversal (hiprz_device.hpp: walk_threaded) ----
+    // nodes keep their index; every world-tree leaf becomes a CHAIN node whose `begin` points at a
+    // run of INSTANCE pseudo-nodes (box = instance box, begin = instance id) appended after the real
+    // nodes and linked by skip; the last one links to whatever follows the leaf.
+    std::vector<hiprz_node> wnodes(sc->nodes, sc->nodes + sc->n_nodes);
+    for (auto& n : wnodes) {
+        const bool leaf = (n.meta & HIPRZ_NODE_LEAF) != 0;
+        n.meta = ((leaf ? RZ_WALK_TRIS : RZ_WALK_INNER) << RZ_WALK_TYPE_SHIFT) | (leaf ? (n.meta & HIPRZ_NODE_COUNT_MASK) : 0u);
+    }
+    for (uint32_t leaf : check.world_leaves) {
+        const hiprz_node src = sc->nodes[leaf];
+        const uint32_t count = src.meta & HIPRZ_NODE_COUNT_MASK;
+        if (count == 0) continue;  // stays an empty TRIS leaf: box test, then follow the link
+        const uint32_t chain = uint32_t(wnodes.size());
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t inst = sc->tlas_order[src.begin + k];
+            hiprz_node p{};
+            std::memcpy(p.bb_min, sc->instances[inst].bb_min, 12);
+            std::memcpy(p.bb_max, sc->instances[inst].bb_max, 12);
+            p.begin = inst;
+            p.meta = RZ_WALK_INSTANCE << RZ_WALK_TYPE_SHIFT;
+            wnodes.push_back(p);
+            skip.push_back(k + 1 < count ? chain + k + 1 : skip[leaf]);
+        }
+        wnodes[leaf].begin = chain;
+        wnodes[leaf].meta = (RZ_WALK_CHAIN << RZ_WALK_TYPE_SHIFT) | count;
+    }
+    // shared-reciprocal division is exact only for coordinates that are 0 or in [2^-60, 2^40)
+    auto coord_ok = [](float x) {
+        uint32_t b;
+        std::memcpy(&b, &x, 4);
+        const uint32_t e = (b >> 23) & 0xFFu;
+        return (b & 0x7FFFFFFFu) == 0u || (e >= 127u - 60u && e < 127u + 40u);
+    };
+    bool fast_div = true;
+    for (const auto& n : wnodes)
+        for (int a = 0; a < 3; ++a) fast_div = fast_div && coord_ok(n.bb_min[a]) && coord_ok(n.bb_max[a]);
+
     (void)hipSetDevice(c->device);
-    RZ_HIP(c, c->nodes.assign(sc->nodes, sc->n_nodes, c->stream));
-    RZ_HIP(c, c->skip.assign(skip.data(), sc->n_nodes, c->stream));
-    RZ_HIP(c, c->tlas_order.assign(sc->tlas_order, sc->n_tlas_order, c->stream));
-    RZ_HIP(c, c->tris.assign(sc->tris, sc->n_tris, c->stream));
-    RZ_HIP(c, c->tri_attrs.assign(sc->tri_attrs, sc->n_tris, c->stream));
-    RZ_HIP(c, c->instances.assign(sc->instances, sc->n_instances, c->stream));
-    RZ_HIP(c, c->inst_materials.assign(sc->inst_materials, sc->n_inst_materials, c->stream));
-    RZ_HIP(c, c->materials.assign(sc->materials, sc->n_materials, c->stream));
+    // hot blob: one buffer, 16-B aligned sections
+    std::vector<uint8_t> blob;
+    auto append = [&blob](const void* src, size_t bytes) {
+        const uint32_t off = uint32_t(blob.size());
+        blob.resize(blob.size() + ((bytes + 15u) & ~size_t(15)), 0);
+        if (bytes) std::memcpy(blob.data() + off, src, bytes);
+        return off;
+    };
+    DScene& d = c->dscene;
+    d.off_nodes = append(sc->nodes, sizeof(hiprz_node) * sc->n_nodes);
+    d.off_tlas_order = append(sc->tlas_order, sizeof(uint32_t) * sc->n_tlas_order);
+    d.off_instances = append(sc->instances, sizeof(hiprz_instance) * sc->n_instances);
+    d.off_tris = append(sc->tris, sizeof(hiprz_tri) * sc->n_tris);
+    d.off_tri_attrs = append(sc->tri_attrs, sizeof(hiprz_tri_attr) * sc->n_tris);
+    d.off_materials = append(sc->materials, sizeof(hiprz_material) * sc->n_materials);
+    d.off_inst_materials = append(sc->inst_materials, sizeof(int32_t) * sc->n_inst_materials);
+    if (blob.size() > 0xFFFFFFF0ull) return fail(c, HIPRZ_ERR_INVALID, "scene geometry exceeds 4 GiB");
+    d.hot_bytes = uint32_t(blob.size());
+
+    RZ_HIP(c, c->hot.assign(blob.data(), blob.size(), c->stream));
+    RZ_HIP(c, c->wnodes.assign(wnodes.data(), wnodes.size(), c->stream));
+    RZ_HIP(c, c->wskip.assign(skip.data(), wnodes.size(), c->stream));
     RZ_HIP(c, c->textures.assign(sc->textures, sc->n_textures, c->stream));
     RZ_HIP(c, c->texels.assign(sc->texels, sc->texel_bytes, c->stream));
     RZ_HIP(c, c->spot_lights.assign(sc->spot_lights, sc->n_spot_lights, c->stream));
     RZ_HIP(c, c->direct_lights.assign(sc->direct_lights, sc->n_direct_lights, c->stream));
-    RZ_HIP(c, hipStreamSynchronize(c->stream));  // `skip` and the caller's arrays may go away after return
+    RZ_HIP(c, hipStreamSynchronize(c->stream));  // host staging vectors and the caller's arrays may go away after return
 
-    DScene& d = c->dscene;
-    d.nodes = reinterpret_cast<const float4*>(c->nodes.ptr);
-    d.skip = c->skip.ptr;
-    d.tlas_order = c->tlas_order.ptr;
-    d.tris = reinterpret_cast<const float4*>(c->tris.ptr);
-    d.tri_attrs = reinterpret_cast<const float4*>(c->tri_attrs.ptr);
-    d.instances = reinterpret_cast<const float4*>(c->instances.ptr);
-    d.inst_materials = c->inst_materials.ptr;
-    d.materials = reinterpret_cast<const float4*>(c->materials.ptr);
+    d.hot = reinterpret_cast<const float4*>(c->hot.ptr);
+    d.nodes = reinterpret_cast<const float4*>(c->hot.ptr + d.off_nodes);
+    d.tlas_order = reinterpret_cast<const uint32_t*>(c->hot.ptr + d.off_tlas_order);
+    d.instances = reinterpret_cast<const float4*>(c->hot.ptr + d.off_instances);
+    d.tris = reinterpret_cast<const float4*>(c->hot.ptr + d.off_tris);
+    d.tri_attrs = reinterpret_cast<const float4*>(c->hot.ptr + d.off_tri_attrs);
+    d.materials = reinterpret_cast<const float4*>(c->hot.ptr + d.off_materials);
+    d.inst_materials = reinterpret_cast<const int32_t*>(c->hot.ptr + d.off_inst_materials);
+    d.wnodes = reinterpret_cast<const float4*>(c->wnodes.ptr);
+    d.wskip = c->wskip.ptr;
+    d.fast_div = fast_div ? 1u : 0u;
     d.textures = reinterpret_cast<const float4*>(c->textures.ptr);
     d.texels = c->texels.ptr;
     d.spot_lights = reinterpret_cast<const float4*>(c->spot_lights.ptr);
@@ -676,6 +783,9 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     d.tlas_root = sc->tlas_root;
     d.n_spot_lights = sc->n_spot_lights;
     d.n_direct_lights = sc->n_direct_lights;
+    // Stage the blob in LDS when three workgroups per CU (the kernel's register-limited residency)
+    // still fit into the CU's 160 KiB together with their traversal stacks.
+    c->lds_scene = size_t(d.hot_bytes) + size_t(c->stack_entries) * 1024u <= kLdsSceneLimit;
     c->have_scene = true;
     c->reset_pending = true;  // world changed => accumulation restarts (cpu_engine_renderer.cpp:108-112)
     c->timings.set("upload scene", timer.ms());
@@ -740,6 +850,13 @@ int hiprz_set_traversal_mode(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
     if (mode != 0 && mode != 1) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: 0 = threaded, 1 = LDS stack");
     c->traversal_mode = mode;
+    return HIPRZ_OK;
+}
+
+int hiprz_set_lds_scene(hiprz_ctx* c, int mode) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (mode < -1 || mode > 1) return fail(c, HIPRZ_ERR_INVALID, "lds scene: -1 auto, 0 off, 1 on");
+    c->lds_scene_override = mode;
     return HIPRZ_OK;
 }
 
@@ -898,6 +1015,18 @@ int hiprz_pick(hiprz_ctx* c, uint32_t x, uint32_t y, int32_t* instance_out, int3
     RZ_HIP(c, hipMemcpyAsync(out2, c->pick_dev.ptr, sizeof out2, hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));
     *instance_out = out2[0], *material_out = out2[1];
+    return HIPRZ_OK;
+}
+
+int hiprz_selftest(hiprz_ctx* c, uint32_t cases_per_thread, uint32_t seed, uint64_t* mismatches, uint64_t* tested) {
+    if (!c || !mismatches || !tested) return HIPRZ_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, hipMemsetAsync(c->counters_dev.ptr, 0, 8 * sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(rz_selftest_div_kernel, dim3(1024), dim3(256), 0, c->stream, cases_per_thread, seed, c->counters_dev.ptr);
+    unsigned long long v[2];
+    RZ_HIP(c, hipMemcpyAsync(v, c->counters_dev.ptr, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    *mismatches = v[0], *tested = v[1];
     return HIPRZ_OK;
 }
 

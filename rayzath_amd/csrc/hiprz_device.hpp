@@ -16,6 +16,13 @@
 namespace hiprz {
 
 #define RZ_DEV __device__ __forceinline__
+// experiment knobs (tools/ab_variants.sh builds one library per setting)
+#ifndef RZ_NESTED_SHARED_RCP
+#define RZ_NESTED_SHARED_RCP 0
+#endif
+#ifndef RZ_MIN_WAVES
+#define RZ_MIN_WAVES 4
+#endif
 #define RZ_PI_F 3.14159265358979323846f
 #define RZ_END 0xFFFFFFFFu
 #define RZ_FLT_MAX 3.402823466e+38f
@@ -45,8 +52,9 @@ namespace hiprz {
 // material = 3, texture = 3, spot light = 3, direct light = 2 float4).
 // ---------------------------------------------------------------------------------------
 struct DScene {
-    const float4* nodes;
-    const uint32_t* skip;  // threaded-walk link per node (derived on upload, see hiprz_api.hip)
+    const float4* nodes;         // hiprz_node records as uploaded (MODE 1)
+    const float4* wnodes;        // walk graph derived on upload (MODE 0): nodes + INSTANCE pseudo-nodes
+    const uint32_t* wskip;       // walk graph: link to the node that follows a node's subtree
     const uint32_t* tlas_order;
     const float4* tris;
     const float4* tri_attrs;
@@ -61,7 +69,25 @@ struct DScene {
     uint32_t tlas_root;
     uint32_t n_spot_lights;
     uint32_t n_direct_lights;
+    uint32_t fast_div;  // every walk-graph coordinate is 0 or in [2^-60, 2^40): shared-reciprocal division is exact
+    // The geometry + shading records live in ONE device buffer ("hot blob": nodes | tlas_order |
+    // instances | tris | tri_attrs | materials | inst_materials, each section 16-B aligned) so a
+    // workgroup can stage it into LDS with one strided copy when it is small enough.
+    uint32_t hot_bytes;
+    const float4* hot;  // start of the blob
+    uint32_t off_nodes, off_tlas_order, off_instances, off_tris, off_tri_attrs, off_materials, off_inst_materials, pad1;
 };
+
+// Re-point the blob sections at a staged copy (LDS).
+RZ_DEV void repoint_hot(DScene& v, const unsigned char* base) {
+    v.nodes = reinterpret_cast<const float4*>(base + v.off_nodes);
+    v.tlas_order = reinterpret_cast<const uint32_t*>(base + v.off_tlas_order);
+    v.instances = reinterpret_cast<const float4*>(base + v.off_instances);
+    v.tris = reinterpret_cast<const float4*>(base + v.off_tris);
+    v.tri_attrs = reinterpret_cast<const float4*>(base + v.off_tri_attrs);
+    v.materials = reinterpret_cast<const float4*>(base + v.off_materials);
+    v.inst_materials = reinterpret_cast<const int32_t*>(base + v.off_inst_materials);
+}
 
 struct DCamera {
     float position[3];
@@ -248,40 +274,19 @@ RZ_DEV float to_local(const InstanceXform& x, const Ray& g, Ray& l) {
 
 // ---------------------------------------------------------------------------------------
 // Tree walk.  The reference descends depth-first, first child then second, testing a
-// node's box when it is entered (cpu_engine_kernel.cpp:254-277, 331-352) — a FIXED order,
-// so the walk needs no stack: every node carries a `skip` link to the node that follows
-// its subtree in that order.  MODE 0 = threaded (skip links, registers only);
-// MODE 1 = explicit stack in LDS (one column per lane, level-major so lanes on the same
-// level hit distinct banks).  Both visit the same nodes in the same order.
+// node's box when it is entered (cpu_engine_kernel.cpp:254-277, 331-352) — a FIXED order.
+// Two implementations visit the same boxes and triangles in that same order:
+//
+//  MODE 0 "threaded" (default): stack-free.  On upload the host derives a walk graph
+//  (hiprz_api.hip: build_walk_graph): every node carries a `skip` link to the node that
+//  follows its subtree, and every world-tree leaf becomes a chain of INSTANCE pseudo-nodes
+//  (box = the instance's world box).  World nodes, instance boxes and mesh nodes are then all
+//  "test a box, follow a link", so each LANE advances through its own sequence of box tests
+//  and the wave never serialises over instances.
+//
+//  MODE 1 "LDS stack": nested loops (world tree -> instances of a leaf -> mesh tree) with an
+//  explicit per-lane stack in LDS (level-major columns: lanes on one level hit distinct banks).
 // ---------------------------------------------------------------------------------------
-template <int MODE>
-struct Walk {
-    uint32_t* stack;  // LDS column of this lane (MODE 1)
-    uint32_t sp;
-    RZ_DEV explicit Walk(uint32_t* lds_column) : stack(lds_column), sp(0) {}
-    RZ_DEV uint32_t mark() const { return sp; }
-    // subtree of n finished (box missed or leaf done): next node in depth-first order
-    RZ_DEV uint32_t next(const DScene& s, uint32_t n, uint32_t base) {
-        if constexpr (MODE == 0) {
-            (void)base;
-            return s.skip[n];
-        } else {
-            (void)n;
-            if (sp == base) return RZ_END;
-            sp -= 1;
-            return stack[sp * blockDim.x];
-        }
-    }
-    // enter inner node: go to first child, remember the second
-    RZ_DEV uint32_t descend(uint32_t first_child) {
-        if constexpr (MODE == 1) {
-            stack[sp * blockDim.x] = first_child + 1u;
-            sp += 1;
-        }
-        return first_child;
-    }
-};
-
 struct Hit {
     int32_t instance;  // -1 = none
     uint32_t triangle;
@@ -289,16 +294,217 @@ struct Hit {
     bool external;
 };
 
+#define RZ_WALK_INNER 0u
+#define RZ_WALK_TRIS 1u
+#define RZ_WALK_INSTANCE 2u
+#define RZ_WALK_CHAIN 3u
+#define RZ_WALK_TYPE_SHIFT 30
+#define RZ_WALK_COUNT_MASK 0x3FFFFFFFu
+
+// Correctly rounded fp32 division with a reciprocal shared between numerators.  This is the
+// instruction sequence hipcc emits for `n / d` (v_rcp_f32, two fma to refine it, then
+// mul + fma,fma + fma,fma on the quotient) WITHOUT the v_div_scale / v_div_fixup wrapping,
+// which is an identity when no operand or result needs rescaling: |d| in [2^-40, 4] and
+// n == 0 or |n| in [2^-84, 2^41] (see safe_for_shared_rcp and the upload-time check of node
+// coordinates).  Outside that range the plain `/` is used.  tests: hiprz_selftest().
+RZ_DEV float refined_rcp(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, r, 1.0f);
+    return __builtin_fmaf(e, r, r);
+}
+RZ_DEV float div_shared(float n, float d, float y) {
+    float q = n * y;
+    float r = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-d, q, n);
+    return __builtin_fmaf(r, y, q);
+}
+// |x| in [2^lo, 2^hi) tested on the exponent field
+RZ_DEV bool exponent_in(float x, int lo, int hi) {
+    const uint32_t e = (__float_as_uint(x) >> 23) & 0xFFu;
+    return (e - uint32_t(lo + 127)) < uint32_t(hi - lo);
+}
+RZ_DEV bool zero_or_exponent_in(float x, int lo, int hi) {
+    return (__float_as_uint(x) & 0x7FFFFFFFu) == 0u || exponent_in(x, lo, hi);
+}
+struct WalkRay {
+    v3 o, d, y;  // y = refined reciprocal of d (valid when `fast`)
+    float near_, far_;
+    bool fast;
+};
+// The nested walk keeps the plain `/` (measured: the extra registers of the shared-reciprocal form
+// cost it an occupancy step); the threaded walk uses the shared reciprocal.
+template <bool SHARED_RCP>
+RZ_DEV void prepare(WalkRay& r, bool scene_fast) {
+    if constexpr (!SHARED_RCP) {
+        r.fast = false;
+        return;
+    }
+    r.fast = scene_fast && exponent_in(r.d.x, -40, 2) && exponent_in(r.d.y, -40, 2) && exponent_in(r.d.z, -40, 2) &&
+             zero_or_exponent_in(r.o.x, -60, 40) && zero_or_exponent_in(r.o.y, -60, 40) && zero_or_exponent_in(r.o.z, -60, 40);
+    r.y = v3{refined_rcp(r.d.x), refined_rcp(r.d.y), refined_rcp(r.d.z)};
+}
+// BoundingBox::rayIntersection (render_parts.cpp:197-217) on a prepared ray
+template <bool SHARED_RCP>
+RZ_DEV bool box_hit(v3 mn, v3 mx, const WalkRay& r) {
+    float t1, t2, t3, t4, t5, t6;
+    if (SHARED_RCP && __all(r.fast)) {  // wave-uniform branch
+        t1 = div_shared(mn.x - r.o.x, r.d.x, r.y.x);
+        t2 = div_shared(mx.x - r.o.x, r.d.x, r.y.x);
+        t3 = div_shared(mn.y - r.o.y, r.d.y, r.y.y);
+        t4 = div_shared(mx.y - r.o.y, r.d.y, r.y.y);
+        t5 = div_shared(mn.z - r.o.z, r.d.z, r.y.z);
+        t6 = div_shared(mx.z - r.o.z, r.d.z, r.y.z);
+    } else {
+        t1 = (mn.x - r.o.x) / r.d.x;
+        t2 = (mx.x - r.o.x) / r.d.x;
+        t3 = (mn.y - r.o.y) / r.d.y;
+        t4 = (mx.y - r.o.y) / r.d.y;
+        t5 = (mn.z - r.o.z) / r.d.z;
+        t6 = (mx.z - r.o.z) / r.d.z;
+    }
+    const float tmin = max_gt(max_gt(min_lt(t1, t2), min_lt(t3, t4)), min_lt(t5, t6));
+    const float tmax = min_lt(min_lt(max_gt(t1, t2), max_gt(t3, t4)), max_gt(t5, t6));
+    return !(tmax < r.near_ || tmin > tmax || tmin > r.far_);
+}
+RZ_DEV bool tri_hit(v3 v1, v3 v2, v3 vv3, const WalkRay& r, float& t, float& b1, float& b2, float& det) {
+    Ray q;
+    q.o = r.o, q.d = r.d, q.near_ = r.near_, q.far_ = r.far_;
+    return tri_hit(v1, v2, vv3, q, t, b1, b2, det);
+}
+
+// closest-hit (ANY = false: traverseWorld + closestIntersection, cpu_engine_kernel.cpp:254-352)
+// and any-hit (ANY = true: anyIntersection, :398-481) on the walk graph.
+// closest: returns 0 = root box missed, 1 = walked, nothing hit, 2 = hit.
+// any:     returns 0 = occluded, 1 = clear (the mask alpha; "TODO: texture fetch" :465).
+template <bool ANY, bool COUNT>
+RZ_DEV int walk_threaded(const DScene& s, Ray& ray, Hit& hit, Counters& cnt) {
+    WalkRay cur;
+    cur.o = ray.o, cur.d = ray.d, cur.near_ = ray.near_, cur.far_ = ray.far_;
+    prepare<true>(cur, s.fast_div != 0u);
+    // state saved while a lane is inside an instance (mesh space)
+    v3 world_o = cur.o, world_d = cur.d;
+    float world_near = cur.near_, len = 1.0f;
+    uint32_t ret = RZ_END, inst = 0u;
+    bool in_mesh = false, found_here = false, root_missed = false;
+
+    uint32_t n = s.tlas_root;
+    while (true) {
+        if (n == RZ_END) {
+            if (!in_mesh) break;
+            // leave the instance: cpu_engine_kernel.cpp:320-329
+            if constexpr (!ANY) {
+                if (found_here) {
+                    hit.instance = int32_t(inst);
+                    world_near = cur.near_ / len;
+                    cur.far_ = cur.far_ / len;
+                } else {
+                    cur.far_ = ray.far_;
+                }
+                ray.far_ = cur.far_;
+            } else {
+                cur.far_ = ray.far_;
+            }
+            cur.o = world_o, cur.d = world_d, cur.near_ = world_near;
+            prepare<true>(cur, s.fast_div != 0u);
+            in_mesh = false;
+            n = ret;
+            continue;
+        }
+        const float4 n0 = s.wnodes[2 * n], n1 = s.wnodes[2 * n + 1];
+        const uint32_t link = s.wskip[n];
+        RZ_COUNT(box_tests);
+        if (box_hit<true>(xyz(n0), v3{n0.w, n1.x, n1.y}, cur)) {
+            const uint32_t a = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+            const uint32_t type = meta >> RZ_WALK_TYPE_SHIFT;
+            if (type == RZ_WALK_INNER || type == RZ_WALK_CHAIN) {
+                n = a;
+                continue;
+            }
+            if (type == RZ_WALK_INSTANCE) {  // cpu_engine_kernel.cpp:307-319 / :441-448
+                inst = a;
+                const InstanceXform x = load_instance_xform(s, inst);
+                world_o = cur.o, world_d = cur.d, world_near = cur.near_;
+                if constexpr (!ANY) ray.far_ = cur.far_;
+                cur.o = transform_backward(x.xa, x.ya, x.za, cur.o - x.position) / x.scale;
+                cur.d = transform_backward(x.xa, x.ya, x.za, cur.d) / x.scale;
+                len = magnitude(cur.d);
+                cur.near_ = cur.near_ * len;
+                cur.far_ = cur.far_ * len;
+                cur.d = cur.d * (1.0f / len);
+                prepare<true>(cur, s.fast_div != 0u);
+                in_mesh = true, found_here = false;
+                ret = link;
+                n = x.blas_root;
+                continue;
+            }
+            const uint32_t end = a + (meta & RZ_WALK_COUNT_MASK);
+            for (uint32_t i = a; i < end; ++i) {
+                const float4 ta = s.tris[3 * i], tb = s.tris[3 * i + 1], tc = s.tris[3 * i + 2];
+                float t, b1, b2, det;
+                RZ_COUNT(tri_tests);
+                if (tri_hit(xyz(ta), xyz(tb), xyz(tc), cur, t, b1, b2, det)) {
+                    if constexpr (ANY) return 0;
+                    cur.far_ = t;
+                    hit.triangle = i;
+                    hit.external = det > 0.0f;
+                    hit.bx = b1, hit.by = b2;
+                    found_here = true;
+                }
+            }
+        } else if (n == s.tlas_root) {
+            root_missed = true;  // cpu_engine_kernel.cpp:283 / :402
+        }
+        n = link;
+    }
+    if constexpr (ANY) return 1;
+    ray.near_ = world_near;
+    ray.far_ = cur.far_;
+    if (root_missed) return 0;
+    return hit.instance >= 0 ? 2 : 1;
+}
+
+// ---- MODE 1: nested loops with an LDS stack ----
+struct LdsStack {
+    uint32_t* column;  // this lane's column: entry k lives at column[k * blockDim.x]
+    uint32_t sp;
+    RZ_DEV explicit LdsStack(uint32_t* lds_column) : column(lds_column), sp(0) {}
+    RZ_DEV uint32_t mark() const { return sp; }
+    RZ_DEV uint32_t next(uint32_t base) {  // subtree finished: pop the pending second child
+        if (sp == base) return RZ_END;
+        sp -= 1;
+        return column[sp * blockDim.x];
+    }
+    RZ_DEV uint32_t descend(uint32_t first_child) {  // enter inner node: remember the second child
+        column[sp * blockDim.x] = first_child + 1u;
+        sp += 1;
+        return first_child;
+    }
+};
+
+// Instance entry: Transformation::transformG2L (render_parts.cpp:117-125) + the range rescale of
+// cpu_engine_kernel.cpp:307-312 / :442-445 on a prepared ray.  Returns the length factor.
+RZ_DEV float to_local(const InstanceXform& x, const WalkRay& g, WalkRay& l, bool scene_fast) {
+    l.o = transform_backward(x.xa, x.ya, x.za, g.o - x.position) / x.scale;
+    l.d = transform_backward(x.xa, x.ya, x.za, g.d) / x.scale;
+    const float len = magnitude(l.d);
+    l.near_ = g.near_ * len;
+    l.far_ = g.far_ * len;
+    l.d = l.d * (1.0f / len);
+    prepare<RZ_NESTED_SHARED_RCP != 0>(l, scene_fast);
+    return len;
+}
+
 // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352
-template <int MODE, bool COUNT>
-RZ_DEV bool closest_in_mesh(const DScene& s, Walk<MODE>& w, uint32_t root, Ray& lr, Hit& hit, Counters& cnt) {
+template <bool COUNT>
+RZ_DEV bool closest_in_mesh_stack(const DScene& s, LdsStack& w, uint32_t root, WalkRay& lr, Hit& hit, Counters& cnt) {
     bool found = false;
     const uint32_t base = w.mark();
     uint32_t n = root;
     while (n != RZ_END) {
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
-        if (box_hit(xyz(n0), v3{n0.w, n1.x, n1.y}, lr)) {
+        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(xyz(n0), v3{n0.w, n1.x, n1.y}, lr)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             if (!(meta & HIPRZ_NODE_LEAF)) {
                 n = w.descend(begin);
@@ -318,27 +524,24 @@ RZ_DEV bool closest_in_mesh(const DScene& s, Walk<MODE>& w, uint32_t root, Ray& 
                 }
             }
         }
-        n = w.next(s, n, base);
+        n = w.next(base);
     }
     return found;
 }
 
-// traverseWorld + closestIntersection(instance): cpu_engine_kernel.cpp:254-330.
-// Returns 0 = no instances / root box missed (the reference returns before it computes the
-// sky texcrd, :282-283), 1 = walked, nothing hit (sky texcrd is computed, :292-295), 2 = hit.
-template <int MODE, bool COUNT>
-RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit, Counters& cnt) {
-    hit.instance = -1;
-    hit.triangle = 0;
-    hit.bx = hit.by = 0.0f;
-    hit.external = true;
-    if (s.n_instances == 0) return 0;
-    Walk<MODE> w(lds_column);
+// traverseWorld + closestIntersection(instance): cpu_engine_kernel.cpp:254-330
+template <bool COUNT>
+RZ_DEV int closest_hit_stack(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit, Counters& cnt) {
+    LdsStack w(lds_column);
+    const bool scene_fast = s.fast_div != 0u;
+    WalkRay g;
+    g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
+    prepare<RZ_NESTED_SHARED_RCP != 0>(g, scene_fast);
     uint32_t n = s.tlas_root;
     while (n != RZ_END) {
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
-        if (box_hit(xyz(n0), v3{n0.w, n1.x, n1.y}, ray)) {
+        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(xyz(n0), v3{n0.w, n1.x, n1.y}, g)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             if (!(meta & HIPRZ_NODE_LEAF)) {
                 n = w.descend(begin);
@@ -350,36 +553,38 @@ RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit
                 v3 mn, mx;
                 load_instance_box(s, inst, mn, mx);
                 RZ_COUNT(box_tests);
-                if (!box_hit(mn, mx, ray)) continue;
+                if (!box_hit<RZ_NESTED_SHARED_RCP != 0>(mn, mx, g)) continue;
                 const InstanceXform x = load_instance_xform(s, inst);
-                Ray lr;
-                const float len = to_local(x, ray, lr);
-                if (closest_in_mesh<MODE, COUNT>(s, w, x.blas_root, lr, hit, cnt)) {
+                WalkRay lr;
+                const float len = to_local(x, g, lr, scene_fast);
+                if (closest_in_mesh_stack<COUNT>(s, w, x.blas_root, lr, hit, cnt)) {
                     hit.instance = int32_t(inst);
-                    ray.near_ = lr.near_ / len;
-                    ray.far_ = lr.far_ / len;
+                    g.near_ = lr.near_ / len;
+                    g.far_ = lr.far_ / len;
                 }
             }
         } else if (n == s.tlas_root) {
             return 0;  // root box missed (cpu_engine_kernel.cpp:283)
         }
-        n = w.next(s, n, 0u);
+        n = w.next(0u);
     }
+    ray.near_ = g.near_, ray.far_ = g.far_;
     return hit.instance >= 0 ? 2 : 1;
 }
 
-// anyIntersection: cpu_engine_kernel.cpp:398-481.  The mask is 1 or 0 ("TODO: texture
-// fetch" :465), so a bool is carried: true = occluded.  Returns the mask alpha.
-template <int MODE, bool COUNT>
-RZ_DEV float any_hit(const DScene& s, uint32_t* lds_column, const Ray& ray, Counters& cnt) {
-    RZ_COUNT(shadow_rays);
-    if (s.n_instances == 0) return 0.0f;
-    Walk<MODE> w(lds_column);
+// anyIntersection: cpu_engine_kernel.cpp:398-481
+template <bool COUNT>
+RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray, Counters& cnt) {
+    LdsStack w(lds_column);
+    const bool scene_fast = s.fast_div != 0u;
+    WalkRay g;
+    g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
+    prepare<RZ_NESTED_SHARED_RCP != 0>(g, scene_fast);
     uint32_t n = s.tlas_root;
     while (n != RZ_END) {
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
-        if (box_hit(xyz(n0), v3{n0.w, n1.x, n1.y}, ray)) {
+        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(xyz(n0), v3{n0.w, n1.x, n1.y}, g)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             if (!(meta & HIPRZ_NODE_LEAF)) {
                 n = w.descend(begin);
@@ -391,17 +596,17 @@ RZ_DEV float any_hit(const DScene& s, uint32_t* lds_column, const Ray& ray, Coun
                 v3 mn, mx;
                 load_instance_box(s, inst, mn, mx);
                 RZ_COUNT(box_tests);
-                if (!box_hit(mn, mx, ray)) continue;
+                if (!box_hit<RZ_NESTED_SHARED_RCP != 0>(mn, mx, g)) continue;
                 const InstanceXform x = load_instance_xform(s, inst);
-                Ray lr;
-                to_local(x, ray, lr);
+                WalkRay lr;
+                to_local(x, g, lr, scene_fast);
                 // anyIntersection(const Mesh&, ...) :450-481
                 const uint32_t base = w.mark();
                 uint32_t m = x.blas_root;
                 while (m != RZ_END) {
                     const float4 m0 = s.nodes[2 * m], m1 = s.nodes[2 * m + 1];
                     RZ_COUNT(box_tests);
-                    if (box_hit(xyz(m0), v3{m0.w, m1.x, m1.y}, lr)) {
+                    if (box_hit<RZ_NESTED_SHARED_RCP != 0>(xyz(m0), v3{m0.w, m1.x, m1.y}, lr)) {
                         const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                         if (!(mmeta & HIPRZ_NODE_LEAF)) {
                             m = w.descend(mbegin);
@@ -415,15 +620,42 @@ RZ_DEV float any_hit(const DScene& s, uint32_t* lds_column, const Ray& ray, Coun
                             if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) return 0.0f;
                         }
                     }
-                    m = w.next(s, m, base);
+                    m = w.next(base);
                 }
             }
         } else if (n == s.tlas_root) {
             return 1.0f;  // root box missed (:402)
         }
-        n = w.next(s, n, 0u);
+        n = w.next(0u);
     }
     return 1.0f;
+}
+
+// Returns 0 = no instances / root box missed (the reference returns before it computes the
+// sky texcrd, cpu_engine_kernel.cpp:282-283), 1 = walked, nothing hit (sky texcrd is computed,
+// :292-295), 2 = hit.
+template <int MODE, bool COUNT>
+RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit, Counters& cnt) {
+    hit.instance = -1;
+    hit.triangle = 0;
+    hit.bx = hit.by = 0.0f;
+    hit.external = true;
+    if (s.n_instances == 0) return 0;
+    if constexpr (MODE == 0) return walk_threaded<false, COUNT>(s, ray, hit, cnt);
+    else return closest_hit_stack<COUNT>(s, lds_column, ray, hit, cnt);
+}
+// anyIntersection(const RangedRay&): returns the shadow mask's alpha (0 or 1)
+template <int MODE, bool COUNT>
+RZ_DEV float any_hit(const DScene& s, uint32_t* lds_column, const Ray& ray, Counters& cnt) {
+    RZ_COUNT(shadow_rays);
+    if (s.n_instances == 0) return 0.0f;
+    if constexpr (MODE == 0) {
+        Ray r = ray;
+        Hit unused;
+        return float(walk_threaded<true, COUNT>(s, r, unused, cnt));
+    } else {
+        return any_hit_stack<COUNT>(s, lds_column, ray, cnt);
+    }
 }
 
 // --- materials and textures -------------------------------------------------------------

@@ -1,0 +1,81 @@
+"""Multi-GPU frame assembly: one process per GPU, the framebuffer sharded by interleaved
+32x8-pixel tiles (tile t belongs to rank t % world; include/hiprz.h: hiprz_set_shard), the
+scene replicated, and ONE collective per readback: a gather of the tile-major RGBA32F
+accumulators to rank 0 over RCCL (torch.distributed backend "nccl") — SURVEY.md §8e.
+There is no collective on the per-pass data path: pixels are independent.
+
+The reference has nothing to mirror here (single device: RayZath/cuda_engine_core.cu:17).
+"""
+import numpy as np
+
+TILE_W, TILE_H, TILE_PIXELS = 32, 8, 256
+
+
+def tile_grid(width, height):
+    return (width + TILE_W - 1) // TILE_W, (height + TILE_H - 1) // TILE_H
+
+
+def owned_tile_count(rank, world, n_tiles):
+    return (n_tiles - rank + world - 1) // world if rank < n_tiles else 0
+
+
+def tile_pixel_coords(width, height, rank, world):
+    """(x, y) of every slot of the tile-major local layout of shard (rank, world), shape
+    (owned_tiles*256,), with -1 for slots outside the frame.  Mirrors pixel_of_thread() in
+    rayzath_amd/csrc/hiprz_device.hpp; used to check the device layout and by the CPU tests."""
+    tiles_x, tiles_y = tile_grid(width, height)
+    n = owned_tile_count(rank, world, tiles_x * tiles_y)
+    lt = np.arange(n, dtype=np.int64)[:, None]
+    tid = np.arange(TILE_PIXELS, dtype=np.int64)[None, :]
+    tile = lt * world + rank
+    tx, ty = tile % tiles_x, tile // tiles_x
+    wave, lane = tid >> 6, tid & 63
+    x = tx * TILE_W + wave * 8 + (lane & 7)
+    y = ty * TILE_H + (lane >> 3)
+    inside = (x < width) & (y < height)
+    return np.where(inside, x, -1).reshape(-1), np.where(inside, y, -1).reshape(-1)
+
+
+def gather_tiles(local_tiles, rank, world, capacity_max, dist, dst=0):
+    """Gather every rank's tile-major buffer (padded to `capacity_max` rows) on `dst`.
+    local_tiles: torch tensor (capacity_max, C).  Returns the list of per-rank tensors on dst,
+    None elsewhere.  Works with any backend (nccl on GPUs, gloo in the CPU tests)."""
+    import torch
+
+    if world == 1:
+        return [local_tiles]
+    gather_list = [torch.empty_like(local_tiles) for _ in range(world)] if rank == dst else None
+    dist.gather(local_tiles, gather_list=gather_list, dst=dst)
+    return gather_list
+
+
+class ShardedFrame:
+    """Rank-local driver: renders the owned tiles and assembles full frames on rank 0."""
+
+    def __init__(self, ctx, rank, world, width, height, dist=None, device=None):
+        import torch
+
+        self.ctx, self.rank, self.world, self.dist = ctx, rank, world, dist
+        self.width, self.height = width, height
+        tiles_x, tiles_y = tile_grid(width, height)
+        self.capacity_max = owned_tile_count(0, world, tiles_x * tiles_y) * TILE_PIXELS
+        self.device = device
+        self.local = torch.zeros((self.capacity_max, 4), dtype=torch.float32, device=device)
+        self.image = torch.zeros((height, width, 4), dtype=torch.float32, device=device) if rank == 0 else None
+        self.rgba8 = torch.zeros((height, width, 4), dtype=torch.uint8, device=device) if rank == 0 else None
+
+    def gather(self):
+        """Accumulators of all shards -> row-major RGBA32F + tone-mapped RGBA8 on rank 0."""
+        import torch
+
+        ctx = self.ctx
+        ctx.export_accum_tiles(self.local.data_ptr(), self.local.numel() * 4)
+        ctx.sync()  # hand the buffer from the render stream to torch's stream
+        parts = gather_tiles(self.local, self.rank, self.world, self.capacity_max, self.dist)
+        if self.rank != 0:
+            return None
+        torch.cuda.current_stream().synchronize()  # and back to the render stream
+        for r, part in enumerate(parts):
+            ctx.untile_accum(part.data_ptr(), r, self.world, self.image.data_ptr())
+        ctx.tonemap_image(self.image.data_ptr(), self.rgba8.data_ptr())
+        return self.image

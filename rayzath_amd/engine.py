@@ -79,6 +79,9 @@ class Context:
     def set_traversal_mode(self, mode):
         self._check(self.lib.hiprz_set_traversal_mode(self._ctx, mode))
 
+    def set_lds_scene(self, mode):
+        self._check(self.lib.hiprz_set_lds_scene(self._ctx, mode))
+
     # --- rendering ---
     def reset(self):
         self._check(self.lib.hiprz_reset(self._ctx))
@@ -134,6 +137,11 @@ class Context:
         i, m = C.c_int32(), C.c_int32()
         self._check(self.lib.hiprz_pick(self._ctx, x, y, C.byref(i), C.byref(m)))
         return i.value, m.value
+
+    def selftest(self, cases_per_thread=64, seed=1):
+        bad, n = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.hiprz_selftest(self._ctx, cases_per_thread, seed, C.byref(bad), C.byref(n)))
+        return bad.value, n.value
 
     def timings(self):
         buf = C.create_string_buffer(4096)
