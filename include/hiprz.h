@@ -246,6 +246,14 @@ int hiprz_destroy(hiprz_ctx* ctx);
 /* message of the last non-OK return on this context (ctx may be NULL for create failures) */
 const char* hiprz_last_error(const hiprz_ctx* ctx);
 
+/* Pure host check of a scene snapshot (the same one hiprz_upload_scene runs before it touches the
+ * device): every index in range, trees disjoint and acyclic, map kinds consistent.  Writes the
+ * reason into message on failure. */
+int hiprz_validate_scene(const hiprz_scene* scene, char* message, size_t len);
+/* sizeof() of the POD records, in the order node, tri, tri_attr, instance, material, texture,
+ * spot_light, direct_light, scene, camera, config, counters, mesh_desc (for binding generators). */
+void hiprz_abi_sizes(uint32_t out[13]);
+
 /* --- host→device mirroring (replaces Cuda::World::reconstruct*, cuda_world.cu:28-57) --- */
 int hiprz_upload_scene(hiprz_ctx* ctx, const hiprz_scene* scene);   /* validates, copies; caller keeps ownership */
 int hiprz_upload_camera(hiprz_ctx* ctx, const hiprz_camera* camera); /* (re)allocates per-pixel state on resize */

@@ -102,6 +102,8 @@ ENTRY_POINTS = {
     "hiprz_create": (C.c_int, [C.POINTER(P), C.c_int]),
     "hiprz_destroy": (C.c_int, [P]),
     "hiprz_last_error": (C.c_char_p, [P]),
+    "hiprz_validate_scene": (C.c_int, [C.POINTER(Scene), C.c_char_p, SZ]),
+    "hiprz_abi_sizes": (None, [P]),
     "hiprz_upload_scene": (C.c_int, [P, C.POINTER(Scene)]),
     "hiprz_upload_camera": (C.c_int, [P, C.POINTER(Camera)]),
     "hiprz_set_config": (C.c_int, [P, C.POINTER(Config)]),

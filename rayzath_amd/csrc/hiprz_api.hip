@@ -586,9 +586,87 @@ int read_untiled(hiprz_ctx* c, const T* tiles, T* dst, size_t bytes, const char*
     return HIPRZ_OK;
 }
 
+// Everything the kernels will dereference is checked here, on the host, before any launch: a
+// bad index or a cyclic tree would otherwise fault or hang the GPU.  Also derives the skip links,
+// the world-tree leaves and the tree depths the upload needs.
+struct SceneCheck {
+    std::string error;
+    std::vector<uint32_t> skip;
+    std::vector<uint32_t> world_leaves;
+    uint32_t world_depth = 0, mesh_depth = 0;
+};
+int check_scene(const hiprz_scene* sc, SceneCheck& out) {
+    auto bad = [&out](const std::string& m) {
+        out.error = m;
+        return HIPRZ_ERR_INVALID;
+    };
+    if (!sc) return bad("scene is null");
+    // ---- validate everything the kernels will dereference, on the host, before any launch ----
+    if (sc->n_materials < 2 || !sc->materials) return bad("scene needs materials[0]=world, [1]=default");
+    if (sc->n_materials > 65536u) return bad("more than 65536 materials");
+    if ((sc->n_nodes && !sc->nodes) || (sc->n_tris && (!sc->tris || !sc->tri_attrs)) || (sc->n_instances && !sc->instances) ||
+        (sc->n_tlas_order && !sc->tlas_order) || (sc->n_inst_materials && !sc->inst_materials) ||
+        (sc->n_textures && !sc->textures) || (sc->texel_bytes && !sc->texels) || (sc->n_spot_lights && !sc->spot_lights) ||
+        (sc->n_direct_lights && !sc->direct_lights))
+        return bad("upload_scene: null array with non-zero count");
+    for (uint32_t i = 0; i < sc->n_textures; ++i) {
+        const hiprz_texture& t = sc->textures[i];
+        const uint64_t texel = t.kind == HIPRZ_TEX_R8 ? 1u : 4u;
+        if (t.kind > HIPRZ_TEX_R32F || t.width == 0 || t.height == 0 || (t.offset & 3u) ||
+            uint64_t(t.offset) + texel * t.width * t.height > sc->texel_bytes)
+            return bad("texture " + std::to_string(i) + ": bad kind/size/offset");
+    }
+    auto tex_ok = [&](int32_t t, uint32_t kind) { return t < 0 || (uint32_t(t) < sc->n_textures && sc->textures[t].kind == kind); };
+    for (uint32_t i = 0; i < sc->n_materials; ++i) {
+        const hiprz_material& m = sc->materials[i];
+        if (!tex_ok(m.texture, HIPRZ_TEX_RGBA8) || !tex_ok(m.normal_map, HIPRZ_TEX_RGBA8) ||
+            !tex_ok(m.metalness_map, HIPRZ_TEX_R8) || !tex_ok(m.roughness_map, HIPRZ_TEX_R8) ||
+            !tex_ok(m.emission_map, HIPRZ_TEX_R32F))
+            return bad("material " + std::to_string(i) + ": map index/kind invalid");
+    }
+    for (uint32_t i = 0; i < sc->n_inst_materials; ++i)
+        if (sc->inst_materials[i] >= int32_t(sc->n_materials))
+            return bad("inst_materials[" + std::to_string(i) + "] out of range");
+    for (uint32_t i = 0; i < sc->n_tlas_order; ++i)
+        if (sc->tlas_order[i] >= sc->n_instances) return bad("tlas_order entry out of range");
+    for (uint32_t i = 0; i < sc->n_instances; ++i) {
+        const hiprz_instance& in = sc->instances[i];
+        if (in.material_count > 64u || uint64_t(in.material_base) + in.material_count > sc->n_inst_materials)
+            return bad("instance " + std::to_string(i) + ": material table out of range");
+    }
+    std::vector<uint32_t> skip(sc->n_nodes ? sc->n_nodes : 1, RZ_END);
+    TreeCheck check{sc, skip, std::vector<uint8_t>(sc->n_nodes ? sc->n_nodes : 1, 0)};
+    uint32_t world_depth = 0, mesh_depth = 0;
+    if (sc->n_instances) {
+        if (!check.walk(sc->tlas_root, true)) return bad("world tree: " + check.error);
+        world_depth = check.max_depth;
+        std::vector<uint8_t> root_seen(sc->n_nodes, 0);
+        for (uint32_t i = 0; i < sc->n_tlas_order; ++i) {
+            const uint32_t root = sc->instances[sc->tlas_order[i]].blas_root;
+            if (root >= sc->n_nodes) return bad("instance mesh root out of range");
+            if (root_seen[root]) continue;
+            root_seen[root] = 1;
+            check.max_depth = 0;
+            if (!check.walk(root, false)) return bad("mesh tree: " + check.error);
+            mesh_depth = std::max(mesh_depth, check.max_depth);
+        }
+    }
+    out.skip = std::move(skip);
+    out.world_leaves = std::move(check.world_leaves);
+    out.world_depth = world_depth, out.mesh_depth = mesh_depth;
+    return HIPRZ_OK;
+}
+
 }  // namespace
 
 extern "C" {
+
+int hiprz_validate_scene(const hiprz_scene* scene, char* message, size_t len) {
+    SceneCheck chk;
+    const int rc = check_scene(scene, chk);
+    if (message && len) std::snprintf(message, len, "%s", chk.error.c_str());
+    return rc;
+}
 
 int hiprz_create(hiprz_ctx** out, int device_id) {
     if (!out) return fail(nullptr, HIPRZ_ERR_INVALID, "hiprz_create: out is null");
@@ -643,58 +721,14 @@ const char* hiprz_last_error(const hiprz_ctx* c) { return c ? c->error.c_str() :
 
 int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     if (!c) return HIPRZ_ERR_INVALID;
-    if (!sc) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: scene is null");
     StageTimer timer;
-    // ---- validate everything the kernels will dereference, on the host, before any launch ----
-    if (sc->n_materials < 2 || !sc->materials) return fail(c, HIPRZ_ERR_INVALID, "scene needs materials[0]=world, [1]=default");
-    if (sc->n_materials > 65536u) return fail(c, HIPRZ_ERR_INVALID, "more than 65536 materials");
-    if ((sc->n_nodes && !sc->nodes) || (sc->n_tris && (!sc->tris || !sc->tri_attrs)) || (sc->n_instances && !sc->instances) ||
-        (sc->n_tlas_order && !sc->tlas_order) || (sc->n_inst_materials && !sc->inst_materials) ||
-        (sc->n_textures && !sc->textures) || (sc->texel_bytes && !sc->texels) || (sc->n_spot_lights && !sc->spot_lights) ||
-        (sc->n_direct_lights && !sc->direct_lights))
-        return fail(c, HIPRZ_ERR_INVALID, "upload_scene: null array with non-zero count");
-    for (uint32_t i = 0; i < sc->n_textures; ++i) {
-        const hiprz_texture& t = sc->textures[i];
-        const uint64_t texel = t.kind == HIPRZ_TEX_R8 ? 1u : 4u;
-        if (t.kind > HIPRZ_TEX_R32F || t.width == 0 || t.height == 0 || (t.offset & 3u) ||
-            uint64_t(t.offset) + texel * t.width * t.height > sc->texel_bytes)
-            return fail(c, HIPRZ_ERR_INVALID, "texture " + std::to_string(i) + ": bad kind/size/offset");
-    }
-    auto tex_ok = [&](int32_t t, uint32_t kind) { return t < 0 || (uint32_t(t) < sc->n_textures && sc->textures[t].kind == kind); };
-    for (uint32_t i = 0; i < sc->n_materials; ++i) {
-        const hiprz_material& m = sc->materials[i];
-        if (!tex_ok(m.texture, HIPRZ_TEX_RGBA8) || !tex_ok(m.normal_map, HIPRZ_TEX_RGBA8) ||
-            !tex_ok(m.metalness_map, HIPRZ_TEX_R8) || !tex_ok(m.roughness_map, HIPRZ_TEX_R8) ||
-            !tex_ok(m.emission_map, HIPRZ_TEX_R32F))
-            return fail(c, HIPRZ_ERR_INVALID, "material " + std::to_string(i) + ": map index/kind invalid");
-    }
-    for (uint32_t i = 0; i < sc->n_inst_materials; ++i)
-        if (sc->inst_materials[i] >= int32_t(sc->n_materials))
-            return fail(c, HIPRZ_ERR_INVALID, "inst_materials[" + std::to_string(i) + "] out of range");
-    for (uint32_t i = 0; i < sc->n_tlas_order; ++i)
-        if (sc->tlas_order[i] >= sc->n_instances) return fail(c, HIPRZ_ERR_INVALID, "tlas_order entry out of range");
-    for (uint32_t i = 0; i < sc->n_instances; ++i) {
-        const hiprz_instance& in = sc->instances[i];
-        if (in.material_count > 64u || uint64_t(in.material_base) + in.material_count > sc->n_inst_materials)
-            return fail(c, HIPRZ_ERR_INVALID, "instance " + std::to_string(i) + ": material table out of range");
-    }
-    std::vector<uint32_t> skip(sc->n_nodes ? sc->n_nodes : 1, RZ_END);
-    TreeCheck check{sc, skip, std::vector<uint8_t>(sc->n_nodes ? sc->n_nodes : 1, 0)};
-    uint32_t world_depth = 0, mesh_depth = 0;
-    if (sc->n_instances) {
-        if (!check.walk(sc->tlas_root, true)) return fail(c, HIPRZ_ERR_INVALID, "world tree: " + check.error);
-        world_depth = check.max_depth;
-        std::vector<uint8_t> root_seen(sc->n_nodes, 0);
-        for (uint32_t i = 0; i < sc->n_tlas_order; ++i) {
-            const uint32_t root = sc->instances[sc->tlas_order[i]].blas_root;
-            if (root >= sc->n_nodes) return fail(c, HIPRZ_ERR_INVALID, "instance mesh root out of range");
-            if (root_seen[root]) continue;
-            root_seen[root] = 1;
-            check.max_depth = 0;
-            if (!check.walk(root, false)) return fail(c, HIPRZ_ERR_INVALID, "mesh tree: " + check.error);
-            mesh_depth = std::max(mesh_depth, check.max_depth);
-        }
-    }
+    SceneCheck chk;
+    if (check_scene(sc, chk) != HIPRZ_OK) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: " + chk.error);
+    std::vector<uint32_t>& skip = chk.skip;
+    struct {
+        std::vector<uint32_t>& world_leaves;
+    } check{chk.world_leaves};
+    const uint32_t world_depth = chk.world_depth, mesh_depth = chk.mesh_depth;
     c->stack_entries = world_depth + mesh_depth + 2u;
 
     // ---- walk graph of the threaded traversal (hiprz_device.hpp: walk_threaded) ----

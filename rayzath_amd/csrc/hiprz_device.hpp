@@ -726,7 +726,7 @@ struct Surface {
 template <bool COUNT>
 RZ_DEV void analyze_intersection(const DScene& s, const Hit& hit, Surface& sf, Material& m, Counters& cnt) {
     const uint32_t inst = uint32_t(hit.instance);
-    const float4 i0 = s.instances[7 * inst + 0], i1 = s.instances[7 * inst + 1], i2 = s.instances[7 * inst + 2],
+    const float4 i1 = s.instances[7 * inst + 1], i2 = s.instances[7 * inst + 2],
                  i3 = s.instances[7 * inst + 3], i4 = s.instances[7 * inst + 4];
     const v3 scale = xyz(i1), xa = xyz(i2), ya = xyz(i3), za = xyz(i4);
     const uint32_t material_base = __float_as_uint(i1.w), material_count = __float_as_uint(i2.w);

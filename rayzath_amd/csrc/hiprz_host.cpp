@@ -338,6 +338,14 @@ float hiprz_seed_value(uint32_t seed, uint32_t pass, uint32_t i) {
     return float(h >> 8) * (20.0f / 16777216.0f) - 10.0f;
 }
 
+void hiprz_abi_sizes(uint32_t out[13]) {
+    const uint32_t v[13] = {sizeof(hiprz_node),   sizeof(hiprz_tri),      sizeof(hiprz_tri_attr),   sizeof(hiprz_instance),
+                            sizeof(hiprz_material), sizeof(hiprz_texture), sizeof(hiprz_spot_light), sizeof(hiprz_direct_light),
+                            sizeof(hiprz_scene),  sizeof(hiprz_camera),   sizeof(hiprz_config),     sizeof(hiprz_counters),
+                            sizeof(hiprz_mesh_desc)};
+    std::memcpy(out, v, sizeof v);
+}
+
 const char* hiprz_version(void) { return "hiprz 0.1 (gfx950)"; }
 
 }  // extern "C"

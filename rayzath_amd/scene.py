@@ -275,7 +275,7 @@ def generate_sphere(resolution=16, normals=True, texture_coordinates=True, displ
             tv.append((t * r + p, (t + 1) * r + (p + 1) % r, (t + 1) * r + p))
             tt.append((t * (r + 1) + p, (t + 1) * (r + 1) + (p + 1), (t + 1) * (r + 1) + p))
     tv = np.array(tv, dtype=np.uint32)
-    tt = np.array(tt, dtype=np.uint32)
+    tt = np.array(tt, dtype=np.int64).astype(np.uint32) if texture_coordinates else None
     if texture_coordinates:
         # the reference's bottom-fan texcrd ids (world.cpp:297-300) reach below the last ring row
         # for i = 0; keep them in range (the reference would index out of bounds there)

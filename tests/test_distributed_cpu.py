@@ -1,0 +1,86 @@
+"""Multi-GPU frame assembly on CPU: world_size-2 (and 3) gloo process groups exercise the same
+`gather_tiles` collective and tile layout the GPU path uses (rayzath_amd/distributed.py); the
+device-side layout itself (pixel_of_thread in hiprz_device.hpp) is checked against
+tile_pixel_coords by the GPU test test_sharded_render_equals_unsharded."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from rayzath_amd.distributed import TILE_PIXELS, owned_tile_count, tile_grid, tile_pixel_coords
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (256, 256), (200, 120), (33, 9), (1, 1), (3840, 2160)])
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_tiles_partition_the_frame(size, world):
+    W, H = size
+    tiles_x, tiles_y = tile_grid(W, H)
+    seen = np.zeros((H, W), np.int32)
+    total_tiles = 0
+    for rank in range(world):
+        x, y = tile_pixel_coords(W, H, rank, world)
+        n = owned_tile_count(rank, world, tiles_x * tiles_y)
+        total_tiles += n
+        assert len(x) == n * TILE_PIXELS
+        inside = x >= 0
+        np.add.at(seen, (y[inside], x[inside]), 1)
+        if rank:  # capacity never exceeds rank 0's (the gather pads to it)
+            assert n <= owned_tile_count(0, world, tiles_x * tiles_y)
+    assert total_tiles == tiles_x * tiles_y
+    assert (seen == 1).all()  # every pixel owned by exactly one shard
+
+
+def test_a_wave_is_an_8x8_pixel_square():
+    x, y = tile_pixel_coords(64, 16, 0, 1)
+    for wave in range(4):
+        wx, wy = x[wave * 64:(wave + 1) * 64], y[wave * 64:(wave + 1) * 64]
+        assert wx.max() - wx.min() == 7 and wy.max() - wy.min() == 7 and wx.min() == wave * 8
+
+
+def _worker(rank, world, port, W, H, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from rayzath_amd.distributed import gather_tiles, owned_tile_count as otc, tile_grid as tg, tile_pixel_coords as tpc
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    tiles_x, tiles_y = tg(W, H)
+    cap = otc(0, world, tiles_x * tiles_y) * 256
+    x, y = tpc(W, H, rank, world)
+    local = torch.zeros((cap, 4), dtype=torch.float32)
+    inside = x >= 0
+    vals = np.stack([x, y, x * 0 + rank, y * W + x], axis=-1).astype(np.float32)
+    local[: len(x)][torch.from_numpy(inside)] = torch.from_numpy(vals[inside])
+    parts = gather_tiles(local, rank, world, cap, dist)
+    if rank == 0:
+        image = np.full((H, W, 4), -1, np.float32)
+        for r, part in enumerate(parts):
+            px, py = tpc(W, H, r, world)
+            ok = px >= 0
+            image[py[ok], px[ok]] = part.numpy()[: len(px)][ok]
+        np.save(out_path, image)
+    else:
+        assert parts is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size", [(2, (200, 120)), (3, (97, 41))])
+def test_gather_assembles_the_frame_over_gloo(tmp_path, world, size):
+    import torch.multiprocessing as mp
+    W, H = size
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, port, W, H, out), nprocs=world, join=True)
+    image = np.load(out)
+    yy, xx = np.mgrid[0:H, 0:W]
+    assert np.array_equal(image[..., 0], xx) and np.array_equal(image[..., 1], yy)
+    assert np.array_equal(image[..., 3], yy * W + xx)
+    tiles_x, _ = tile_grid(W, H)
+    assert np.array_equal(image[..., 2], ((yy // 8) * tiles_x + xx // 32) % world)  # owner = tile id mod world

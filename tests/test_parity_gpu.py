@@ -165,3 +165,82 @@ def test_shared_reciprocal_division_is_exact(built):
         bad, n = ctx.selftest(256, seed)
         assert n == 1024 * 256 * 256
         assert bad == 0, f"{bad} of {n} quotients differ"
+
+
+@pytest.mark.parametrize("name", ["cornell_128", "living_room_96x64", "sphere_160x90"])
+@pytest.mark.parametrize("mode", [1, 0])
+def test_gpu_matches_committed_golden(built, name, mode):
+    """Same comparison without the oracle in the loop: committed fixtures (tests/golden)."""
+    from test_golden_oracle import load_golden
+    g, flat, cam, cfg = load_golden(name)
+    ctx = Context(0)
+    ctx.set_traversal_mode(mode)
+    ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(cfg)
+    first = ctx.render_counted(1)
+    assert list(first.values()) == g["counters_first"].tolist()
+    assert np.array_equal(ctx.read_depth(), g["depth"])
+    ctx.render(int(g["passes"]) - 1)
+    acc = ctx.read_accum()
+    lights = len(flat.spot_lights) + len(flat.direct_lights) > 0
+    frac = 0.02 if lights else FRACTION
+    assert (acc[..., 3] == g["accum"][..., 3]).mean() >= 1 - frac
+    assert _close(acc[..., :3], g["accum"][..., :3]).all(-1).mean() >= 1 - frac
+    st = ctx.read_state()
+    assert (st["depth"] == g["path_depth"]).mean() >= 1 - frac and (st["material"] == g["ray_material"]).mean() >= 1 - frac
+    ctx.tonemap()
+    assert (np.abs(ctx.read_rgba8().astype(int) - g["rgba8"].astype(int)).max(-1) <= 1).mean() >= 1 - frac
+
+
+@pytest.mark.parametrize("lds", [0, 1])
+def test_lds_staged_scene_is_only_a_placement_choice(built, lds):
+    world = scenes.cornell_box(160, 96)
+    ctx, ref = _run_both(world, 4, 6, mode=1)
+    ctx.set_lds_scene(lds)
+    ctx.render(6)
+    ref.render(6)
+    assert np.array_equal(ctx.read_accum(), ref.accum)
+
+
+def test_device_tile_layout_matches_host_layout(built):
+    from rayzath_amd.distributed import tile_pixel_coords
+    world = scenes.cornell_box(100, 44)
+    flat, cam = flatten(world), camera_struct(world.camera)
+    ctx = Context(0)
+    ctx.set_shard(1, 3)
+    ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(RenderConfig(tracing=Tracing(4, 1)).struct())
+    ctx.render(1)
+    owned = ctx.read_depth() != 0
+    x, y = tile_pixel_coords(100, 44, 1, 3)
+    want = np.zeros((44, 100), bool)
+    want[y[x >= 0], x[x >= 0]] = True
+    assert np.array_equal(owned, want)
+
+
+def test_engine_interface_and_errors(built):
+    """Engine.renderWorld mirrors the reference backend contract; misuse raises HiprzError."""
+    from rayzath_amd import HiprzError
+    from rayzath_amd.engine import Engine
+    eng = Engine(0)
+    world = scenes.cornell_box(96, 64)
+    cfg = RenderConfig(tracing=Tracing(4, 3))
+    eng.renderWorld(world, cfg)
+    assert world.camera.image_buffer.shape == (64, 96, 4) and world.camera.ray_count == 3 * 96 * 64
+    eng.renderWorld(world, cfg)
+    assert world.camera.ray_count == 6 * 96 * 64                 # accumulation continues
+    world.camera.position[0] += 0.25
+    eng.renderWorld(world, cfg)
+    assert world.camera.ray_count == 3 * 96 * 64                 # camera moved: restart (cpu_engine_renderer.cpp:108-112)
+    assert "render" in eng.timingsString()
+    ctx = Context(0)
+    with pytest.raises(HiprzError) as e:
+        ctx.render(1)
+    assert e.value.code == 3
+    with pytest.raises(HiprzError):
+        ctx.set_config(RenderConfig(LightSampling(0, 1)).struct())   # 0 samples would be 0/0 in the reference
+    with pytest.raises(HiprzError):
+        ctx.set_shard(3, 3)
+    flat = flatten(world)
+    flat.nodes["begin"][0] = 12345
+    with pytest.raises(HiprzError) as e:
+        ctx.upload_scene(flat)
+    assert e.value.code == 1 and "leaf range" in str(e.value)
