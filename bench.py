@@ -55,7 +55,7 @@ def cpu_baseline(flat, cam, cfg, budget_s=12.0):
         ref.render(1, threads=cores)
         passes += 1
         dt = time.perf_counter() - t0
-        if dt >= budget_s or passes >= 64:
+        if dt >= budget_s or passes >= 4096:
             break
     rays = passes * cam.width * cam.height
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
