@@ -1,0 +1,286 @@
+// hip_engine.cpp — see hip_engine.hpp.  Host-only C++ (no device code): everything below the
+// C-ABI lives in hiprz_api.hip / hiprz_host.cpp.
+#include "hip_engine.hpp"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+
+namespace RayZath::Hip {
+
+// ---- Mesh ----
+uint32_t Mesh::createVertex(float x, float y, float z) {
+    vertices.insert(vertices.end(), {x, y, z});
+    return uint32_t(vertices.size() / 3 - 1);
+}
+uint32_t Mesh::createTexcrd(float u, float v) {
+    texcrds.insert(texcrds.end(), {u, v});
+    return uint32_t(texcrds.size() / 2 - 1);
+}
+uint32_t Mesh::createTriangle(std::array<uint32_t, 3> vs, std::array<uint32_t, 3> ts, std::array<uint32_t, 3> ns,
+                              uint32_t material_id) {
+    tri_vertices.insert(tri_vertices.end(), vs.begin(), vs.end());
+    tri_texcrds.insert(tri_texcrds.end(), ts.begin(), ts.end());
+    tri_normals.insert(tri_normals.end(), ns.begin(), ns.end());
+    tri_materials.push_back(material_id);
+    return uint32_t(tri_materials.size() - 1);
+}
+std::shared_ptr<Mesh> Mesh::generateCube() {  // world.cpp:129-166
+    auto m = std::make_shared<Mesh>();
+    const float v[8][3] = {{-.5f, .5f, -.5f}, {-.5f, .5f, .5f}, {.5f, .5f, .5f}, {.5f, .5f, -.5f},
+                           {-.5f, -.5f, -.5f}, {-.5f, -.5f, .5f}, {.5f, -.5f, .5f}, {.5f, -.5f, -.5f}};
+    for (auto& p : v) m->createVertex(p[0], p[1], p[2]);
+    m->createTexcrd(0, 0), m->createTexcrd(0, 1), m->createTexcrd(1, 1), m->createTexcrd(1, 0);
+    const uint32_t t[12][3] = {{1, 2, 0}, {3, 0, 2}, {4, 7, 5}, {6, 5, 7}, {0, 3, 4}, {7, 4, 3},
+                               {2, 1, 6}, {5, 6, 1}, {3, 2, 7}, {6, 7, 2}, {1, 0, 5}, {4, 5, 0}};
+    for (int i = 0; i < 12; ++i)
+        m->createTriangle({t[i][0], t[i][1], t[i][2]}, i % 2 == 0 ? std::array<uint32_t, 3>{1, 2, 0} : std::array<uint32_t, 3>{3, 0, 2});
+    return m;
+}
+
+World::World() {
+    material.color = Color{0xFF, 0xFF, 0xFF, 0x00};  // world.cpp:33-38
+    material.ior(1.0f);
+    default_material.color = Color{0xC0, 0xC0, 0xC0, 0xFF};  // Palette::LightGrey (value assumed)
+}
+
+// ---- flattening ----
+hiprz_scene FlatScene::view() const {
+    hiprz_scene s{};
+    s.n_nodes = uint32_t(nodes.size()), s.nodes = nodes.data();
+    s.tlas_root = 0;
+    s.n_tlas_order = uint32_t(tlas_order.size()), s.tlas_order = tlas_order.data();
+    s.n_tris = uint32_t(tris.size()), s.tris = tris.data(), s.tri_attrs = tri_attrs.data();
+    s.n_instances = uint32_t(instances.size()), s.instances = instances.data();
+    s.n_inst_materials = uint32_t(inst_materials.size()), s.inst_materials = inst_materials.data();
+    s.n_materials = uint32_t(materials.size()), s.materials = materials.data();
+    s.n_textures = uint32_t(textures.size()), s.textures = textures.data();
+    s.texel_bytes = texels.size(), s.texels = texels.data();
+    s.n_spot_lights = uint32_t(spot_lights.size()), s.spot_lights = spot_lights.data();
+    s.n_direct_lights = uint32_t(direct_lights.size()), s.direct_lights = direct_lights.data();
+    return s;
+}
+
+namespace {
+void put3(float* dst, const vec3f& v) { dst[0] = v.x, dst[1] = v.y, dst[2] = v.z; }
+void normalize3(float* v) {
+    const float s = 1.0f / std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    v[0] *= s, v[1] *= s, v[2] *= s;
+}
+}  // namespace
+
+FlatScene flatten(const World& world) {
+    FlatScene f;
+    std::map<const TextureBuffer*, int32_t> tex_index;
+    auto tex_id = [&](const std::shared_ptr<TextureBuffer>& t) -> int32_t {
+        if (!t) return -1;
+        auto it = tex_index.find(t.get());
+        if (it != tex_index.end()) return it->second;
+        while (f.texels.size() % 4) f.texels.push_back(0);
+        hiprz_texture rec{};
+        rec.kind = t->kind, rec.width = t->width, rec.height = t->height, rec.offset = uint32_t(f.texels.size());
+        rec.scale[0] = t->scale[0], rec.scale[1] = t->scale[1];
+        rec.translation[0] = t->translation[0], rec.translation[1] = t->translation[1];
+        rec.rotation = t->rotation, rec.cos_rotation = std::cos(t->rotation), rec.sin_rotation = std::sin(t->rotation);
+        f.texels.insert(f.texels.end(), t->bitmap.begin(), t->bitmap.end());
+        f.textures.push_back(rec);
+        return tex_index[t.get()] = int32_t(f.textures.size() - 1);
+    };
+    std::map<const Material*, int32_t> mat_index;
+    auto add_material = [&](const Material& m) {
+        hiprz_material r{};
+        r.color[0] = m.color.red, r.color[1] = m.color.green, r.color[2] = m.color.blue, r.color[3] = m.color.alpha;
+        r.metalness = m.metalness(), r.roughness = m.roughness(), r.emission = m.emission(), r.ior = m.ior(), r.scattering = m.scattering();
+        r.texture = tex_id(m.texture), r.normal_map = tex_id(m.normal_map), r.metalness_map = tex_id(m.metalness_map);
+        r.roughness_map = tex_id(m.roughness_map), r.emission_map = tex_id(m.emission_map);
+        mat_index[&m] = int32_t(f.materials.size());
+        f.materials.push_back(r);
+    };
+    add_material(world.material);
+    add_material(world.default_material);
+    for (const auto& m : world.materials) add_material(*m);
+
+    // one tree per distinct mesh
+    struct MeshTree {
+        std::vector<hiprz_node> nodes;
+        std::vector<hiprz_tri> tris;
+        std::vector<hiprz_tri_attr> attrs;
+    };
+    std::map<const Mesh*, size_t> mesh_slot;
+    std::vector<MeshTree> trees;
+    for (const auto& inst : world.instances) {
+        if (!inst->mesh || mesh_slot.count(inst->mesh.get())) continue;
+        const Mesh& m = *inst->mesh;
+        hiprz_mesh_desc d{};
+        d.n_vertices = uint32_t(m.vertices.size() / 3), d.vertices = m.vertices.data();
+        d.n_texcrds = uint32_t(m.texcrds.size() / 2), d.texcrds = m.texcrds.data();
+        d.n_normals = uint32_t(m.normals.size() / 3), d.normals = m.normals.data();
+        d.n_triangles = uint32_t(m.tri_materials.size());
+        d.tri_vertices = m.tri_vertices.data(), d.tri_texcrds = m.tri_texcrds.data();
+        d.tri_normals = m.tri_normals.data(), d.tri_materials = m.tri_materials.data();
+        MeshTree t;
+        t.nodes.resize(2 * size_t(d.n_triangles) + 1);
+        t.tris.resize(d.n_triangles ? d.n_triangles : 1);
+        t.attrs.resize(d.n_triangles ? d.n_triangles : 1);
+        uint32_t n = 0;
+        if (hiprz_build_mesh_tree(&d, t.nodes.data(), uint32_t(t.nodes.size()), &n, t.tris.data(), t.attrs.data()) != HIPRZ_OK)
+            throw Exception(HIPRZ_ERR_INVALID, "mesh with out-of-range indices");
+        t.nodes.resize(n), t.tris.resize(d.n_triangles), t.attrs.resize(d.n_triangles);
+        mesh_slot[&m] = trees.size();
+        trees.push_back(std::move(t));
+    }
+
+    std::vector<uint8_t> has_mesh;
+    for (const auto& inst : world.instances) {
+        hiprz_instance r{};
+        put3(r.position, inst->position), put3(r.scale, inst->scale);
+        float rot[3];
+        put3(rot, inst->rotation);
+        hiprz_axes_from_rotation(rot, r.x_axis, r.y_axis, r.z_axis);
+        r.material_base = uint32_t(f.inst_materials.size());
+        uint32_t count = 0;
+        for (uint32_t k = 0; k < Instance::materialCapacity(); ++k)
+            if (inst->materials[k]) count = k + 1;
+        r.material_count = count;
+        for (uint32_t k = 0; k < count; ++k) {
+            const auto& m = inst->materials[k];
+            if (m && !mat_index.count(m.get())) throw Exception(HIPRZ_ERR_INVALID, "instance uses a material that is not in the world");
+            f.inst_materials.push_back(m ? mat_index[m.get()] : -1);
+        }
+        if (inst->mesh) hiprz_instance_bounds(inst->mesh->vertices.data(), uint32_t(inst->mesh->vertices.size() / 3), &r);
+        has_mesh.push_back(inst->mesh ? 1 : 0);
+        f.instances.push_back(r);
+    }
+
+    const uint32_t n_inst = uint32_t(f.instances.size());
+    if (n_inst) {
+        f.nodes.resize(2 * size_t(n_inst) + 1);
+        f.tlas_order.resize(n_inst);
+        uint32_t n = 0, n_order = 0;
+        hiprz_build_world_tree(f.instances.data(), has_mesh.data(), n_inst, f.nodes.data(), uint32_t(f.nodes.size()), &n,
+                               f.tlas_order.data(), &n_order);
+        f.nodes.resize(n), f.tlas_order.resize(n_order);
+    }
+    std::vector<uint32_t> roots;
+    for (auto& t : trees) {
+        const uint32_t node_base = uint32_t(f.nodes.size()), tri_base = uint32_t(f.tris.size());
+        roots.push_back(node_base);
+        for (auto n : t.nodes) {
+            n.begin += (n.meta & HIPRZ_NODE_LEAF) ? tri_base : node_base;
+            f.nodes.push_back(n);
+        }
+        f.tris.insert(f.tris.end(), t.tris.begin(), t.tris.end());
+        f.tri_attrs.insert(f.tri_attrs.end(), t.attrs.begin(), t.attrs.end());
+    }
+    for (size_t i = 0; i < world.instances.size(); ++i)
+        if (world.instances[i]->mesh) f.instances[i].blas_root = roots[mesh_slot[world.instances[i]->mesh.get()]];
+
+    for (const auto& l : world.spot_lights) {
+        hiprz_spot_light r{};
+        put3(r.position, l->position), put3(r.direction, l->direction);
+        normalize3(r.direction);
+        r.size = std::max(l->size, std::numeric_limits<float>::min()), r.emission = std::max(l->emission, 0.0f);
+        r.color[0] = l->color.red, r.color[1] = l->color.green, r.color[2] = l->color.blue, r.color[3] = l->color.alpha;
+        r.angle = std::min(std::max(l->beam_angle, 0.0f), 3.14159f), r.cos_angle = std::cos(r.angle);
+        f.spot_lights.push_back(r);
+    }
+    for (const auto& l : world.direct_lights) {
+        hiprz_direct_light r{};
+        put3(r.direction, l->direction);
+        normalize3(r.direction);
+        r.emission = std::max(l->emission, 0.0f);
+        r.color[0] = l->color.red, r.color[1] = l->color.green, r.color[2] = l->color.blue, r.color[3] = l->color.alpha;
+        r.angular_size = std::min(std::max(l->angular_size, 0.0f), 3.14159265358979f), r.cos_angular_size = std::cos(r.angular_size);
+        f.direct_lights.push_back(r);
+    }
+    return f;
+}
+
+hiprz_camera cameraRecord(const Camera& cam) {
+    const float eps = std::numeric_limits<float>::epsilon();
+    hiprz_camera c{};
+    put3(c.position, cam.position);
+    float rot[3];
+    put3(rot, cam.rotation);
+    hiprz_axes_look_at(rot, c.x_axis, c.y_axis, c.z_axis);  // camera.cpp:95-100
+    c.width = std::max(cam.width, 1u), c.height = std::max(cam.height, 1u);
+    c.fov = std::min(std::max(cam.fov, eps), 3.14159265358979f - eps);  // camera.cpp:100-110
+    c.tan_half_fov = std::tan(c.fov * 0.5f);
+    c.aspect_ratio = float(c.width) / float(c.height);
+    c.near_far[0] = std::max(cam.near_plane, eps);
+    c.near_far[1] = std::max(cam.far_plane, c.near_far[0] + eps);
+    c.focal_distance = std::max(cam.focal_distance, eps);
+    c.aperture = std::max(cam.aperture, eps);
+    c.exposure_time = std::max(cam.exposure_time, eps);
+    return c;
+}
+
+// ---- Engine ----
+Engine::Engine(int device) {
+    const int rc = hiprz_create(&m_ctx, device);
+    if (rc != HIPRZ_OK) throw Exception(rc, std::string("HIPGPU backend unavailable: ") + hiprz_last_error(nullptr));
+}
+Engine::~Engine() { hiprz_destroy(m_ctx); }
+
+void Engine::check(int rc) {
+    if (rc != HIPRZ_OK) throw Exception(rc, hiprz_last_error(m_ctx));
+}
+
+void Engine::readback(Camera& camera) {
+    const size_t n = size_t(camera.width) * camera.height;
+    camera.image_buffer.resize(n * 4);
+    camera.depth_buffer.resize(n);
+    check(hiprz_read_rgba8(m_ctx, camera.image_buffer.data(), n * 4));
+    check(hiprz_read_depth(m_ctx, camera.depth_buffer.data(), n * sizeof(float)));
+    check(hiprz_ray_count(m_ctx, &camera.ray_count));
+}
+
+void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, bool sync) {
+    std::lock_guard<std::mutex> lock(m_mutex);
+    if (m_deferred) {  // error of the previous, already returned, asynchronous frame
+        Exception e = *m_deferred;
+        m_deferred.reset();
+        throw e;
+    }
+    if (m_pending_readback) {  // pipelined frame of the previous non-sync call
+        m_pending_readback = false;
+        readback(world.camera);
+    }
+    // re-mirror what changed; either change restarts accumulation (cpu_engine_renderer.cpp:108-112)
+    if (world.isModified() || m_last_world != &world) {
+        const FlatScene flat = flatten(world);
+        const hiprz_scene view = flat.view();
+        check(hiprz_upload_scene(m_ctx, &view));
+        world.makeUnmodified();
+        world.camera.makeModified();
+        m_last_world = &world;
+    }
+    if (world.camera.isModified()) {
+        const hiprz_camera cam = cameraRecord(world.camera);
+        check(hiprz_upload_camera(m_ctx, &cam));
+        world.camera.makeUnmodified();
+    }
+    hiprz_config c{};
+    c.max_depth = cfg.tracing.max_depth, c.rpp = cfg.tracing.rpp;
+    c.spot_samples = std::max<uint32_t>(cfg.light_sampling.spot_light, 1u);      // cuda_kernel_data.cu:23-31
+    c.direct_samples = std::max<uint32_t>(cfg.light_sampling.direct_light, 1u);
+    c.seed = cfg.seed;
+    check(hiprz_set_config(m_ctx, &c));
+    check(hiprz_render(m_ctx, std::max(cfg.tracing.rpp, 1u)));
+    check(hiprz_tonemap(m_ctx));
+    if (sync) {
+        readback(world.camera);
+    } else {
+        m_pending_readback = true;
+        // nothing has been waited for: a device fault would surface at the next call's first hip* return
+    }
+}
+
+std::string Engine::timingsString() {
+    std::lock_guard<std::mutex> lock(m_mutex);
+    char buf[4096];
+    if (hiprz_timings(m_ctx, buf, sizeof buf) != HIPRZ_OK) return {};
+    return buf;
+}
+
+}  // namespace RayZath::Hip

@@ -1,0 +1,188 @@
+// hip_engine.hpp — C++ host side of the HIPGPU backend, above the C-ABI (include/hiprz.h).
+//
+// `RayZath::Hip::Engine` has exactly the interface the facade calls on its backends
+// (RayZath/cpu_engine.hpp:17-22, RayZath/cuda_engine.cuh:34-39):
+//
+//     void renderWorld(World&, const RenderConfig&, bool block = true, bool sync = true);
+//     std::string timingsString();
+//
+// The reference's host `World` cannot be compiled in this image (un-vendored Math/Graphics
+// headers), so this header carries a minimal stand-alone twin of the parts of it
+// the render path reads — same object kinds, member names, defaults and clamping rules
+// (world.hpp:64-76, material.hpp, mesh.hpp, instance.hpp, camera.hpp, spot_light.hpp,
+// direct_light.hpp, engine_parts.hpp:76-128).  INTEGRATION.md shows the adapter that fills the
+// same `hiprz_scene` from the real `RayZath::Engine::World` instead.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "hiprz.h"
+
+namespace RayZath::Hip {
+
+// RayZath::Exception : std::runtime_error (rzexception.hpp:11-18); Cuda::Exception's peer.
+struct Exception : public std::runtime_error {
+    int code;
+    Exception(int code_, const std::string& message) : std::runtime_error(message), code(code_) {}
+};
+
+struct vec3f {
+    float x = 0, y = 0, z = 0;
+};
+struct Color {
+    uint8_t red = 255, green = 255, blue = 255, alpha = 255;
+};
+
+// dirty-flag base, after Updatable/StateRegister (updatable.cpp:23-51)
+class Updatable {
+public:
+    bool isModified() const { return m_modified; }
+    void makeModified() { m_modified = true; }
+    void makeUnmodified() { m_modified = false; }
+
+private:
+    bool m_modified = true;
+};
+
+struct TextureBuffer {  // render_parts.hpp:113-222
+    uint32_t kind = HIPRZ_TEX_RGBA8, width = 0, height = 0;
+    std::vector<uint8_t> bitmap;  // row-major, top row first
+    float scale[2] = {1, 1}, rotation = 0, translation[2] = {0, 0};
+};
+
+struct Material {  // material.hpp:119-160; setters clamp as material.cpp:32-61
+    Color color{0xC0, 0xC0, 0xC0, 0xFF};
+    std::shared_ptr<TextureBuffer> texture, normal_map, metalness_map, roughness_map, emission_map;
+    void metalness(float v) { m_metalness = v < 0 ? 0 : v > 1 ? 1 : v; }
+    void roughness(float v) { m_roughness = v < 0 ? 0 : v > 1 ? 1 : v; }
+    void emission(float v) { m_emission = v < 0 ? 0 : v; }
+    void ior(float v) { m_ior = v < 1 ? 1 : v; }
+    void scattering(float v) { m_scattering = v < 0 ? 0 : v; }
+    float metalness() const { return m_metalness; }
+    float roughness() const { return m_roughness; }
+    float emission() const { return m_emission; }
+    float ior() const { return m_ior; }
+    float scattering() const { return m_scattering; }
+
+private:
+    float m_metalness = 0, m_roughness = 0, m_emission = 0, m_ior = 1.5f, m_scattering = 0;
+};
+
+struct Mesh {  // mesh.hpp
+    static constexpr uint32_t ids_unused = 0xFFFFFFFFu;
+    std::vector<float> vertices, texcrds, normals;                // xyz / uv / xyz
+    std::vector<uint32_t> tri_vertices, tri_texcrds, tri_normals; // 3 per triangle
+    std::vector<uint32_t> tri_materials;                          // 1 per triangle
+    uint32_t createVertex(float x, float y, float z);
+    uint32_t createTexcrd(float u, float v);
+    uint32_t createTriangle(std::array<uint32_t, 3> vs, std::array<uint32_t, 3> ts = {ids_unused, ids_unused, ids_unused},
+                            std::array<uint32_t, 3> ns = {ids_unused, ids_unused, ids_unused}, uint32_t material_id = 0);
+    static std::shared_ptr<Mesh> generateCube();  // world.cpp:129-166
+};
+
+struct Instance {  // instance.hpp:9-60
+    static constexpr uint32_t materialCapacity() { return 64; }
+    vec3f position, rotation, scale{1, 1, 1};
+    std::shared_ptr<Mesh> mesh;
+    std::array<std::shared_ptr<Material>, 64> materials;
+};
+
+struct SpotLight {  // spot_light.hpp
+    vec3f position, direction{0, -1, 0};
+    Color color;
+    float size = 0.5f, emission = 100.0f, beam_angle = 1.0f;
+};
+struct DirectLight {  // direct_light.hpp
+    vec3f direction{0, -1, 0};
+    Color color;
+    float emission = 100.0f, angular_size = 0.1f;
+};
+
+struct Camera : public Updatable {  // camera.hpp:127-161
+    vec3f position{0, 0, -10}, rotation;
+    uint32_t width = 1280, height = 720;
+    float fov = 1.57079632679f, near_plane = 1.0e-2f, far_plane = 1.0e3f;
+    float focal_distance = 10.0f, aperture = 0.02f, exposure_time = 1.0f / 60.0f;
+    // outputs the backend writes (camera.hpp:50-56, 113-119)
+    std::vector<uint8_t> image_buffer;  // RGBA8 W*H
+    std::vector<float> depth_buffer;    // W*H
+    uint64_t ray_count = 0;
+};
+
+struct World : public Updatable {  // world.hpp:64-76
+    World();
+    std::vector<std::shared_ptr<Material>> materials;
+    std::vector<std::shared_ptr<Mesh>> meshes;
+    std::vector<std::shared_ptr<Instance>> instances;
+    std::vector<std::shared_ptr<SpotLight>> spot_lights;
+    std::vector<std::shared_ptr<DirectLight>> direct_lights;
+    Camera camera;
+    Material material;          // world / sky medium (world.cpp:33-38)
+    Material default_material;  // world.cpp:39-43
+};
+
+struct LightSampling {  // engine_parts.hpp:76-94
+    uint8_t spot_light = 1, direct_light = 1;
+};
+struct Tracing {  // engine_parts.hpp:95-113
+    uint8_t max_depth = 16;
+    uint32_t rpp = 8;
+};
+struct RenderConfig {
+    LightSampling light_sampling;
+    Tracing tracing;
+    uint32_t seed = 20240501u;
+};
+
+// The flattened snapshot with owning storage (what hiprz_upload_scene copies).
+struct FlatScene {
+    std::vector<hiprz_node> nodes;
+    std::vector<uint32_t> tlas_order;
+    std::vector<hiprz_tri> tris;
+    std::vector<hiprz_tri_attr> tri_attrs;
+    std::vector<hiprz_instance> instances;
+    std::vector<int32_t> inst_materials;
+    std::vector<hiprz_material> materials;
+    std::vector<hiprz_texture> textures;
+    std::vector<uint8_t> texels;
+    std::vector<hiprz_spot_light> spot_lights;
+    std::vector<hiprz_direct_light> direct_lights;
+    hiprz_scene view() const;
+};
+FlatScene flatten(const World& world);           // pure host
+hiprz_camera cameraRecord(const Camera& camera); // pure host
+
+class Engine {
+public:
+    explicit Engine(int device = 0);  // throws Hip::Exception: the facade then falls back to CPU (rayzath.cpp:21-28)
+    ~Engine();
+    Engine(const Engine&) = delete;
+    Engine& operator=(const Engine&) = delete;
+
+    // `block` is accepted and ignored like in both reference backends.  sync = true: the camera buffers hold
+    // THIS call's frame on return.  sync = false: the call only enqueues; the buffers are filled by the next call
+    // (the CUDA backend's pipelined readback, cuda_engine_core.cu:115-120).  A device error met after a
+    // non-sync call returned is stored and thrown by the next call (cuda_engine_core.cu:41).
+    void renderWorld(World& world, const RenderConfig& render_config, bool block = true, bool sync = true);
+    std::string timingsString();
+
+    hiprz_ctx* context() { return m_ctx; }  // for tests
+
+private:
+    void check(int rc);
+    void readback(Camera& camera);
+
+    hiprz_ctx* m_ctx = nullptr;
+    std::mutex m_mutex;  // renderWorld is serialised (cpu_engine_core.cpp:15)
+    bool m_pending_readback = false;
+    std::unique_ptr<Exception> m_deferred;
+    const World* m_last_world = nullptr;
+};
+
+}  // namespace RayZath::Hip

@@ -1,0 +1,112 @@
+// hip_engine_test.cpp — drives the C++ host side (hip_engine.hpp) the way RayZath's facade drives a
+// backend; tests/test_cpp_host.py compares what it writes with the Python host side on the same scene.
+//   hip_engine_test flatten <out.bin>          pure host: dump the flattened snapshot
+//   hip_engine_test render  <out.bin> <calls>  GPU: renderWorld <calls> times, dump the camera outputs
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "hip_engine.hpp"
+
+using namespace RayZath::Hip;
+
+static std::shared_ptr<Mesh> quad(const float v[4][3]) {
+    auto m = std::make_shared<Mesh>();
+    for (int i = 0; i < 4; ++i) m->createVertex(v[i][0], v[i][1], v[i][2]);
+    m->createTexcrd(0, 0), m->createTexcrd(0, 1), m->createTexcrd(1, 1), m->createTexcrd(1, 0);
+    m->createTriangle({0, 2, 1}, {0, 2, 1});
+    m->createTriangle({0, 3, 2}, {0, 3, 2});
+    return m;
+}
+static std::shared_ptr<Material> material(World& w, Color c, float metal, float rough, float emission, float ior) {
+    auto m = std::make_shared<Material>();
+    m->color = c, m->metalness(metal), m->roughness(rough), m->emission(emission), m->ior(ior);
+    w.materials.push_back(m);
+    return m;
+}
+static void instance(World& w, std::shared_ptr<Mesh> mesh, std::shared_ptr<Material> mat, vec3f pos, vec3f rot = {}, vec3f scale = {1, 1, 1}) {
+    auto i = std::make_shared<Instance>();
+    i->mesh = mesh, i->materials[0] = mat, i->position = pos, i->rotation = rot, i->scale = scale;
+    w.instances.push_back(i);
+}
+
+// The same scene tests/test_cpp_host.py builds in Python: an open box room of explicit quads + two boxes.
+static void build(World& w, uint32_t width, uint32_t height) {
+    auto white = material(w, {230, 230, 230, 255}, 0, 1, 0, 1.5f), red = material(w, {200, 40, 40, 255}, 0, 1, 0, 1.5f);
+    auto green = material(w, {40, 200, 40, 255}, 0, 1, 0, 1.5f), light = material(w, {255, 255, 255, 255}, 0, 1, 50, 1.5f);
+    auto mirror = material(w, {0xF0, 0xF0, 0xF0, 0xFF}, 0.9f, 0, 0, 1.0f);
+    const float fl[4][3] = {{-2, 0, -2}, {-2, 0, 2}, {2, 0, 2}, {2, 0, -2}};
+    const float bk[4][3] = {{-2, -1, 2}, {-2, 3, 2}, {2, 3, 2}, {2, -1, 2}};
+    const float lf[4][3] = {{-2, -1, -2}, {-2, 3, -2}, {-2, 3, 2}, {-2, -1, 2}};
+    const float rt[4][3] = {{2, -1, -2}, {2, 3, -2}, {2, 3, 2}, {2, -1, 2}};
+    const float lp[4][3] = {{-0.5f, 0, -0.5f}, {-0.5f, 0, 0.5f}, {0.5f, 0, 0.5f}, {0.5f, 0, -0.5f}};
+    auto floor_mesh = quad(fl), cube = Mesh::generateCube();
+    w.meshes = {floor_mesh, cube};
+    instance(w, floor_mesh, white, {0, -1, 0});
+    instance(w, floor_mesh, white, {0, 3, 0});
+    instance(w, quad(bk), white, {0, 0, 0});
+    instance(w, quad(lf), red, {0, 0, 0});
+    instance(w, quad(rt), green, {0, 0, 0});
+    instance(w, quad(lp), light, {0, 2.99f, 0});
+    instance(w, cube, mirror, {-0.7f, 0.2f, 0.6f}, {0, 0.3f, 0}, {1.2f, 2.4f, 1.2f});
+    instance(w, cube, white, {0.7f, -0.4f, -0.5f}, {0, -0.3f, 0}, {1.2f, 1.2f, 1.2f});
+    w.camera.position = {0, 1, -3.5f};
+    w.camera.width = width, w.camera.height = height;
+    w.camera.focal_distance = 4.0f;
+}
+
+template <typename T>
+static void dump(FILE* f, const char* name, const std::vector<T>& v) {
+    char tag[16] = {0};
+    std::strncpy(tag, name, 15);
+    const uint64_t bytes = v.size() * sizeof(T);
+    std::fwrite(tag, 1, 16, f);
+    std::fwrite(&bytes, 8, 1, f);
+    if (bytes) std::fwrite(v.data(), 1, bytes, f);
+}
+
+int main(int argc, char** argv) {
+    if (argc < 3) return std::fprintf(stderr, "usage: %s flatten|render <out.bin> [calls]\n", argv[0]), 2;
+    const std::string mode = argv[1];
+    FILE* out = std::fopen(argv[2], "wb");
+    if (!out) return std::perror("open"), 2;
+    World world;
+    build(world, 96, 64);
+    try {
+        if (mode == "flatten") {
+            const FlatScene f = flatten(world);
+            dump(out, "nodes", f.nodes), dump(out, "tlas_order", f.tlas_order), dump(out, "tris", f.tris);
+            dump(out, "tri_attrs", f.tri_attrs), dump(out, "instances", f.instances), dump(out, "inst_materials", f.inst_materials);
+            dump(out, "materials", f.materials);
+            const hiprz_camera cam = cameraRecord(world.camera);
+            dump(out, "camera", std::vector<hiprz_camera>{cam});
+        } else {
+            const int calls = argc > 3 ? std::atoi(argv[3]) : 2;
+            Engine engine(0);
+            RenderConfig cfg;
+            cfg.tracing.max_depth = 4, cfg.tracing.rpp = 3;
+            for (int i = 0; i < calls; ++i) engine.renderWorld(world, cfg, true, i % 2 == 0);  // alternate sync / pipelined
+            engine.renderWorld(world, cfg, true, true);
+            std::vector<float> accum(size_t(96) * 64 * 4);
+            if (hiprz_read_accum(engine.context(), accum.data(), accum.size() * 4) != HIPRZ_OK) throw Exception(2, "read_accum");
+            dump(out, "image", world.camera.image_buffer), dump(out, "depth", world.camera.depth_buffer), dump(out, "accum", accum);
+            dump(out, "ray_count", std::vector<uint64_t>{world.camera.ray_count});
+            // a broken world must surface as Hip::Exception, not as a device fault
+            world.instances[0]->materials[0] = std::make_shared<Material>();  // not registered in the world
+            world.makeModified();
+            bool thrown = false;
+            try {
+                engine.renderWorld(world, cfg);
+            } catch (const Exception& e) {
+                thrown = e.code == HIPRZ_ERR_INVALID;
+            }
+            dump(out, "threw", std::vector<uint8_t>{uint8_t(thrown)});
+            std::printf("%s", engine.timingsString().c_str());
+        }
+    } catch (const Exception& e) {
+        std::fprintf(stderr, "Hip::Exception %d: %s\n", e.code, e.what());
+        return 1;
+    }
+    std::fclose(out);
+    return 0;
+}
