@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--config", default="B", help="scene preset of rayzath_amd/scenes.py (B = the quoted config)")
     ap.add_argument("--traversal", type=int, default=1, help="1 nested walk with LDS stack (default), 0 threaded walk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N ranks share GPU 0 and talk over gloo: exercises the sharded path where only one GPU exists")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,10 +89,15 @@ def main():
     from rayzath_amd.engine import Context, RenderConfig, Tracing
     from rayzath_amd.scene import camera_struct, flatten
 
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     preset = scenes.CONFIGS[args.config]
     scene_world = preset["build"]()

@@ -44,6 +44,11 @@ def gather_tiles(local_tiles, rank, world, capacity_max, dist, dst=0):
 
     if world == 1:
         return [local_tiles]
+    if local_tiles.is_cuda and dist.get_backend() == "gloo":  # one-GPU rehearsal: stage through the host
+        host = local_tiles.cpu()
+        gather_list = [torch.empty_like(host) for _ in range(world)] if rank == dst else None
+        dist.gather(host, gather_list=gather_list, dst=dst)
+        return [t.to(local_tiles.device) for t in gather_list] if rank == dst else None
     gather_list = [torch.empty_like(local_tiles) for _ in range(world)] if rank == dst else None
     dist.gather(local_tiles, gather_list=gather_list, dst=dst)
     return gather_list

@@ -9,6 +9,8 @@ indexing bit-exact"):
     rel 1e-3 (abs 1e-3 below 1.0) except a stated small fraction of pixels whose path
     crossed a geometric edge because of such an ulp (FRACTION below).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -244,3 +246,20 @@ def test_engine_interface_and_errors(built):
     with pytest.raises(HiprzError) as e:
         ctx.upload_scene(flat)
     assert e.value.code == 1 and "leaf range" in str(e.value)
+
+
+def test_sharded_bench_path_rehearsal(built):
+    """bench.py's N > 1 path (shard, render, gather to rank 0, untile, tone-map) with 2 ranks sharing GPU 0
+    over gloo; the assembled frame must equal the single-rank frame."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29671", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "A",
+           "--rehearse-on-one-gpu", "--no-cpu-baseline"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = [l for l in proc.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "strong"
