@@ -69,8 +69,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="B", help="scene preset of rayzath_amd/scenes.py (B = the quoted config)")
-    ap.add_argument("--traversal", type=int, default=1, help="1 nested walk with LDS stack (default), 0 threaded walk")
+    ap.add_argument("--traversal", type=int, default=-1, help="-1 per-scene choice (default), 1 nested walk with LDS stack, 2 workgroup-binned, 0 threaded")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-gather", action="store_true", help="check the gathered frame against an unsharded render (N > 1)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N ranks share GPU 0 and talk over gloo: exercises the sharded path where only one GPU exists")
     args = ap.parse_args()
@@ -128,6 +129,18 @@ def main():
         torch.cuda.synchronize()
 
     ctx.render(1)  # renderFirstPass; the timed steps are cumulative passes, as in steady-state rendering
+    if args.verify_gather and world > 1:  # the assembled frame must equal what a single shard-less context renders
+        ctx.render(RPP)
+        img = frame.gather_accum()
+        ctx.sync()
+        if rank == 0:
+            ref = Context(local_rank)
+            ref.set_traversal_mode(args.traversal)
+            ref.upload_scene(flat), ref.upload_camera(cam), ref.set_config(cfg)
+            ref.render(1 + RPP)
+            import numpy as np
+            assert np.array_equal(img.cpu().numpy(), ref.read_accum()), "gathered frame differs from the unsharded frame"
+            ref.close()
     for _ in range(args.warmup):
         step()
     fence()
@@ -171,7 +184,7 @@ def main():
             "config": {"workload": preset["note"], "resolution": [W, H], "max_depth": preset["max_depth"], "passes_per_step": RPP,
                        "triangles": int(len(flat.tris)), "instances": int(len(flat.instances)),
                        "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
-                       "traversal": "threaded" if args.traversal == 0 else "lds-stack"},
+                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned"}[ctx.traversal_mode()]},
             "spp_per_s": spp_per_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": traffic, "kernel": "rz_pass_kernel<cumulative>", "avg_launch_us": avg_kernel_s * 1e6,

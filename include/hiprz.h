@@ -262,15 +262,21 @@ int hiprz_set_config(hiprz_ctx* ctx, const hiprz_config* config);
  * unchanged, so results are identical for any world size).  Default rank 0 of 1. */
 int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
 
-/* Tree-walk variant of the pass kernel: 1 = nested loops with a per-lane stack in LDS (default),
- * 0 = threaded (skip links + instance pseudo-nodes, no stack).  Both visit the same boxes and
- * triangles in the same order and give identical results. */
+/* Tree-walk variant of the pass kernel.  -1 (default) = chosen per scene; 1 = nested loops with a
+ * per-lane stack in LDS; 2 = workgroup-binned (rays advance in rounds, the (ray, instance) visits of
+ * a round are compacted and sorted by instance in LDS and processed by dense waves); 0 = threaded
+ * (skip links + instance pseudo-nodes, no stack).  All visit the same boxes and triangles in the
+ * same per-ray order and give identical results. */
 int hiprz_set_traversal_mode(hiprz_ctx* ctx, int mode);
+int hiprz_traversal_mode(hiprz_ctx* ctx, int* effective_mode_out); /* valid after hiprz_upload_scene */
 
 /* Stage the scene's geometry + shading records into LDS in every workgroup (ds_read instead of
  * dependent global loads): -1 = automatic (when the records fit three workgroups per CU), 0 = never,
  * 1 = whenever they fit one workgroup.  Results are identical either way. */
 int hiprz_set_lds_scene(hiprz_ctx* ctx, int mode);
+
+/* Replay the cumulative passes of a render call from a captured hipGraph (default on). */
+int hiprz_set_graph(hiprz_ctx* ctx, int enabled);
 
 /* --- rendering (replaces Renderer::renderFunction, cuda_engine_renderer.cu:73-262) --- */
 /* Restart accumulation: the next hiprz_render starts with renderFirstPass
@@ -301,6 +307,9 @@ int hiprz_pass_count(hiprz_ctx* ctx, uint32_t* out);
  * Layout: owned tile lt (global tile lt*world+rank), 256 pixels each (4 waves of 8x8). --- */
 int hiprz_local_pixel_capacity(hiprz_ctx* ctx, size_t* out);          /* owned tiles * 256 */
 int hiprz_export_accum_tiles(hiprz_ctx* ctx, void* dst_device, size_t bytes);  /* float4 per local pixel, D2D on ctx stream */
+/* The same for the tone-mapped output: u32 RGBA8 per local pixel (after hiprz_tonemap). */
+int hiprz_export_rgba8_tiles(hiprz_ctx* ctx, void* dst_device, size_t bytes);
+int hiprz_untile_rgba8(hiprz_ctx* ctx, const void* src_device_tiles, uint32_t rank, uint32_t world, void* dst_device_image);
 /* Scatter tile-major float4 tiles of shard (rank, world) into a row-major W*H*16 device image. */
 int hiprz_untile_accum(hiprz_ctx* ctx, const void* src_device_tiles, uint32_t rank, uint32_t world,
                        void* dst_device_image);

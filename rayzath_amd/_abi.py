@@ -110,6 +110,8 @@ ENTRY_POINTS = {
     "hiprz_set_shard": (C.c_int, [P, U32, U32]),
     "hiprz_set_traversal_mode": (C.c_int, [P, C.c_int]),
     "hiprz_set_lds_scene": (C.c_int, [P, C.c_int]),
+    "hiprz_traversal_mode": (C.c_int, [P, C.POINTER(C.c_int)]),
+    "hiprz_set_graph": (C.c_int, [P, C.c_int]),
     "hiprz_reset": (C.c_int, [P]),
     "hiprz_render": (C.c_int, [P, U32]),
     "hiprz_render_counted": (C.c_int, [P, U32, C.POINTER(Counters)]),
@@ -123,6 +125,8 @@ ENTRY_POINTS = {
     "hiprz_pass_count": (C.c_int, [P, C.POINTER(U32)]),
     "hiprz_local_pixel_capacity": (C.c_int, [P, C.POINTER(SZ)]),
     "hiprz_export_accum_tiles": (C.c_int, [P, P, SZ]),
+    "hiprz_export_rgba8_tiles": (C.c_int, [P, P, SZ]),
+    "hiprz_untile_rgba8": (C.c_int, [P, P, U32, U32, P]),
     "hiprz_untile_accum": (C.c_int, [P, P, U32, U32, P]),
     "hiprz_tonemap_image": (C.c_int, [P, P, P]),
     "hiprz_stream": (P, [P]),

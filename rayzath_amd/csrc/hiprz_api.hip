@@ -41,22 +41,18 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene
         repoint_hot(s, rz_lds);
         stack_offset = s.hot_bytes;
     }
-    uint32_t* lds_column = reinterpret_cast<uint32_t*>(rz_lds + stack_offset) + threadIdx.x;
+    // MODE 2 workspace: [ray/hit/item/bin slots | stack columns]; its stack columns double as the LDS stack of the shadow rays
+    unsigned char* workspace = rz_lds + stack_offset;
+    uint32_t* lds_column = reinterpret_cast<uint32_t*>(MODE == 2 ? workspace + BinnedLds::kFixedBytes : workspace) + threadIdx.x;
     const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
     Counters cnt;
+    Ray ray;
+    col4 ray_color = splat(1.0f);
+    uint32_t ray_material = HIPRZ_MATERIAL_WORLD, depth = 0u;
+    ray.o = ray.d = V3(0.0f, 0.0f, 1.0f), ray.near_ = 0.0f, ray.far_ = 0.0f;
     if (p.active) {
-        const uint32_t pass = FIRST ? 0u : *f.pass;
-        const uint32_t pixel_idx = p.y * cam.width + p.x;
-
-        Ray ray;
-        col4 ray_color;
-        uint32_t ray_material;
-        uint32_t depth;
         if constexpr (FIRST) {
             generate_simple_ray(cam, ray, p.x, p.y);
-            ray_color = splat(1.0f);
-            ray_material = HIPRZ_MATERIAL_WORLD;
-            depth = 0u;
         } else {
             const float4 s0 = f.st0[p.local], s1 = f.st1[p.local];
             const float2 s2 = f.st2[p.local];
@@ -69,6 +65,22 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene
             depth = (bits >> 16) & 0xFFu;
             if (depth == 0u) ray.near_ = cam.near_, ray.far_ = cam.far_;
         }
+    }
+    Hit hit;
+    int found = 0;
+    if constexpr (MODE == 2) {  // all 256 threads; what the walk does not read is parked in LDS meanwhile
+        uint32_t* park = reinterpret_cast<uint32_t*>(workspace + 15u * 1024u);
+        park[0 * 256 + threadIdx.x] = __float_as_uint(ray_color.r), park[1 * 256 + threadIdx.x] = __float_as_uint(ray_color.g);
+        park[2 * 256 + threadIdx.x] = __float_as_uint(ray_color.b), park[3 * 256 + threadIdx.x] = ray_material | (depth << 16);
+        found = closest_hit_binned<COUNT>(s, workspace, p.active, ray, hit, cnt);
+        ray_color = col4{__uint_as_float(park[0 * 256 + threadIdx.x]), __uint_as_float(park[1 * 256 + threadIdx.x]),
+                         __uint_as_float(park[2 * 256 + threadIdx.x]), 1.0f};
+        const uint32_t bits = park[3 * 256 + threadIdx.x];
+        ray_material = bits & 0xFFFFu, depth = bits >> 16;
+    }
+    if (p.active) {
+        const uint32_t pass = FIRST ? 0u : *f.pass;
+        const uint32_t pixel_idx = p.y * cam.width + p.x;
         Rng rng(float(p.x) / float(cam.width), float(p.y) / float(cam.height),
                 seed_value(cfg.seed, pass, (pixel_idx + depth) & 255u));
 
@@ -81,8 +93,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene
         sf.fresnel = 1.0f, sf.reflectance = 0.0f, sf.tint_factor = 0.0f, sf.refr_x = sf.refr_y = 0.0f;
         sf.metalness = sf.roughness = 0.0f;
 
-        Hit hit;
-        const int found = closest_hit<MODE, COUNT>(s, lds_column, ray, hit, cnt);
+        if constexpr (MODE != 2) found = closest_hit<MODE, COUNT>(s, lds_column, ray, hit, cnt);
         Material m;
 #ifdef RZ_EXP_TRAVERSAL_ONLY
         if (found == 2) {
@@ -125,7 +136,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene
             point = (ray.o + ray.d * ray.far_) + sf.normal * (0.0001f * ray.far_);
             (void)incoming_material;
 
-            const col4 direct = direct_illumination<MODE, COUNT>(s, cfg, lds_column, ray.d, ray_material, point,
+            const col4 direct = direct_illumination<(MODE == 2 ? 1 : MODE), COUNT>(s, cfg, lds_column, ray.d, ray_material, point,
                                                                  next_direction, sf, rng, cnt);
             final_color = final_color + (direct * ray_color) * lerp(splat(1.0f), sf.color, sf.metalness);
             ray_color = lerp(ray_color, ray_color * sf.color, sf.tint_factor);  // ColorF::Blend
@@ -255,9 +266,13 @@ __global__ void __launch_bounds__(256) rz_selftest_div_kernel(uint32_t n_per_thr
         float n = __uint_as_float((g & 0x80000000u) | (ne << 23) | (mix32(g) & 0x7FFFFFu));
         if ((g & 0xFFu) == 0u) n = 0.0f;
         const float y = refined_rcp(d);
-        const float fast = div_shared(n, d, y), exact = n / d;
-        tested += 1;
-        if (__float_as_uint(fast) != __float_as_uint(exact) && !(fast == 0.0f && exact == 0.0f)) bad += 1;
+        const float n2 = n == 0.0f ? 0.0f : __uint_as_float(__float_as_uint(n) ^ (mix32(g + 7u) & 0x007FFFFFu));  // second numerator, same exponent
+        const f2 fast = div_shared2(f2{n, n2}, d, y);
+        const float exact = n / d, exact2 = n2 / d;
+        tested += 2;
+        if (__float_as_uint(fast.x) != __float_as_uint(exact) && !(fast.x == 0.0f && exact == 0.0f)) bad += 1;
+        if (__float_as_uint(fast.y) != __float_as_uint(exact2) && !(fast.y == 0.0f && exact2 == 0.0f)) bad += 1;
+        if (__float_as_uint(div_shared(n, d, y)) != __float_as_uint(fast.x)) bad += 1;
     }
     atomicAdd(&out[0], (unsigned long long)bad);
     atomicAdd(&out[1], (unsigned long long)tested);
@@ -379,7 +394,14 @@ struct hiprz_ctx {
     bool reset_pending = true;
     uint32_t passes = 0;
     uint64_t ray_count = 0;
-    int traversal_mode = 1;
+    int traversal_mode = -1;  // -1 = choose per scene (effective_mode)
+
+    // hipGraph of one batch of cumulative passes ([pass kernel, pass update] x n): replayed while nothing that
+    // the captured kernel arguments depend on has changed (scene, camera, config, shard, variants)
+    hipGraphExec_t graph_exec = nullptr;
+    uint32_t graph_passes = 0;
+    bool graph_valid = false;
+    bool use_graph = true;
 
     // kernel timing (hip events on `stream` around each render batch)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
@@ -497,6 +519,14 @@ DConfig make_config(const hiprz_ctx* c) {
     return DConfig{c->config.max_depth, c->config.spot_samples, c->config.direct_samples, c->config.seed};
 }
 
+// The binned walk pays off when a mesh visit is short and uniform (every mesh tree is a single leaf, e.g. the
+// Cornell configs: 329 vs 370 us per pass); with deep mesh trees a round lasts as long as its slowest item
+// and the nested walk is faster (config C: 1 668 vs 2 450 us).
+int effective_mode(const hiprz_ctx* c) {
+    if (c->traversal_mode >= 0) return c->traversal_mode;
+    return c->dscene.mesh_stack_entries <= 2u ? 2 : 1;
+}
+
 constexpr size_t kLdsSceneLimit = 52u * 1024u;  // per workgroup: 3 x 52 KiB < 160 KiB per CU
 
 bool use_lds_scene(const hiprz_ctx* c) {
@@ -511,7 +541,12 @@ void launch_pass(hiprz_ctx* c, const DFrame& f) {
     const DConfig cfg = make_config(c);
     const bool lds_scene = use_lds_scene(c);
     const size_t blob = lds_scene ? c->dscene.hot_bytes : 0u;
-    if (c->traversal_mode == 1) {
+    const int mode = effective_mode(c);
+    if (mode == 2) {
+        const size_t lds = blob + size_t(BinnedLds::bytes_host(c->dscene.world_stack_entries, c->dscene.mesh_stack_entries));
+        if (lds_scene) hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 2, true>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
+        else hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 2, false>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
+    } else if (mode == 1) {
         const size_t lds = blob + size_t(c->stack_entries) * 256u * sizeof(uint32_t);
         if (lds_scene) hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 1, true>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
         else hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 1, false>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
@@ -532,6 +567,35 @@ hipEvent_t take_event(hiprz_ctx* c) {
     return e;
 }
 
+void drop_graph(hiprz_ctx* c) {
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    c->graph_exec = nullptr;
+    c->graph_valid = false;
+}
+
+// [cumulative pass, pass update] x n on the stream — eagerly, or into a capture
+void enqueue_cumulative(hiprz_ctx* c, const DFrame& f, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) {
+        launch_pass<false, false>(c, f);
+        hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+    }
+}
+
+int finish_batch(hiprz_ctx* c, hipEvent_t e0, hipEvent_t e1, uint32_t n_passes, const StageTimer& timer) {
+    RZ_HIP(c, hipEventRecord(e1, c->stream));
+    RZ_HIP(c, hipGetLastError());
+    if (c->pending_events.size() >= 4096) {  // nobody is collecting timings: recycle the oldest pair
+        c->event_pool.push_back(c->pending_events.front().first);
+        c->event_pool.push_back(c->pending_events.front().second);
+        c->pending_events.erase(c->pending_events.begin());
+        c->pending_launches.erase(c->pending_launches.begin());
+    }
+    c->pending_events.emplace_back(e0, e1);
+    c->pending_launches.push_back(n_passes);
+    c->timings.set("render (enqueue)", timer.ms());
+    return HIPRZ_OK;
+}
+
 int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     if (!c->have_scene || !c->have_camera) return fail(c, HIPRZ_ERR_STATE, "render before scene and camera upload");
     if (n_passes == 0 || c->n_local_tiles == 0) return HIPRZ_OK;
@@ -539,6 +603,25 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     const DFrame f = make_frame(c, counted);
     hipEvent_t e0 = take_event(c), e1 = take_event(c);
     RZ_HIP(c, hipEventRecord(e0, c->stream));
+    if (c->use_graph && !counted && !c->reset_pending && n_passes >= 2) {
+        // steady state: one graph launch instead of 2 * n_passes kernel launches
+        if (!c->graph_valid || c->graph_passes != n_passes) {
+            drop_graph(c);
+            hipGraph_t graph = nullptr;
+            RZ_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            enqueue_cumulative(c, f, n_passes);
+            RZ_HIP(c, hipStreamEndCapture(c->stream, &graph));
+            const hipError_t ie = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph);
+            if (ie != hipSuccess) return fail(c, HIPRZ_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+            c->graph_passes = n_passes;
+            c->graph_valid = true;
+        }
+        RZ_HIP(c, hipGraphLaunch(c->graph_exec, c->stream));
+        c->passes += n_passes;
+        c->ray_count += uint64_t(n_passes) * c->owned_pixels;
+        return finish_batch(c, e0, e1, n_passes, timer);
+    }
     for (uint32_t i = 0; i < n_passes; ++i) {
         if (c->reset_pending) {
             hipLaunchKernelGGL(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
@@ -555,18 +638,7 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
         c->passes += 1;
         c->ray_count += c->owned_pixels;  // traced_rays += W*H per pass (cpu_engine_renderer.cpp:173), per shard
     }
-    RZ_HIP(c, hipEventRecord(e1, c->stream));
-    RZ_HIP(c, hipGetLastError());
-    if (c->pending_events.size() >= 4096) {  // nobody is collecting timings: recycle the oldest pair
-        c->event_pool.push_back(c->pending_events.front().first);
-        c->event_pool.push_back(c->pending_events.front().second);
-        c->pending_events.erase(c->pending_events.begin());
-        c->pending_launches.erase(c->pending_launches.begin());
-    }
-    c->pending_events.emplace_back(e0, e1);
-    c->pending_launches.push_back(n_passes);
-    c->timings.set("render (enqueue)", timer.ms());
-    return HIPRZ_OK;
+    return finish_batch(c, e0, e1, n_passes, timer);
 }
 
 template <typename T>
@@ -703,6 +775,7 @@ int hiprz_destroy(hiprz_ctx* c) {
     if (!c) return HIPRZ_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    drop_graph(c);
     for (auto& p : c->pending_events) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -721,6 +794,7 @@ const char* hiprz_last_error(const hiprz_ctx* c) { return c ? c->error.c_str() :
 
 int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     if (!c) return HIPRZ_ERR_INVALID;
+    c->graph_valid = false;
     StageTimer timer;
     SceneCheck chk;
     if (check_scene(sc, chk) != HIPRZ_OK) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: " + chk.error);
@@ -730,6 +804,8 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     } check{chk.world_leaves};
     const uint32_t world_depth = chk.world_depth, mesh_depth = chk.mesh_depth;
     c->stack_entries = world_depth + mesh_depth + 2u;
+    c->dscene.world_stack_entries = world_depth + 1u;
+    c->dscene.mesh_stack_entries = mesh_depth + 1u;
 
     // ---- walk graph of the threaded traversal (hiprz_device.hpp: walk_threaded) ----
     // nodes keep their index; every world-tree leaf becomes a CHAIN node whose `begin` points at a
@@ -779,9 +855,25 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
         return off;
     };
     DScene& d = c->dscene;
-    d.off_nodes = append(sc->nodes, sizeof(hiprz_node) * sc->n_nodes);
+    // device copies keep every box interleaved, (min.x, max.x, min.y, max.y, min.z, max.z), so one axis' two
+    // plane distances are one packed operand of the box test (hiprz_device.hpp: box_hit)
+    auto interleave = [](float* mn, float* mx) {
+        const float v[6] = {mn[0], mx[0], mn[1], mx[1], mn[2], mx[2]};
+        mn[0] = v[0], mn[1] = v[1], mn[2] = v[2], mx[0] = v[3], mx[1] = v[4], mx[2] = v[5];
+    };
+    std::vector<hiprz_node> dnodes(sc->nodes, sc->nodes + sc->n_nodes);
+    for (auto& n : dnodes) interleave(n.bb_min, n.bb_max);  // bb_min[3] and bb_max[3] are contiguous
+    for (auto& n : wnodes) interleave(n.bb_min, n.bb_max);
+    std::vector<hiprz_instance> dinstances(sc->instances, sc->instances + sc->n_instances);
+    for (auto& in : dinstances) {
+        const float v[6] = {in.bb_min[0], in.bb_max[0], in.bb_min[1], in.bb_max[1], in.bb_min[2], in.bb_max[2]};
+        in.bb_min[0] = v[0], in.bb_min[1] = v[1], in.bb_min[2] = v[2];
+        std::memcpy(&in.pad2, &v[3], 4);
+        in.bb_max[0] = v[4], in.bb_max[1] = v[5], in.bb_max[2] = 0.0f;
+    }
+    d.off_nodes = append(dnodes.data(), sizeof(hiprz_node) * dnodes.size());
     d.off_tlas_order = append(sc->tlas_order, sizeof(uint32_t) * sc->n_tlas_order);
-    d.off_instances = append(sc->instances, sizeof(hiprz_instance) * sc->n_instances);
+    d.off_instances = append(dinstances.data(), sizeof(hiprz_instance) * dinstances.size());
     d.off_tris = append(sc->tris, sizeof(hiprz_tri) * sc->n_tris);
     d.off_tri_attrs = append(sc->tri_attrs, sizeof(hiprz_tri_attr) * sc->n_tris);
     d.off_materials = append(sc->materials, sizeof(hiprz_material) * sc->n_materials);
@@ -819,7 +911,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     d.n_direct_lights = sc->n_direct_lights;
     // Stage the blob in LDS when three workgroups per CU (the kernel's register-limited residency)
     // still fit into the CU's 160 KiB together with their traversal stacks.
-    c->lds_scene = size_t(d.hot_bytes) + size_t(c->stack_entries) * 1024u <= kLdsSceneLimit;
+    c->lds_scene = size_t(d.hot_bytes) + size_t(c->stack_entries) * 1024u + BinnedLds::kFixedBytes <= kLdsSceneLimit;
     c->have_scene = true;
     c->reset_pending = true;  // world changed => accumulation restarts (cpu_engine_renderer.cpp:108-112)
     c->timings.set("upload scene", timer.ms());
@@ -828,6 +920,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
 
 int hiprz_upload_camera(hiprz_ctx* c, const hiprz_camera* cam) {
     if (!c) return HIPRZ_ERR_INVALID;
+    c->graph_valid = false;
     if (!cam) return fail(c, HIPRZ_ERR_INVALID, "upload_camera: camera is null");
     if (cam->width == 0 || cam->height == 0 || cam->width > 32768u || cam->height > 32768u)
         return fail(c, HIPRZ_ERR_INVALID, "upload_camera: resolution must be 1..32768");
@@ -856,6 +949,7 @@ int hiprz_upload_camera(hiprz_ctx* c, const hiprz_camera* cam) {
 
 int hiprz_set_config(hiprz_ctx* c, const hiprz_config* cfg) {
     if (!c) return HIPRZ_ERR_INVALID;
+    c->graph_valid = false;
     if (!cfg) return fail(c, HIPRZ_ERR_INVALID, "set_config: config is null");
     if (cfg->max_depth == 0 || cfg->max_depth > 254u) return fail(c, HIPRZ_ERR_INVALID, "max_depth must be 1..254 (u8, 255 = path ended)");
     // The CPU kernel divides by sample_count/light_count and yields NaN for 0 samples
@@ -868,6 +962,7 @@ int hiprz_set_config(hiprz_ctx* c, const hiprz_config* cfg) {
 
 int hiprz_set_shard(hiprz_ctx* c, uint32_t rank, uint32_t world) {
     if (!c) return HIPRZ_ERR_INVALID;
+    c->graph_valid = false;
     if (world == 0 || rank >= world) return fail(c, HIPRZ_ERR_INVALID, "set_shard: need rank < world");
     const bool changed = rank != c->rank || world != c->world;
     c->rank = rank, c->world = world;
@@ -882,15 +977,29 @@ int hiprz_set_shard(hiprz_ctx* c, uint32_t rank, uint32_t world) {
 
 int hiprz_set_traversal_mode(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
-    if (mode != 0 && mode != 1) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: 0 = threaded, 1 = LDS stack");
+    c->graph_valid = false;
+    if (mode < -1 || mode > 2) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: -1 = auto, 0 = threaded, 1 = LDS stack, 2 = workgroup-binned");
     c->traversal_mode = mode;
     return HIPRZ_OK;
 }
 
 int hiprz_set_lds_scene(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
+    c->graph_valid = false;
     if (mode < -1 || mode > 1) return fail(c, HIPRZ_ERR_INVALID, "lds scene: -1 auto, 0 off, 1 on");
     c->lds_scene_override = mode;
+    return HIPRZ_OK;
+}
+
+int hiprz_traversal_mode(hiprz_ctx* c, int* out) {
+    if (!c || !out) return HIPRZ_ERR_INVALID;
+    *out = effective_mode(c);
+    return HIPRZ_OK;
+}
+
+int hiprz_set_graph(hiprz_ctx* c, int enabled) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    c->use_graph = enabled != 0;
     return HIPRZ_OK;
 }
 
@@ -1000,6 +1109,28 @@ int hiprz_export_accum_tiles(hiprz_ctx* c, void* dst_device, size_t bytes) {
     if (need) RZ_HIP(c, hipMemcpyAsync(dst_device, c->accum.ptr, need, hipMemcpyDeviceToDevice, c->stream));
     return HIPRZ_OK;
 }
+int hiprz_export_rgba8_tiles(hiprz_ctx* c, void* dst_device, size_t bytes) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    const size_t need = size_t(c->n_local_tiles) * 256u * sizeof(uint32_t);
+    if (!dst_device || bytes < need) return fail(c, HIPRZ_ERR_INVALID, "export_rgba8_tiles: destination too small");
+    (void)hipSetDevice(c->device);
+    if (need) RZ_HIP(c, hipMemcpyAsync(dst_device, c->rgba8.ptr, need, hipMemcpyDeviceToDevice, c->stream));
+    return HIPRZ_OK;
+}
+int hiprz_untile_rgba8(hiprz_ctx* c, const void* src_tiles, uint32_t rank, uint32_t world, void* dst_image) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "untile before camera upload");
+    if (!src_tiles || !dst_image || world == 0 || rank >= world) return fail(c, HIPRZ_ERR_INVALID, "untile_rgba8: bad arguments");
+    (void)hipSetDevice(c->device);
+    const uint32_t n_tiles = c->tiles_x * c->tiles_y;
+    const uint32_t n_local = rank < n_tiles ? (n_tiles - rank + world - 1u) / world : 0u;
+    if (n_local)
+        hipLaunchKernelGGL((rz_untile_kernel<uint32_t>), dim3(n_local), dim3(256), 0, c->stream,
+                           reinterpret_cast<const uint32_t*>(src_tiles), reinterpret_cast<uint32_t*>(dst_image), c->camera.width,
+                           c->camera.height, c->tiles_x, rank, world);
+    RZ_HIP(c, hipGetLastError());
+    return HIPRZ_OK;
+}
 int hiprz_untile_accum(hiprz_ctx* c, const void* src_tiles, uint32_t rank, uint32_t world, void* dst_image) {
     if (!c) return HIPRZ_ERR_INVALID;
     if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "untile before camera upload");
@@ -1063,6 +1194,15 @@ int hiprz_selftest(hiprz_ctx* c, uint32_t cases_per_thread, uint32_t seed, uint6
     *mismatches = v[0], *tested = v[1];
     return HIPRZ_OK;
 }
+
+#ifdef RZ_STAMP
+int hiprz_read_stamps(unsigned long long out[8]) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(hiprz::rz_stamp_sums), 64);
+    unsigned long long zero[8] = {0};
+    hipMemcpyToSymbol(HIP_SYMBOL(hiprz::rz_stamp_sums), zero, 64);
+    return 0;
+}
+#endif
 
 int hiprz_timings(hiprz_ctx* c, char* buf, size_t len) {
     if (!c || !buf || len == 0) return HIPRZ_ERR_INVALID;

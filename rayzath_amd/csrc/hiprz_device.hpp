@@ -75,7 +75,9 @@ struct DScene {
     // workgroup can stage it into LDS with one strided copy when it is small enough.
     uint32_t hot_bytes;
     const float4* hot;  // start of the blob
-    uint32_t off_nodes, off_tlas_order, off_instances, off_tris, off_tri_attrs, off_materials, off_inst_materials, pad1;
+    uint32_t off_nodes, off_tlas_order, off_instances, off_tris, off_tri_attrs, off_materials, off_inst_materials;
+    uint32_t world_stack_entries;  // LDS stack entries per lane the world tree needs / the deepest mesh tree needs
+    uint32_t mesh_stack_entries, pad1;
 };
 
 // Re-point the blob sections at a staged copy (LDS).
@@ -234,9 +236,10 @@ struct Instance {
     v3 position, scale, xa, ya, za, bb_min, bb_max;
     uint32_t blas_root, material_base, material_count;
 };
-RZ_DEV void load_instance_box(const DScene& s, uint32_t i, v3& mn, v3& mx) {
-    mn = xyz(s.instances[7 * i + 5]);
-    mx = xyz(s.instances[7 * i + 6]);
+// device instance records keep the box interleaved like nodes: [5] = (min.x, max.x, min.y, max.y), [6].xy = (min.z, max.z)
+RZ_DEV void load_instance_box(const DScene& s, uint32_t i, float4& b0, float4& b1) {
+    b0 = s.instances[7 * i + 5];
+    b1 = s.instances[7 * i + 6];
 }
 struct InstanceXform {
     v3 position, scale, xa, ya, za;
@@ -304,9 +307,12 @@ struct Hit {
 // Correctly rounded fp32 division with a reciprocal shared between numerators.  This is the
 // instruction sequence hipcc emits for `n / d` (v_rcp_f32, two fma to refine it, then
 // mul + fma,fma + fma,fma on the quotient) WITHOUT the v_div_scale / v_div_fixup wrapping,
-// which is an identity when no operand or result needs rescaling: |d| in [2^-40, 4] and
-// n == 0 or |n| in [2^-84, 2^41] (see safe_for_shared_rcp and the upload-time check of node
-// coordinates).  Outside that range the plain `/` is used.  tests: hiprz_selftest().
+// which is an identity when no operand or result needs rescaling: |d| in [2^-40, 4) and
+// n == 0 or |n| in [2^-84, 2^41) (see prepare() and the upload-time check of box coordinates).
+// Outside that range the plain `/` is used.  The two quotients of one axis (box min and max over the
+// same ray component) run as ONE packed sequence (v_pk_mul_f32 + 4 v_pk_fma_f32: measured 1.05 ns
+// per fma-lane against 1.8 ns for v_fma_f32).  Proven bit-equal to `/` by hiprz_selftest().
+typedef float f2 __attribute__((ext_vector_type(2)));
 RZ_DEV float refined_rcp(float d) {
     const float r = __builtin_amdgcn_rcpf(d);
     const float e = __builtin_fmaf(-d, r, 1.0f);
@@ -318,6 +324,14 @@ RZ_DEV float div_shared(float n, float d, float y) {
     q = __builtin_fmaf(r, y, q);
     r = __builtin_fmaf(-d, q, n);
     return __builtin_fmaf(r, y, q);
+}
+RZ_DEV f2 div_shared2(f2 n, float d, float y) {
+    const f2 nd = {-d, -d}, yy = {y, y};
+    f2 q = n * yy;
+    f2 r = __builtin_elementwise_fma(nd, q, n);
+    q = __builtin_elementwise_fma(r, yy, q);
+    r = __builtin_elementwise_fma(nd, q, n);
+    return __builtin_elementwise_fma(r, yy, q);
 }
 // |x| in [2^lo, 2^hi) tested on the exponent field
 RZ_DEV bool exponent_in(float x, int lo, int hi) {
@@ -332,8 +346,6 @@ struct WalkRay {
     float near_, far_;
     bool fast;
 };
-// The nested walk keeps the plain `/` (measured: the extra registers of the shared-reciprocal form
-// cost it an occupancy step); the threaded walk uses the shared reciprocal.
 template <bool SHARED_RCP>
 RZ_DEV void prepare(WalkRay& r, bool scene_fast) {
     if constexpr (!SHARED_RCP) {
@@ -344,25 +356,50 @@ RZ_DEV void prepare(WalkRay& r, bool scene_fast) {
              zero_or_exponent_in(r.o.x, -60, 40) && zero_or_exponent_in(r.o.y, -60, 40) && zero_or_exponent_in(r.o.z, -60, 40);
     r.y = v3{refined_rcp(r.d.x), refined_rcp(r.d.y), refined_rcp(r.d.z)};
 }
-// BoundingBox::rayIntersection (render_parts.cpp:197-217) on a prepared ray
+// min / max without NaN handling (operands are finite on the path that uses them)
+RZ_DEV float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+RZ_DEV float vmax(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+RZ_DEV float vmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+RZ_DEV float vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// BoundingBox::rayIntersection (render_parts.cpp:197-217) on a prepared ray.  The box comes as the
+// device stores it: b0 = (min.x, max.x, min.y, max.y), b1.xy = (min.z, max.z).
 template <bool SHARED_RCP>
-RZ_DEV bool box_hit(v3 mn, v3 mx, const WalkRay& r) {
-    float t1, t2, t3, t4, t5, t6;
+RZ_DEV bool box_hit(float4 b0, float4 b1, const WalkRay& r) {
+#ifdef RZ_EXP_FORCE_FAST
+    if (SHARED_RCP) {
+#else
     if (SHARED_RCP && __all(r.fast)) {  // wave-uniform branch
-        t1 = div_shared(mn.x - r.o.x, r.d.x, r.y.x);
-        t2 = div_shared(mx.x - r.o.x, r.d.x, r.y.x);
-        t3 = div_shared(mn.y - r.o.y, r.d.y, r.y.y);
-        t4 = div_shared(mx.y - r.o.y, r.d.y, r.y.y);
-        t5 = div_shared(mn.z - r.o.z, r.d.z, r.y.z);
-        t6 = div_shared(mx.z - r.o.z, r.d.z, r.y.z);
-    } else {
-        t1 = (mn.x - r.o.x) / r.d.x;
-        t2 = (mx.x - r.o.x) / r.d.x;
-        t3 = (mn.y - r.o.y) / r.d.y;
-        t4 = (mx.y - r.o.y) / r.d.y;
-        t5 = (mn.z - r.o.z) / r.d.z;
-        t6 = (mx.z - r.o.z) / r.d.z;
+#endif
+        const f2 tx = div_shared2(f2{b0.x, b0.y} - f2{r.o.x, r.o.x}, r.d.x, r.y.x);
+        const f2 ty = div_shared2(f2{b0.z, b0.w} - f2{r.o.y, r.o.y}, r.d.y, r.y.y);
+        const f2 tz = div_shared2(f2{b1.x, b1.y} - f2{r.o.z, r.o.z}, r.d.z, r.y.z);
+        // every t is finite here, so `a < b ? a : b` is the plain minimum (equal values may differ in the sign of zero only)
+        const float tmin = vmax3(vmin(tx.x, tx.y), vmin(ty.x, ty.y), vmin(tz.x, tz.y));
+        const float tmax = vmin3(vmax(tx.x, tx.y), vmax(ty.x, ty.y), vmax(tz.x, tz.y));
+        return !(tmax < r.near_ || tmin > tmax || tmin > r.far_);
     }
+    const float t1 = (b0.x - r.o.x) / r.d.x;
+    const float t2 = (b0.y - r.o.x) / r.d.x;
+    const float t3 = (b0.z - r.o.y) / r.d.y;
+    const float t4 = (b0.w - r.o.y) / r.d.y;
+    const float t5 = (b1.x - r.o.z) / r.d.z;
+    const float t6 = (b1.y - r.o.z) / r.d.z;
     const float tmin = max_gt(max_gt(min_lt(t1, t2), min_lt(t3, t4)), min_lt(t5, t6));
     const float tmax = min_lt(min_lt(max_gt(t1, t2), max_gt(t3, t4)), max_gt(t5, t6));
     return !(tmax < r.near_ || tmin > tmax || tmin > r.far_);
@@ -414,7 +451,7 @@ RZ_DEV int walk_threaded(const DScene& s, Ray& ray, Hit& hit, Counters& cnt) {
         const float4 n0 = s.wnodes[2 * n], n1 = s.wnodes[2 * n + 1];
         const uint32_t link = s.wskip[n];
         RZ_COUNT(box_tests);
-        if (box_hit<true>(xyz(n0), v3{n0.w, n1.x, n1.y}, cur)) {
+        if (box_hit<true>(n0, n1, cur)) {
             const uint32_t a = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             const uint32_t type = meta >> RZ_WALK_TYPE_SHIFT;
             if (type == RZ_WALK_INNER || type == RZ_WALK_CHAIN) {
@@ -504,7 +541,7 @@ RZ_DEV bool closest_in_mesh_stack(const DScene& s, LdsStack& w, uint32_t root, W
     while (n != RZ_END) {
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
-        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(xyz(n0), v3{n0.w, n1.x, n1.y}, lr)) {
+        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(n0, n1, lr)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             if (!(meta & HIPRZ_NODE_LEAF)) {
                 n = w.descend(begin);
@@ -541,7 +578,7 @@ RZ_DEV int closest_hit_stack(const DScene& s, uint32_t* lds_column, Ray& ray, Hi
     while (n != RZ_END) {
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
-        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(xyz(n0), v3{n0.w, n1.x, n1.y}, g)) {
+        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(n0, n1, g)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             if (!(meta & HIPRZ_NODE_LEAF)) {
                 n = w.descend(begin);
@@ -550,10 +587,10 @@ RZ_DEV int closest_hit_stack(const DScene& s, uint32_t* lds_column, Ray& ray, Hi
             const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
             for (uint32_t i = begin; i < end; ++i) {
                 const uint32_t inst = s.tlas_order[i];
-                v3 mn, mx;
-                load_instance_box(s, inst, mn, mx);
+                float4 ib0, ib1;
+                load_instance_box(s, inst, ib0, ib1);
                 RZ_COUNT(box_tests);
-                if (!box_hit<RZ_NESTED_SHARED_RCP != 0>(mn, mx, g)) continue;
+                if (!box_hit<RZ_NESTED_SHARED_RCP != 0>(ib0, ib1, g)) continue;
                 const InstanceXform x = load_instance_xform(s, inst);
                 WalkRay lr;
                 const float len = to_local(x, g, lr, scene_fast);
@@ -584,7 +621,7 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
     while (n != RZ_END) {
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
-        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(xyz(n0), v3{n0.w, n1.x, n1.y}, g)) {
+        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(n0, n1, g)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             if (!(meta & HIPRZ_NODE_LEAF)) {
                 n = w.descend(begin);
@@ -593,10 +630,10 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
             const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
             for (uint32_t i = begin; i < end; ++i) {
                 const uint32_t inst = s.tlas_order[i];
-                v3 mn, mx;
-                load_instance_box(s, inst, mn, mx);
+                float4 ib0, ib1;
+                load_instance_box(s, inst, ib0, ib1);
                 RZ_COUNT(box_tests);
-                if (!box_hit<RZ_NESTED_SHARED_RCP != 0>(mn, mx, g)) continue;
+                if (!box_hit<RZ_NESTED_SHARED_RCP != 0>(ib0, ib1, g)) continue;
                 const InstanceXform x = load_instance_xform(s, inst);
                 WalkRay lr;
                 to_local(x, g, lr, scene_fast);
@@ -606,7 +643,7 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
                 while (m != RZ_END) {
                     const float4 m0 = s.nodes[2 * m], m1 = s.nodes[2 * m + 1];
                     RZ_COUNT(box_tests);
-                    if (box_hit<RZ_NESTED_SHARED_RCP != 0>(xyz(m0), v3{m0.w, m1.x, m1.y}, lr)) {
+                    if (box_hit<RZ_NESTED_SHARED_RCP != 0>(m0, m1, lr)) {
                         const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                         if (!(mmeta & HIPRZ_NODE_LEAF)) {
                             m = w.descend(mbegin);
@@ -631,6 +668,197 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
     return 1.0f;
 }
 
+
+// ---- MODE 2: workgroup-binned closest hit ("wave64 ballot/prefix compaction of live paths") ----
+// With one thread = one ray, only the lanes whose ray enters an instance do the expensive part
+// (instance transform, mesh-tree walk, triangle tests): ~30 % of a wave on the Cornell scene.  Here
+// the 256 rays of a workgroup advance in rounds.  In a round every ray walks the world tree to ITS
+// next instance whose box it hits (its own order, with its current range — the reference's sequence);
+// the (ray, instance) items are then counted per instance, prefix-summed and scattered into a dense
+// list in LDS, and lanes 0..n_items-1 each process ONE item: fetch that ray from LDS, enter the
+// instance, walk the mesh tree, and write a closer hit back to the ray's slot.  Idle lanes become idle
+// WAVES, which cost nothing, and a wave's items are (nearly) all the same instance, so its leaf loops
+// have equal trip counts.  Every ray still sees its instances one after another with an updated
+// range, so results equal the sequential walk bit for bit.
+#define RZ_BIN_NONE 0xFFFFFFFFu
+#ifdef RZ_STAMP  // diagnostic build: where do the rounds spend their cycles (never timed, never shipped)
+__device__ unsigned long long rz_stamp_sums[8];
+#define RZ_STAMP_BEGIN() long long rz_t = __builtin_amdgcn_s_memtime(); long long rz_acc[6] = {0, 0, 0, 0, 0, 0}
+#define RZ_STAMP_MARK(k)                                   \
+    {                                                      \
+        const long long rz_now = __builtin_amdgcn_s_memtime(); \
+        rz_acc[k] += rz_now - rz_t;                        \
+        rz_t = rz_now;                                     \
+    }
+#define RZ_STAMP_END()                                                                                         \
+    if ((threadIdx.x & 63u) == 0u) {                                                                           \
+        for (int k = 0; k < 6; ++k) atomicAdd(&rz_stamp_sums[k], (unsigned long long)rz_acc[k]);               \
+        atomicAdd(&rz_stamp_sums[6], (unsigned long long)round);                                               \
+        atomicAdd(&rz_stamp_sums[7], 1ull);                                                                    \
+    }
+#else
+#define RZ_STAMP_BEGIN()
+#define RZ_STAMP_MARK(k)
+#define RZ_STAMP_END()
+#endif
+struct BinnedLds {  // per-workgroup workspace carved from dynamic LDS (256 lanes)
+    float* ray;         // [8][256]  o.xyz d.xyz near far
+    uint32_t* hit;      // [5][256]  triangle, external, b1, b2, instance
+    uint32_t* items;    // [256]     instance << 8 | source lane
+    uint32_t* bins;     // [2][64] per-instance item counts, double-buffered by round
+    uint32_t* park;     // [4][256]  values the walk does not need (kept out of registers while it runs)
+    uint32_t* stacks;   // [(world + mesh entries)][256] level-major stack columns
+    static constexpr uint32_t kFixedBytes = 19u * 1024u;
+    static __host__ uint32_t bytes_host(uint32_t world_entries, uint32_t mesh_entries) {
+        return kFixedBytes + (world_entries + mesh_entries) * 1024u;
+    }
+    __device__ __forceinline__ explicit BinnedLds(unsigned char* base) {
+        ray = reinterpret_cast<float*>(base);
+        hit = reinterpret_cast<uint32_t*>(base + 8u * 1024u);
+        items = reinterpret_cast<uint32_t*>(base + 13u * 1024u);
+        bins = reinterpret_cast<uint32_t*>(base + 14u * 1024u);
+        park = reinterpret_cast<uint32_t*>(base + 15u * 1024u);
+        stacks = reinterpret_cast<uint32_t*>(base + kFixedBytes);
+    }
+};
+
+// Must be called by ALL 256 threads of the workgroup (it contains barriers); `active` = this lane
+// carries a ray.  Returns 0 / 1 / 2 like closest_hit().
+template <bool COUNT>
+__device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char* workspace, bool active, Ray& ray, Hit& hit,
+                                                  Counters& cnt) {
+    const uint32_t tid = threadIdx.x;
+    BinnedLds lds(workspace);
+    hit.instance = -1, hit.triangle = 0, hit.bx = hit.by = 0.0f, hit.external = true;
+    if (s.n_instances == 0) return 0;  // uniform
+
+    lds.ray[0 * 256 + tid] = ray.o.x, lds.ray[1 * 256 + tid] = ray.o.y, lds.ray[2 * 256 + tid] = ray.o.z;
+    lds.ray[3 * 256 + tid] = ray.d.x, lds.ray[4 * 256 + tid] = ray.d.y, lds.ray[5 * 256 + tid] = ray.d.z;
+    lds.ray[6 * 256 + tid] = ray.near_, lds.ray[7 * 256 + tid] = ray.far_;
+    lds.hit[4 * 256 + tid] = 0xFFFFFFFFu;
+
+    LdsStack world(lds.stacks + tid);
+    uint32_t* mesh_column = lds.stacks + s.world_stack_entries * 256u + tid;
+    const bool sorted = s.n_instances <= 64u;
+    WalkRay g;
+    g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
+    const bool scene_fast = s.fast_div != 0u;
+    prepare<RZ_NESTED_SHARED_RCP != 0>(g, scene_fast);
+    uint32_t n = active ? s.tlas_root : RZ_END;  // world-tree cursor of this lane's ray
+    uint32_t leaf_i = 0, leaf_end = 0;
+    bool root_missed = false;
+    uint32_t round = 0u;
+    if (tid < 128u) lds.bins[tid] = 0u;
+    __syncthreads();
+    RZ_STAMP_BEGIN();
+
+    while (true) {
+        // A. advance this ray to its next candidate instance (traverseWorld, cpu_engine_kernel.cpp:254-277, 305)
+        uint32_t cand = RZ_BIN_NONE;
+        while (true) {
+            if (leaf_i < leaf_end) {
+                const uint32_t inst = s.tlas_order[leaf_i++];
+                float4 ib0, ib1;
+                load_instance_box(s, inst, ib0, ib1);
+                RZ_COUNT(box_tests);
+                if (box_hit<RZ_NESTED_SHARED_RCP != 0>(ib0, ib1, g)) {
+                    cand = inst;
+                    break;
+                }
+                continue;
+            }
+            if (n == RZ_END) break;
+            const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
+            RZ_COUNT(box_tests);
+            if (box_hit<RZ_NESTED_SHARED_RCP != 0>(n0, n1, g)) {
+                const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+                if (!(meta & HIPRZ_NODE_LEAF)) {
+                    n = world.descend(begin);
+                    continue;
+                }
+                leaf_i = begin, leaf_end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
+            } else if (n == s.tlas_root) {
+                root_missed = true;
+            }
+            n = world.next(0u);
+        }
+
+        // B. bin the items by instance: count (LDS atomics), exclusive prefix over the 64 bins computed
+        //    redundantly by every wave (no barrier between scan and scatter), scatter.  The bins are
+        //    double-buffered: this round's were zeroed during the previous round.
+        RZ_STAMP_MARK(0);  // A: world walk
+        uint32_t* bins = lds.bins + (round & 1u) * 64u;
+        uint32_t rank = 0u;
+        const uint32_t bin = sorted ? cand : 0u;
+        if (cand != RZ_BIN_NONE) rank = atomicAdd(&bins[bin], 1u);
+        __syncthreads();
+        RZ_STAMP_MARK(1);  // count + barrier (waiting for the slowest walker)
+        const uint32_t lane = tid & 63u;
+        const uint32_t c = bins[lane];
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (int(lane) >= off) incl += v;
+        }
+        const uint32_t n_items = __shfl(incl, 63);
+        if (n_items == 0u) break;  // workgroup-uniform
+        const uint32_t start = __shfl(incl - c, int(bin & 63u));
+        if (cand != RZ_BIN_NONE) lds.items[start + rank] = (cand << 8) | tid;
+        if (tid < 64u) lds.bins[((round + 1u) & 1u) * 64u + tid] = 0u;
+        __syncthreads();
+        RZ_STAMP_MARK(2);  // scan + scatter + barrier
+
+        // C. dense: one lane per item (closestIntersection(instance) + (mesh), :299-352).  The lane that
+        //    takes item i rotates with the round and the workgroup, so the busy waves — and with them the
+        //    SIMDs they live on — change from round to round instead of always being waves 0..1.
+        const uint32_t slot = (tid - ((blockIdx.x + round) & 3u) * 64u) & 255u;
+        if (slot < n_items) {
+            const uint32_t item = lds.items[slot], inst = item >> 8, src = item & 255u;
+            WalkRay w;
+            w.o = V3(lds.ray[0 * 256 + src], lds.ray[1 * 256 + src], lds.ray[2 * 256 + src]);
+            w.d = V3(lds.ray[3 * 256 + src], lds.ray[4 * 256 + src], lds.ray[5 * 256 + src]);
+            w.near_ = lds.ray[6 * 256 + src], w.far_ = lds.ray[7 * 256 + src];
+            const InstanceXform x = load_instance_xform(s, inst);
+            WalkRay lr;
+            const float len = to_local(x, w, lr, scene_fast);
+            LdsStack mesh(mesh_column);
+            Hit h;
+            if (closest_in_mesh_stack<COUNT>(s, mesh, x.blas_root, lr, h, cnt)) {
+                lds.ray[6 * 256 + src] = lr.near_ / len;
+                lds.ray[7 * 256 + src] = lr.far_ / len;
+                lds.hit[0 * 256 + src] = h.triangle;
+                lds.hit[1 * 256 + src] = h.external ? 1u : 0u;
+                lds.hit[2 * 256 + src] = __float_as_uint(h.bx);
+                lds.hit[3 * 256 + src] = __float_as_uint(h.by);
+                lds.hit[4 * 256 + src] = inst;
+            }
+        }
+        RZ_STAMP_MARK(3);  // C: dense item work
+        __syncthreads();
+        RZ_STAMP_MARK(4);  // barrier (waiting for the slowest item)
+        round += 1u;
+        // D. the ray's owner picks up its (possibly shortened) range
+        g.near_ = lds.ray[6 * 256 + tid];
+        g.far_ = lds.ray[7 * 256 + tid];
+    }
+    RZ_STAMP_END();
+    // origin and direction were not kept in registers across the rounds: take them back from the slot
+    ray.o = V3(lds.ray[0 * 256 + tid], lds.ray[1 * 256 + tid], lds.ray[2 * 256 + tid]);
+    ray.d = V3(lds.ray[3 * 256 + tid], lds.ray[4 * 256 + tid], lds.ray[5 * 256 + tid]);
+    ray.near_ = g.near_, ray.far_ = g.far_;
+    const uint32_t inst = lds.hit[4 * 256 + tid];
+    if (inst != 0xFFFFFFFFu) {
+        hit.instance = int32_t(inst);
+        hit.triangle = lds.hit[0 * 256 + tid];
+        hit.external = lds.hit[1 * 256 + tid] != 0u;
+        hit.bx = __uint_as_float(lds.hit[2 * 256 + tid]);
+        hit.by = __uint_as_float(lds.hit[3 * 256 + tid]);
+    }
+    if (root_missed) return 0;
+    return hit.instance >= 0 ? 2 : 1;
+}
+
 // Returns 0 = no instances / root box missed (the reference returns before it computes the
 // sky texcrd, cpu_engine_kernel.cpp:282-283), 1 = walked, nothing hit (sky texcrd is computed,
 // :292-295), 2 = hit.
@@ -642,7 +870,7 @@ RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit
     hit.external = true;
     if (s.n_instances == 0) return 0;
     if constexpr (MODE == 0) return walk_threaded<false, COUNT>(s, ray, hit, cnt);
-    else return closest_hit_stack<COUNT>(s, lds_column, ray, hit, cnt);
+    else return closest_hit_stack<COUNT>(s, lds_column, ray, hit, cnt);  // MODE 2 calls closest_hit_binned directly
 }
 // anyIntersection(const RangedRay&): returns the shadow mask's alpha (0 or 1)
 template <int MODE, bool COUNT>

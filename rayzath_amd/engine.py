@@ -79,6 +79,11 @@ class Context:
     def set_traversal_mode(self, mode):
         self._check(self.lib.hiprz_set_traversal_mode(self._ctx, mode))
 
+    def traversal_mode(self):
+        v = C.c_int()
+        self._check(self.lib.hiprz_traversal_mode(self._ctx, C.byref(v)))
+        return v.value
+
     def set_lds_scene(self, mode):
         self._check(self.lib.hiprz_set_lds_scene(self._ctx, mode))
 
@@ -162,6 +167,15 @@ class Context:
 
     def export_accum_tiles(self, dst_ptr, nbytes):
         self._check(self.lib.hiprz_export_accum_tiles(self._ctx, dst_ptr, nbytes))
+
+    def export_rgba8_tiles(self, dst_ptr, nbytes):
+        self._check(self.lib.hiprz_export_rgba8_tiles(self._ctx, dst_ptr, nbytes))
+
+    def untile_rgba8(self, src_ptr, rank, world, dst_ptr):
+        self._check(self.lib.hiprz_untile_rgba8(self._ctx, src_ptr, rank, world, dst_ptr))
+
+    def set_graph(self, enabled):
+        self._check(self.lib.hiprz_set_graph(self._ctx, int(enabled)))
 
     def untile_accum(self, src_ptr, rank, world, dst_ptr):
         self._check(self.lib.hiprz_untile_accum(self._ctx, src_ptr, rank, world, dst_ptr))
