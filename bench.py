@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="B", help="scene preset of rayzath_amd/scenes.py (B = the quoted config)")
     ap.add_argument("--traversal", type=int, default=-1, help="-1 per-scene choice (default), 1 nested walk with LDS stack, 2 workgroup-binned, 0 threaded")
+    ap.add_argument("--pipeline", type=int, default=-1, help="0 fused pass kernel, 1 trace + shade kernels (-1: library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-gather", action="store_true", help="check the gathered frame against an unsharded render (N > 1)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -108,6 +109,8 @@ def main():
 
     ctx = Context(local_rank)
     ctx.set_traversal_mode(args.traversal)
+    if args.pipeline >= 0:
+        ctx.set_pipeline(args.pipeline)
     ctx.set_shard(rank, world)
     ctx.upload_scene(flat)
     ctx.upload_camera(cam)
@@ -184,10 +187,12 @@ def main():
             "config": {"workload": preset["note"], "resolution": [W, H], "max_depth": preset["max_depth"], "passes_per_step": RPP,
                        "triangles": int(len(flat.tris)), "instances": int(len(flat.instances)),
                        "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
-                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned"}[ctx.traversal_mode()]},
+                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned"}[ctx.traversal_mode()],
+                       "pipeline": "fused" if args.pipeline == 0 else "trace+shade"},
             "spp_per_s": spp_per_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                         "traffic": traffic, "kernel": "rz_pass_kernel<cumulative>", "avg_launch_us": avg_kernel_s * 1e6,
+                         "traffic": traffic, "kernel": "one pass = rz_trace_kernel + rz_shade_kernel (cumulative)" if args.pipeline != 0 else "rz_pass_kernel (cumulative)",
+                         "avg_launch_us": avg_kernel_s * 1e6,
                          "algorithmic_bytes_per_launch": bytes_per_launch, "segments_per_launch": counters["segments"] / RPP,
                          "box_tests_per_segment": counters["box_tests"] / max(counters["segments"], 1),
                          "tri_tests_per_segment": counters["tri_tests"] / max(counters["segments"], 1)},

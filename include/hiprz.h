@@ -275,6 +275,9 @@ int hiprz_traversal_mode(hiprz_ctx* ctx, int* effective_mode_out); /* valid afte
  * 1 = whenever they fit one workgroup.  Results are identical either way. */
 int hiprz_set_lds_scene(hiprz_ctx* ctx, int mode);
 
+/* 1 (default) = a lean trace kernel followed by a shade kernel, with a 20-byte hit record per pixel passed
+ * through device memory; 0 = one fused pass kernel.  Identical results. */
+int hiprz_set_pipeline(hiprz_ctx* ctx, int pipeline);
 /* Replay the cumulative passes of a render call from a captured hipGraph (default on). */
 int hiprz_set_graph(hiprz_ctx* ctx, int enabled);
 

@@ -110,6 +110,7 @@ ENTRY_POINTS = {
     "hiprz_set_shard": (C.c_int, [P, U32, U32]),
     "hiprz_set_traversal_mode": (C.c_int, [P, C.c_int]),
     "hiprz_set_lds_scene": (C.c_int, [P, C.c_int]),
+    "hiprz_set_pipeline": (C.c_int, [P, C.c_int]),
     "hiprz_traversal_mode": (C.c_int, [P, C.POINTER(C.c_int)]),
     "hiprz_set_graph": (C.c_int, [P, C.c_int]),
     "hiprz_reset": (C.c_int, [P]),

@@ -17,11 +17,17 @@ namespace hiprz {
 
 #define RZ_DEV __device__ __forceinline__
 // experiment knobs (tools/ab_variants.sh builds one library per setting)
-#ifndef RZ_NESTED_SHARED_RCP
-#define RZ_NESTED_SHARED_RCP 0
+#ifndef RZ_FUSED_SHARED_RCP   // packed shared-reciprocal box test in the fused pass kernel's closest-hit walk
+#define RZ_FUSED_SHARED_RCP 0
+#endif
+#ifndef RZ_TRACE_SHARED_RCP   // ... in the split pipeline's trace kernel (lean enough not to spill with it)
+#define RZ_TRACE_SHARED_RCP 1
 #endif
 #ifndef RZ_MIN_WAVES
 #define RZ_MIN_WAVES 4
+#endif
+#ifndef RZ_TRACE_MIN_WAVES
+#define RZ_TRACE_MIN_WAVES 5
 #endif
 #define RZ_PI_F 3.14159265358979323846f
 #define RZ_END 0xFFFFFFFFu
@@ -111,6 +117,8 @@ struct DFrame {
     float4* st1;      // direction.yz, color.rg
     float2* st2;      // color.b, bits(material | depth << 16)
     float4* accum;    // RGBA32F, alpha = finished paths
+    float4* hit0;     // split pipeline: far, b1, b2, bits(triangle)
+    uint32_t* hit1;   // split pipeline: instance | found << 29 | external << 31
     float* depth;     // first-hit distance (first pass)
     uint32_t* rgba8;  // tone-mapped output
     const uint32_t* pass;  // device-resident pass index
@@ -521,6 +529,7 @@ struct LdsStack {
 
 // Instance entry: Transformation::transformG2L (render_parts.cpp:117-125) + the range rescale of
 // cpu_engine_kernel.cpp:307-312 / :442-445 on a prepared ray.  Returns the length factor.
+template <bool RCP>
 RZ_DEV float to_local(const InstanceXform& x, const WalkRay& g, WalkRay& l, bool scene_fast) {
     l.o = transform_backward(x.xa, x.ya, x.za, g.o - x.position) / x.scale;
     l.d = transform_backward(x.xa, x.ya, x.za, g.d) / x.scale;
@@ -528,12 +537,12 @@ RZ_DEV float to_local(const InstanceXform& x, const WalkRay& g, WalkRay& l, bool
     l.near_ = g.near_ * len;
     l.far_ = g.far_ * len;
     l.d = l.d * (1.0f / len);
-    prepare<RZ_NESTED_SHARED_RCP != 0>(l, scene_fast);
+    prepare<RCP>(l, scene_fast);
     return len;
 }
 
 // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352
-template <bool COUNT>
+template <bool COUNT, bool RCP>
 RZ_DEV bool closest_in_mesh_stack(const DScene& s, LdsStack& w, uint32_t root, WalkRay& lr, Hit& hit, Counters& cnt) {
     bool found = false;
     const uint32_t base = w.mark();
@@ -541,7 +550,7 @@ RZ_DEV bool closest_in_mesh_stack(const DScene& s, LdsStack& w, uint32_t root, W
     while (n != RZ_END) {
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
-        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(n0, n1, lr)) {
+        if (box_hit<RCP>(n0, n1, lr)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             if (!(meta & HIPRZ_NODE_LEAF)) {
                 n = w.descend(begin);
@@ -567,18 +576,18 @@ RZ_DEV bool closest_in_mesh_stack(const DScene& s, LdsStack& w, uint32_t root, W
 }
 
 // traverseWorld + closestIntersection(instance): cpu_engine_kernel.cpp:254-330
-template <bool COUNT>
+template <bool COUNT, bool RCP>
 RZ_DEV int closest_hit_stack(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit, Counters& cnt) {
     LdsStack w(lds_column);
     const bool scene_fast = s.fast_div != 0u;
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
-    prepare<RZ_NESTED_SHARED_RCP != 0>(g, scene_fast);
+    prepare<RCP>(g, scene_fast);
     uint32_t n = s.tlas_root;
     while (n != RZ_END) {
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
-        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(n0, n1, g)) {
+        if (box_hit<RCP>(n0, n1, g)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             if (!(meta & HIPRZ_NODE_LEAF)) {
                 n = w.descend(begin);
@@ -590,11 +599,11 @@ RZ_DEV int closest_hit_stack(const DScene& s, uint32_t* lds_column, Ray& ray, Hi
                 float4 ib0, ib1;
                 load_instance_box(s, inst, ib0, ib1);
                 RZ_COUNT(box_tests);
-                if (!box_hit<RZ_NESTED_SHARED_RCP != 0>(ib0, ib1, g)) continue;
+                if (!box_hit<RCP>(ib0, ib1, g)) continue;
                 const InstanceXform x = load_instance_xform(s, inst);
                 WalkRay lr;
-                const float len = to_local(x, g, lr, scene_fast);
-                if (closest_in_mesh_stack<COUNT>(s, w, x.blas_root, lr, hit, cnt)) {
+                const float len = to_local<RCP>(x, g, lr, scene_fast);
+                if (closest_in_mesh_stack<COUNT, RCP>(s, w, x.blas_root, lr, hit, cnt)) {
                     hit.instance = int32_t(inst);
                     g.near_ = lr.near_ / len;
                     g.far_ = lr.far_ / len;
@@ -616,12 +625,12 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
     const bool scene_fast = s.fast_div != 0u;
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
-    prepare<RZ_NESTED_SHARED_RCP != 0>(g, scene_fast);
+    prepare<false>(g, scene_fast);
     uint32_t n = s.tlas_root;
     while (n != RZ_END) {
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
-        if (box_hit<RZ_NESTED_SHARED_RCP != 0>(n0, n1, g)) {
+        if (box_hit<false>(n0, n1, g)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             if (!(meta & HIPRZ_NODE_LEAF)) {
                 n = w.descend(begin);
@@ -633,17 +642,17 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
                 float4 ib0, ib1;
                 load_instance_box(s, inst, ib0, ib1);
                 RZ_COUNT(box_tests);
-                if (!box_hit<RZ_NESTED_SHARED_RCP != 0>(ib0, ib1, g)) continue;
+                if (!box_hit<false>(ib0, ib1, g)) continue;
                 const InstanceXform x = load_instance_xform(s, inst);
                 WalkRay lr;
-                to_local(x, g, lr, scene_fast);
+                to_local<false>(x, g, lr, scene_fast);
                 // anyIntersection(const Mesh&, ...) :450-481
                 const uint32_t base = w.mark();
                 uint32_t m = x.blas_root;
                 while (m != RZ_END) {
                     const float4 m0 = s.nodes[2 * m], m1 = s.nodes[2 * m + 1];
                     RZ_COUNT(box_tests);
-                    if (box_hit<RZ_NESTED_SHARED_RCP != 0>(m0, m1, lr)) {
+                    if (box_hit<false>(m0, m1, lr)) {
                         const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                         if (!(mmeta & HIPRZ_NODE_LEAF)) {
                             m = w.descend(mbegin);
@@ -724,7 +733,7 @@ struct BinnedLds {  // per-workgroup workspace carved from dynamic LDS (256 lane
 
 // Must be called by ALL 256 threads of the workgroup (it contains barriers); `active` = this lane
 // carries a ray.  Returns 0 / 1 / 2 like closest_hit().
-template <bool COUNT>
+template <bool COUNT, bool RCP>
 __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char* workspace, bool active, Ray& ray, Hit& hit,
                                                   Counters& cnt) {
     const uint32_t tid = threadIdx.x;
@@ -743,7 +752,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
     const bool scene_fast = s.fast_div != 0u;
-    prepare<RZ_NESTED_SHARED_RCP != 0>(g, scene_fast);
+    prepare<RCP>(g, scene_fast);
     uint32_t n = active ? s.tlas_root : RZ_END;  // world-tree cursor of this lane's ray
     uint32_t leaf_i = 0, leaf_end = 0;
     bool root_missed = false;
@@ -761,7 +770,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
                 float4 ib0, ib1;
                 load_instance_box(s, inst, ib0, ib1);
                 RZ_COUNT(box_tests);
-                if (box_hit<RZ_NESTED_SHARED_RCP != 0>(ib0, ib1, g)) {
+                if (box_hit<RCP>(ib0, ib1, g)) {
                     cand = inst;
                     break;
                 }
@@ -770,7 +779,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
             if (n == RZ_END) break;
             const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
             RZ_COUNT(box_tests);
-            if (box_hit<RZ_NESTED_SHARED_RCP != 0>(n0, n1, g)) {
+            if (box_hit<RCP>(n0, n1, g)) {
                 const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
                 if (!(meta & HIPRZ_NODE_LEAF)) {
                     n = world.descend(begin);
@@ -821,10 +830,10 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
             w.near_ = lds.ray[6 * 256 + src], w.far_ = lds.ray[7 * 256 + src];
             const InstanceXform x = load_instance_xform(s, inst);
             WalkRay lr;
-            const float len = to_local(x, w, lr, scene_fast);
+            const float len = to_local<RCP>(x, w, lr, scene_fast);
             LdsStack mesh(mesh_column);
             Hit h;
-            if (closest_in_mesh_stack<COUNT>(s, mesh, x.blas_root, lr, h, cnt)) {
+            if (closest_in_mesh_stack<COUNT, RCP>(s, mesh, x.blas_root, lr, h, cnt)) {
                 lds.ray[6 * 256 + src] = lr.near_ / len;
                 lds.ray[7 * 256 + src] = lr.far_ / len;
                 lds.hit[0 * 256 + src] = h.triangle;
@@ -862,7 +871,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
 // Returns 0 = no instances / root box missed (the reference returns before it computes the
 // sky texcrd, cpu_engine_kernel.cpp:282-283), 1 = walked, nothing hit (sky texcrd is computed,
 // :292-295), 2 = hit.
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool RCP>
 RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit, Counters& cnt) {
     hit.instance = -1;
     hit.triangle = 0;
@@ -870,7 +879,7 @@ RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit
     hit.external = true;
     if (s.n_instances == 0) return 0;
     if constexpr (MODE == 0) return walk_threaded<false, COUNT>(s, ray, hit, cnt);
-    else return closest_hit_stack<COUNT>(s, lds_column, ray, hit, cnt);  // MODE 2 calls closest_hit_binned directly
+    else return closest_hit_stack<COUNT, RCP>(s, lds_column, ray, hit, cnt);  // MODE 2 calls closest_hit_binned directly
 }
 // anyIntersection(const RangedRay&): returns the shadow mask's alpha (0 or 1)
 template <int MODE, bool COUNT>

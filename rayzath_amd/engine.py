@@ -79,6 +79,9 @@ class Context:
     def set_traversal_mode(self, mode):
         self._check(self.lib.hiprz_set_traversal_mode(self._ctx, mode))
 
+    def set_pipeline(self, pipeline):
+        self._check(self.lib.hiprz_set_pipeline(self._ctx, pipeline))
+
     def traversal_mode(self):
         v = C.c_int()
         self._check(self.lib.hiprz_traversal_mode(self._ctx, C.byref(v)))

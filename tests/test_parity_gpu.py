@@ -150,6 +150,25 @@ def test_sharded_render_equals_unsharded(built):
     assert rays == full.ray_count() == 5 * 200 * 120
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_split_pipeline_equals_fused(built, mode):
+    """trace kernel + shade kernel (hit record through HBM) == fused pass kernel, incl. lights and counters."""
+    for world, depth in ((scenes.cornell_box(160, 96), 4), (scenes.living_room(96, 64, 16), 5), (scenes.cornell_sphere(128, 72, 32), 6)):
+        flat, cam = flatten(world), camera_struct(world.camera)
+        cfg = RenderConfig(LightSampling(2, 1), Tracing(depth, 4)).struct()
+        out = []
+        for pipeline in (0, 1):
+            c = Context(0)
+            c.set_traversal_mode(mode), c.set_pipeline(pipeline)
+            c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+            counters = c.render_counted(1)
+            c.render(5)
+            out.append((c.read_accum(), c.read_depth(), c.read_state(), counters))
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][3] == out[1][3]
+        for k in out[0][2]:
+            assert np.array_equal(out[0][2][k], out[1][2][k]), k
+
+
 def test_graph_replay_equals_eager_launches(built):
     world = scenes.cornell_box(160, 96)
     flat, cam = flatten(world), camera_struct(world.camera)
