@@ -81,6 +81,16 @@ template <int MODE, bool COUNT, bool RCP>
 RZ_DEV int trace_path(const DScene& s, unsigned char* workspace, uint32_t* lds_column, bool active, Ray& ray, Hit& hit, Counters& cnt) {
     if constexpr (MODE == 2) {
         return closest_hit_binned<COUNT, RCP>(s, workspace, active, ray, hit, cnt);
+    } else if constexpr (MODE == 3) {  // workspace = [top nodes][top links], staged here by the whole workgroup
+        float4* ln = reinterpret_cast<float4*>(workspace);
+        uint32_t* ls = reinterpret_cast<uint32_t*>(workspace + s.top_count * 32u);
+        for (uint32_t i = threadIdx.x; i < 2u * s.top_count; i += 256u) ln[i] = s.nodes[i];
+        for (uint32_t i = threadIdx.x; i < s.top_count; i += 256u) ls[i] = s.node_skip[i];
+        __syncthreads();
+        hit.instance = -1, hit.triangle = 0, hit.bx = hit.by = 0.0f, hit.external = true;
+        if (!active || s.n_instances == 0) return 0;
+        const TopCache top{ln, ls, s.top_count};
+        return closest_hit_skip<COUNT, RCP>(s, top, ray, hit, cnt);
     } else {
         hit.instance = -1, hit.triangle = 0, hit.bx = hit.by = 0.0f, hit.external = true;
         return active ? closest_hit<MODE, COUNT, RCP>(s, lds_column, ray, hit, cnt) : 0;
@@ -454,6 +464,7 @@ struct hiprz_ctx {
     DeviceArray<uint8_t> hot;  // nodes | tlas_order | instances | tris | tri_attrs | materials | inst_materials
     DeviceArray<hiprz_node> wnodes;
     DeviceArray<uint32_t> wskip;
+    DeviceArray<uint32_t> node_skip;
     DeviceArray<hiprz_texture> textures;
     DeviceArray<uint8_t> texels;
     DeviceArray<hiprz_spot_light> spot_lights;
@@ -622,8 +633,11 @@ DConfig make_config(const hiprz_ctx* c) {
 // and the nested walk is faster (config C: 1 668 vs 2 450 us).
 int effective_mode(const hiprz_ctx* c) {
     if (c->traversal_mode >= 0) return c->traversal_mode;
+    if (!c->lds_scene && c->pipeline == 1) return 3;  // records do not fit LDS: skip-link walk + cached tree tops
     return c->dscene.mesh_stack_entries <= 2u ? 2 : 1;
 }
+
+constexpr uint32_t kTopCacheNodes = 682u;  // 682 x 36 B = 24 KiB per workgroup: ~9 levels of every tree, 5 workgroups per CU
 
 constexpr size_t kLdsSceneLimit = 52u * 1024u;  // per workgroup: 3 x 52 KiB < 160 KiB per CU
 
@@ -639,7 +653,8 @@ void launch_pass(hiprz_ctx* c, const DFrame& f) {
     const DConfig cfg = make_config(c);
     const bool lds_scene = use_lds_scene(c);
     const size_t blob = lds_scene ? c->dscene.hot_bytes : 0u;
-    const int mode = effective_mode(c);
+    int mode = effective_mode(c);
+    if (mode == 3 && (lds_scene || c->pipeline != 1)) mode = 1;  // the top cache is for scenes that are not staged whole, in the trace kernel
     const size_t stack_lds = size_t(c->stack_entries) * 256u * sizeof(uint32_t);
     const size_t walk_lds = mode == 2 ? size_t(BinnedLds::bytes_host(c->dscene.world_stack_entries, c->dscene.mesh_stack_entries))
                             : mode == 1 ? stack_lds : 0u;
@@ -649,7 +664,8 @@ void launch_pass(hiprz_ctx* c, const DFrame& f) {
         else hipLaunchKernelGGL(kernel_global, grid, block, (lds_bytes), c->stream, __VA_ARGS__);                   \
     } while (0)
     if (c->pipeline == 1) {
-        if (mode == 2) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 2, true>), (rz_trace_kernel<FIRST, COUNT, 2, false>), walk_lds, c->dscene, c->dcamera, f);
+        if (mode == 3) hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 3, false>), grid, block, TopCache::bytes_host(c->dscene.top_count), c->stream, c->dscene, c->dcamera, f);
+        else if (mode == 2) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 2, true>), (rz_trace_kernel<FIRST, COUNT, 2, false>), walk_lds, c->dscene, c->dcamera, f);
         else if (mode == 1) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 1, true>), (rz_trace_kernel<FIRST, COUNT, 1, false>), walk_lds, c->dscene, c->dcamera, f);
         else RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 0, true>), (rz_trace_kernel<FIRST, COUNT, 0, false>), walk_lds, c->dscene, c->dcamera, f);
         RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, true>), (rz_shade_kernel<FIRST, COUNT, false>), stack_lds, c->dscene, c->dcamera, cfg, f);
@@ -836,13 +852,122 @@ int check_scene(const hiprz_scene* sc, SceneCheck& out) {
     return HIPRZ_OK;
 }
 
+// Device-side tables derived from a validated scene (pure host): relayouted nodes + links, walk graph.
+struct DerivedTables {
+    std::vector<uint32_t> new_index;
+    std::vector<hiprz_node> dnodes, wnodes;
+    std::vector<uint32_t> dskip, wskip;
+};
+int derive_tables(const hiprz_scene* sc, SceneCheck& chk, DerivedTables& out) {
+    // Relayout: breadth-first over ALL trees at once (world root, then every distinct mesh root, then their child
+    // pairs, ...), children staying adjacent.  The levels nearest the roots become a prefix of the array (the part
+    // MODE 3 caches in LDS) and siblings/cousins share cache lines.  Leaf ranges are untouched.
+    std::vector<uint32_t>& new_index = out.new_index;
+    new_index.assign(sc->n_nodes, RZ_END);
+    std::vector<uint32_t> bfs;
+    bfs.reserve(sc->n_nodes);
+    auto enqueue = [&](uint32_t old) {
+        if (old < sc->n_nodes && new_index[old] == RZ_END) {
+            new_index[old] = uint32_t(bfs.size());
+            bfs.push_back(old);
+        }
+    };
+    if (sc->n_instances) enqueue(sc->tlas_root);
+    for (uint32_t i = 0; i < sc->n_tlas_order; ++i) enqueue(sc->instances[sc->tlas_order[i]].blas_root);
+    for (size_t q = 0; q < bfs.size(); ++q) {
+        const hiprz_node& n = sc->nodes[bfs[q]];
+        if (!(n.meta & HIPRZ_NODE_LEAF)) enqueue(n.begin), enqueue(n.begin + 1);
+    }
+    for (uint32_t old = 0; old < sc->n_nodes; ++old) enqueue(old);  // nodes no instance reaches keep a slot
+    std::vector<hiprz_node>& dnodes = out.dnodes;
+    std::vector<uint32_t>& dskip = out.dskip;
+    dnodes.assign(sc->n_nodes, hiprz_node{});
+    dskip.assign(sc->n_nodes ? sc->n_nodes : 1, RZ_END);
+    for (uint32_t old = 0; old < sc->n_nodes; ++old) {
+        hiprz_node n = sc->nodes[old];
+        if (!(n.meta & HIPRZ_NODE_LEAF)) n.begin = new_index[n.begin];
+        dnodes[new_index[old]] = n;
+        dskip[new_index[old]] = chk.skip[old] == RZ_END ? RZ_END : new_index[chk.skip[old]];
+    }
+
+    // ---- walk graph of the threaded traversal (hiprz_device.hpp: walk_threaded), in the relayouted numbering ----
+    // every world-tree leaf becomes a CHAIN node whose `begin` points at a run of INSTANCE pseudo-nodes
+    // (box = instance box, begin = instance id) appended after the real nodes and linked by skip; the last one
+    // links to whatever follows the leaf.
+    std::vector<hiprz_node>& wnodes = out.wnodes;
+    std::vector<uint32_t>& wskip = out.wskip;
+    wnodes = dnodes;
+    wskip.assign(dskip.begin(), dskip.begin() + sc->n_nodes);
+    for (auto& n : wnodes) {
+        const bool leaf = (n.meta & HIPRZ_NODE_LEAF) != 0;
+        n.meta = ((leaf ? RZ_WALK_TRIS : RZ_WALK_INNER) << RZ_WALK_TYPE_SHIFT) | (leaf ? (n.meta & HIPRZ_NODE_COUNT_MASK) : 0u);
+    }
+    for (uint32_t old_leaf : chk.world_leaves) {
+        const uint32_t leaf = new_index[old_leaf];
+        const hiprz_node src = dnodes[leaf];
+        const uint32_t count = src.meta & HIPRZ_NODE_COUNT_MASK;
+        if (count == 0) continue;  // stays an empty TRIS leaf: box test, then follow the link
+        const uint32_t chain = uint32_t(wnodes.size());
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t inst = sc->tlas_order[src.begin + k];
+            hiprz_node p{};
+            std::memcpy(p.bb_min, sc->instances[inst].bb_min, 12);
+            std::memcpy(p.bb_max, sc->instances[inst].bb_max, 12);
+            p.begin = inst;
+            p.meta = RZ_WALK_INSTANCE << RZ_WALK_TYPE_SHIFT;
+            wnodes.push_back(p);
+            wskip.push_back(k + 1 < count ? chain + k + 1 : wskip[leaf]);
+        }
+        wnodes[leaf].begin = chain;
+        wnodes[leaf].meta = (RZ_WALK_CHAIN << RZ_WALK_TYPE_SHIFT) | count;
+    }
+    // The kernels follow these derived tables blindly: prove on the host that every walk over them terminates
+    // (each step moves strictly forward in depth-first order, so a walk may take at most one step per node).
+    {
+        auto terminates = [](const std::vector<hiprz_node>& nodes, const std::vector<uint32_t>& links, uint32_t root, bool walk_graph) {
+            uint32_t n = root;
+            for (size_t steps = 0; steps <= nodes.size(); ++steps) {
+                if (n == RZ_END) return true;
+                if (n >= nodes.size()) return false;
+                const hiprz_node& nd = nodes[n];
+                bool descend;
+                if (walk_graph) {
+                    const uint32_t type = nd.meta >> RZ_WALK_TYPE_SHIFT;
+                    descend = type == RZ_WALK_INNER || type == RZ_WALK_CHAIN;
+                } else {
+                    descend = !(nd.meta & HIPRZ_NODE_LEAF);
+                }
+                n = descend ? nd.begin : links[n];
+            }
+            return false;
+        };
+        bool ok = true;
+        for (uint32_t old = 0; ok && old < sc->n_nodes; ++old)  // the stack walks reach the second child as first + 1
+            if (!(sc->nodes[old].meta & HIPRZ_NODE_LEAF)) ok = new_index[sc->nodes[old].begin + 1] == new_index[sc->nodes[old].begin] + 1u;
+        if (ok && sc->n_instances) ok = terminates(dnodes, dskip, new_index[sc->tlas_root], false) && terminates(wnodes, wskip, new_index[sc->tlas_root], true);
+        for (uint32_t i = 0; ok && i < sc->n_tlas_order; ++i) {
+            const uint32_t root = new_index[sc->instances[sc->tlas_order[i]].blas_root];
+            ok = terminates(dnodes, dskip, root, false) && terminates(wnodes, wskip, root, true);
+        }
+        if (!ok) {
+            chk.error = "internal: derived walk tables are inconsistent (refusing to launch)";
+            return HIPRZ_ERR_INVALID;
+        }
+    }
+    return HIPRZ_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 int hiprz_validate_scene(const hiprz_scene* scene, char* message, size_t len) {
     SceneCheck chk;
-    const int rc = check_scene(scene, chk);
+    int rc = check_scene(scene, chk);
+    if (rc == HIPRZ_OK) {  // also prove that the tables the kernels will follow can be derived and terminate
+        DerivedTables derived;
+        rc = derive_tables(scene, chk, derived);
+    }
     if (message && len) std::snprintf(message, len, "%s", chk.error.c_str());
     return rc;
 }
@@ -888,7 +1013,7 @@ int hiprz_destroy(hiprz_ctx* c) {
         (void)hipEventDestroy(p.second);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
-    c->hot.release(), c->wnodes.release(), c->wskip.release(), c->textures.release();
+    c->hot.release(), c->wnodes.release(), c->wskip.release(), c->node_skip.release(), c->textures.release();
     c->texels.release(), c->spot_lights.release(), c->direct_lights.release();
     release_frame(c);
     c->pass_dev.release(), c->counters_dev.release(), c->pick_dev.release();
@@ -914,33 +1039,13 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     c->dscene.world_stack_entries = world_depth + 1u;
     c->dscene.mesh_stack_entries = mesh_depth + 1u;
 
-    // ---- walk graph of the threaded traversal (hiprz_device.hpp: walk_threaded) ----
-    // nodes keep their index; every world-tree leaf becomes a CHAIN node whose `begin` points at a
-    // run of INSTANCE pseudo-nodes (box = instance box, begin = instance id) appended after the real
-    // nodes and linked by skip; the last one links to whatever follows the leaf.
-    std::vector<hiprz_node> wnodes(sc->nodes, sc->nodes + sc->n_nodes);
-    for (auto& n : wnodes) {
-        const bool leaf = (n.meta & HIPRZ_NODE_LEAF) != 0;
-        n.meta = ((leaf ? RZ_WALK_TRIS : RZ_WALK_INNER) << RZ_WALK_TYPE_SHIFT) | (leaf ? (n.meta & HIPRZ_NODE_COUNT_MASK) : 0u);
-    }
-    for (uint32_t leaf : check.world_leaves) {
-        const hiprz_node src = sc->nodes[leaf];
-        const uint32_t count = src.meta & HIPRZ_NODE_COUNT_MASK;
-        if (count == 0) continue;  // stays an empty TRIS leaf: box test, then follow the link
-        const uint32_t chain = uint32_t(wnodes.size());
-        for (uint32_t k = 0; k < count; ++k) {
-            const uint32_t inst = sc->tlas_order[src.begin + k];
-            hiprz_node p{};
-            std::memcpy(p.bb_min, sc->instances[inst].bb_min, 12);
-            std::memcpy(p.bb_max, sc->instances[inst].bb_max, 12);
-            p.begin = inst;
-            p.meta = RZ_WALK_INSTANCE << RZ_WALK_TYPE_SHIFT;
-            wnodes.push_back(p);
-            skip.push_back(k + 1 < count ? chain + k + 1 : skip[leaf]);
-        }
-        wnodes[leaf].begin = chain;
-        wnodes[leaf].meta = (RZ_WALK_CHAIN << RZ_WALK_TYPE_SHIFT) | count;
-    }
+    DerivedTables derived;
+    if (derive_tables(sc, chk, derived) != HIPRZ_OK) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: " + chk.error);
+    std::vector<uint32_t>& new_index = derived.new_index;
+    std::vector<hiprz_node>& dnodes = derived.dnodes;
+    std::vector<hiprz_node>& wnodes = derived.wnodes;
+    std::vector<uint32_t>& dskip = derived.dskip;
+    std::vector<uint32_t>& wskip = derived.wskip;
     // shared-reciprocal division is exact only for coordinates that are 0 or in [2^-60, 2^40)
     auto coord_ok = [](float x) {
         uint32_t b;
@@ -968,11 +1073,11 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
         const float v[6] = {mn[0], mx[0], mn[1], mx[1], mn[2], mx[2]};
         mn[0] = v[0], mn[1] = v[1], mn[2] = v[2], mx[0] = v[3], mx[1] = v[4], mx[2] = v[5];
     };
-    std::vector<hiprz_node> dnodes(sc->nodes, sc->nodes + sc->n_nodes);
     for (auto& n : dnodes) interleave(n.bb_min, n.bb_max);  // bb_min[3] and bb_max[3] are contiguous
     for (auto& n : wnodes) interleave(n.bb_min, n.bb_max);
     std::vector<hiprz_instance> dinstances(sc->instances, sc->instances + sc->n_instances);
     for (auto& in : dinstances) {
+        if (in.blas_root < sc->n_nodes) in.blas_root = new_index[in.blas_root];
         const float v[6] = {in.bb_min[0], in.bb_max[0], in.bb_min[1], in.bb_max[1], in.bb_min[2], in.bb_max[2]};
         in.bb_min[0] = v[0], in.bb_min[1] = v[1], in.bb_min[2] = v[2];
         std::memcpy(&in.pad2, &v[3], 4);
@@ -989,8 +1094,9 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     d.hot_bytes = uint32_t(blob.size());
 
     RZ_HIP(c, c->hot.assign(blob.data(), blob.size(), c->stream));
+    RZ_HIP(c, c->node_skip.assign(dskip.data(), dskip.size(), c->stream));
     RZ_HIP(c, c->wnodes.assign(wnodes.data(), wnodes.size(), c->stream));
-    RZ_HIP(c, c->wskip.assign(skip.data(), wnodes.size(), c->stream));
+    RZ_HIP(c, c->wskip.assign(wskip.data(), wskip.size(), c->stream));
     RZ_HIP(c, c->textures.assign(sc->textures, sc->n_textures, c->stream));
     RZ_HIP(c, c->texels.assign(sc->texels, sc->texel_bytes, c->stream));
     RZ_HIP(c, c->spot_lights.assign(sc->spot_lights, sc->n_spot_lights, c->stream));
@@ -1013,7 +1119,9 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     d.spot_lights = reinterpret_cast<const float4*>(c->spot_lights.ptr);
     d.direct_lights = reinterpret_cast<const float4*>(c->direct_lights.ptr);
     d.n_instances = sc->n_instances;
-    d.tlas_root = sc->tlas_root;
+    d.tlas_root = sc->n_instances ? new_index[sc->tlas_root] : 0u;
+    d.node_skip = c->node_skip.ptr;
+    d.top_count = std::min<uint32_t>(sc->n_nodes, kTopCacheNodes);
     d.n_spot_lights = sc->n_spot_lights;
     d.n_direct_lights = sc->n_direct_lights;
     // Stage the blob in LDS when three workgroups per CU (the kernel's register-limited residency)
@@ -1085,7 +1193,7 @@ int hiprz_set_shard(hiprz_ctx* c, uint32_t rank, uint32_t world) {
 int hiprz_set_traversal_mode(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
     c->graph_valid = false;
-    if (mode < -1 || mode > 2) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: -1 = auto, 0 = threaded, 1 = LDS stack, 2 = workgroup-binned");
+    if (mode < -1 || mode > 3) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: -1 = auto, 0 = threaded, 1 = LDS stack, 2 = workgroup-binned, 3 = skip links + LDS-cached tree tops");
     c->traversal_mode = mode;
     return HIPRZ_OK;
 }

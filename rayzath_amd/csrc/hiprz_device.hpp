@@ -31,6 +31,19 @@ namespace hiprz {
 #endif
 #define RZ_PI_F 3.14159265358979323846f
 #define RZ_END 0xFFFFFFFFu
+// Termination of every walk is proven on the host before anything is launched (hiprz_api.hip: check_scene walks the
+// uploaded trees, derive_tables walks the derived links), so the loops need no step budget.  -DRZ_WALK_GUARD=1 adds
+// one anyway (debug builds: a wrong table then gives wrong pixels instead of a hung wave); it costs 9 % on config B.
+#define RZ_GUARD_LIMIT (1u << 26)
+#ifndef RZ_WALK_GUARD
+#define RZ_WALK_GUARD 0
+#endif
+#if RZ_WALK_GUARD
+#define RZ_GUARD(counter) \
+    if (++(counter) > RZ_GUARD_LIMIT) break
+#else
+#define RZ_GUARD(counter) (void)(counter)
+#endif
 #define RZ_FLT_MAX 3.402823466e+38f
 
 #ifdef HIPRZ_PORTABLE_MATH
@@ -83,7 +96,9 @@ struct DScene {
     const float4* hot;  // start of the blob
     uint32_t off_nodes, off_tlas_order, off_instances, off_tris, off_tri_attrs, off_materials, off_inst_materials;
     uint32_t world_stack_entries;  // LDS stack entries per lane the world tree needs / the deepest mesh tree needs
-    uint32_t mesh_stack_entries, pad1;
+    uint32_t mesh_stack_entries;
+    uint32_t top_count;            // MODE 3: the first top_count nodes (+ their links) are staged in LDS by every workgroup
+    const uint32_t* node_skip;     // link to the node that follows a node's subtree (same numbering as `nodes`)
 };
 
 // Re-point the blob sections at a staged copy (LDS).
@@ -433,8 +448,9 @@ RZ_DEV int walk_threaded(const DScene& s, Ray& ray, Hit& hit, Counters& cnt) {
     uint32_t ret = RZ_END, inst = 0u;
     bool in_mesh = false, found_here = false, root_missed = false;
 
-    uint32_t n = s.tlas_root;
+    uint32_t n = s.tlas_root, guard = 0u;
     while (true) {
+        RZ_GUARD(guard);
         if (n == RZ_END) {
             if (!in_mesh) break;
             // leave the instance: cpu_engine_kernel.cpp:320-329
@@ -546,8 +562,9 @@ template <bool COUNT, bool RCP>
 RZ_DEV bool closest_in_mesh_stack(const DScene& s, LdsStack& w, uint32_t root, WalkRay& lr, Hit& hit, Counters& cnt) {
     bool found = false;
     const uint32_t base = w.mark();
-    uint32_t n = root;
+    uint32_t n = root, guard = 0u;
     while (n != RZ_END) {
+        RZ_GUARD(guard);
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
         if (box_hit<RCP>(n0, n1, lr)) {
@@ -583,8 +600,9 @@ RZ_DEV int closest_hit_stack(const DScene& s, uint32_t* lds_column, Ray& ray, Hi
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
     prepare<RCP>(g, scene_fast);
-    uint32_t n = s.tlas_root;
+    uint32_t n = s.tlas_root, guard = 0u;
     while (n != RZ_END) {
+        RZ_GUARD(guard);
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
         if (box_hit<RCP>(n0, n1, g)) {
@@ -626,8 +644,9 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
     prepare<false>(g, scene_fast);
-    uint32_t n = s.tlas_root;
+    uint32_t n = s.tlas_root, guard = 0u;
     while (n != RZ_END) {
+        RZ_GUARD(guard);
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
         if (box_hit<false>(n0, n1, g)) {
@@ -650,6 +669,7 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
                 const uint32_t base = w.mark();
                 uint32_t m = x.blas_root;
                 while (m != RZ_END) {
+                    RZ_GUARD(guard);
                     const float4 m0 = s.nodes[2 * m], m1 = s.nodes[2 * m + 1];
                     RZ_COUNT(box_tests);
                     if (box_hit<false>(m0, m1, lr)) {
@@ -761,10 +781,12 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
     __syncthreads();
     RZ_STAMP_BEGIN();
 
-    while (true) {
+    uint32_t guard = 0u;
+    while (round < (1u << 20)) {  // workgroup-uniform bound: a ray enters each instance at most once
         // A. advance this ray to its next candidate instance (traverseWorld, cpu_engine_kernel.cpp:254-277, 305)
         uint32_t cand = RZ_BIN_NONE;
         while (true) {
+            RZ_GUARD(guard);
             if (leaf_i < leaf_end) {
                 const uint32_t inst = s.tlas_order[leaf_i++];
                 float4 ib0, ib1;
@@ -865,6 +887,100 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
         hit.by = __uint_as_float(lds.hit[3 * 256 + tid]);
     }
     if (root_missed) return 0;
+    return hit.instance >= 0 ? 2 : 1;
+}
+
+
+// ---- MODE 3: nested walk on skip links with the top of every tree cached in LDS ----
+// For scenes whose records do not fit LDS (configs C, D) a segment is a chain of ~60-90 dependent node
+// fetches served by L2.  The device copy of the nodes is laid out breadth-first over ALL trees
+// (hiprz_api.hip: relayout), so the levels nearest the roots — the ones every ray visits — form a prefix;
+// each workgroup stages that prefix (nodes + links) into LDS.  Following skip links instead of popping a
+// stack means the walk needs no LDS stack at all, which is what frees the space for the cache.
+struct TopCache {
+    const float4* nodes;   // LDS: top_count x 2 float4
+    const uint32_t* skip;  // LDS: top_count
+    uint32_t count;
+    static __host__ uint32_t bytes_host(uint32_t top_count) { return top_count * 36u; }
+};
+RZ_DEV void fetch_node(const DScene& s, const TopCache& top, uint32_t n, float4& n0, float4& n1, uint32_t& link) {
+    if (n < top.count) {
+        n0 = top.nodes[2 * n], n1 = top.nodes[2 * n + 1], link = top.skip[n];
+    } else {
+        n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1], link = s.node_skip[n];
+    }
+}
+template <bool COUNT, bool RCP>
+RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit& hit, Counters& cnt) {
+    const bool scene_fast = s.fast_div != 0u;
+    WalkRay g;
+    g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
+    prepare<RCP>(g, scene_fast);
+    uint32_t n = s.tlas_root, guard = 0u;
+    while (n != RZ_END) {
+        RZ_GUARD(guard);
+        float4 n0, n1;
+        uint32_t link;
+        fetch_node(s, top, n, n0, n1, link);
+        RZ_COUNT(box_tests);
+        if (box_hit<RCP>(n0, n1, g)) {
+            const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+            if (!(meta & HIPRZ_NODE_LEAF)) {
+                n = begin;
+                continue;
+            }
+            const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
+            for (uint32_t i = begin; i < end; ++i) {
+                const uint32_t inst = s.tlas_order[i];
+                float4 ib0, ib1;
+                load_instance_box(s, inst, ib0, ib1);
+                RZ_COUNT(box_tests);
+                if (!box_hit<RCP>(ib0, ib1, g)) continue;
+                const InstanceXform x = load_instance_xform(s, inst);
+                WalkRay lr;
+                const float len = to_local<RCP>(x, g, lr, scene_fast);
+                bool found = false;
+                uint32_t m = x.blas_root;
+                while (m != RZ_END) {  // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352
+                    RZ_GUARD(guard);
+                    float4 m0, m1;
+                    uint32_t mlink;
+                    fetch_node(s, top, m, m0, m1, mlink);
+                    RZ_COUNT(box_tests);
+                    if (box_hit<RCP>(m0, m1, lr)) {
+                        const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
+                        if (!(mmeta & HIPRZ_NODE_LEAF)) {
+                            m = mbegin;
+                            continue;
+                        }
+                        const uint32_t mend = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
+                        for (uint32_t j = mbegin; j < mend; ++j) {
+                            const float4 a = s.tris[3 * j], b = s.tris[3 * j + 1], c = s.tris[3 * j + 2];
+                            float t, b1, b2, det;
+                            RZ_COUNT(tri_tests);
+                            if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
+                                lr.far_ = t;
+                                hit.triangle = j;
+                                hit.external = det > 0.0f;
+                                hit.bx = b1, hit.by = b2;
+                                found = true;
+                            }
+                        }
+                    }
+                    m = mlink;
+                }
+                if (found) {
+                    hit.instance = int32_t(inst);
+                    g.near_ = lr.near_ / len;
+                    g.far_ = lr.far_ / len;
+                }
+            }
+        } else if (n == s.tlas_root) {
+            return 0;  // root box missed (cpu_engine_kernel.cpp:283)
+        }
+        n = link;
+    }
+    ray.near_ = g.near_, ray.far_ = g.far_;
     return hit.instance >= 0 ? 2 : 1;
 }
 
