@@ -278,6 +278,10 @@ int hiprz_set_lds_scene(hiprz_ctx* ctx, int mode);
 /* 1 (default) = a lean trace kernel followed by a shade kernel, with a 20-byte hit record per pixel passed
  * through device memory; 0 = one fused pass kernel.  Identical results. */
 int hiprz_set_pipeline(hiprz_ctx* ctx, int pipeline);
+/* XCD-aware workgroup -> tile mapping of the pass kernels (default off — it unbalances scenes whose cost is
+ * concentrated in one image region): each of the 8 XCDs works through one
+ * contiguous band of the owned tiles, so its L2 holds that band's part of the trees.  Execution order only. */
+int hiprz_set_xcd_swizzle(hiprz_ctx* ctx, int enabled);
 /* Replay the cumulative passes of a render call from a captured hipGraph (default on). */
 int hiprz_set_graph(hiprz_ctx* ctx, int enabled);
 

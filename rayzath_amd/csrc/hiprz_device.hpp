@@ -141,6 +141,7 @@ struct DFrame {
     uint32_t tiles_x;      // 32x8-pixel tiles per row
     uint32_t rank, world;  // tile sharding
     uint32_t n_local_tiles;
+    uint32_t xcd_swizzle;  // 1: workgroup b works on owned tile (b % 8) * ceil(n/8) + b / 8 (see pixel_of_thread)
 };
 
 struct v3 {
@@ -402,8 +403,21 @@ RZ_DEV float vmax3(float a, float b, float c) {
 }
 // BoundingBox::rayIntersection (render_parts.cpp:197-217) on a prepared ray.  The box comes as the
 // device stores it: b0 = (min.x, max.x, min.y, max.y), b1.xy = (min.z, max.z).
+#ifdef RZ_BOXPATH_STATS  // diagnostic build: how many wave-level box tests take the packed path
+__device__ unsigned long long rz_boxpath[4];
+#endif
 template <bool SHARED_RCP>
 RZ_DEV bool box_hit(float4 b0, float4 b1, const WalkRay& r) {
+#ifdef RZ_BOXPATH_STATS
+    if (SHARED_RCP) {
+        const unsigned long long active = __ballot(1), fast = __ballot(r.fast);
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {
+            atomicAdd(&rz_boxpath[fast == active ? 0 : 1], 1ull);
+            atomicAdd(&rz_boxpath[2], (unsigned long long)__popcll(active));
+            atomicAdd(&rz_boxpath[3], (unsigned long long)__popcll(active & ~fast));
+        }
+    }
+#endif
 #ifdef RZ_EXP_FORCE_FAST
     if (SHARED_RCP) {
 #else
@@ -1407,14 +1421,23 @@ struct PixelId {
     bool active;
 };
 RZ_DEV PixelId pixel_of_thread(const DFrame& f, const DCamera& c, uint32_t block, uint32_t tid) {
-    const uint32_t tile = block * f.world + f.rank;
+    // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, MI355X_MICROARCH.md), each with its
+    // own 4 MiB L2.  With the swizzle, XCD k works through the k-th contiguous eighth of the owned tiles — one band of
+    // the image — so the tree nodes its rays visit are shared within ONE L2 instead of being replicated in all eight.
+    // Only the execution order changes: storage stays indexed by the owned-tile number.
+    uint32_t lt = block;
+    if (f.xcd_swizzle) {
+        const uint32_t per_xcd = (f.n_local_tiles + 7u) >> 3;
+        lt = (block & 7u) * per_xcd + (block >> 3);
+    }
+    const uint32_t tile = lt * f.world + f.rank;
     const uint32_t tx = tile % f.tiles_x, ty = tile / f.tiles_x;
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     PixelId p;
     p.x = tx * 32u + wave * 8u + (lane & 7u);
     p.y = ty * 8u + (lane >> 3);
-    p.local = block * 256u + tid;
-    p.active = p.x < c.width && p.y < c.height;
+    p.local = lt * 256u + tid;
+    p.active = lt < f.n_local_tiles && p.x < c.width && p.y < c.height;
     return p;
 }
 
