@@ -375,6 +375,11 @@ __global__ void __launch_bounds__(256) rz_selftest_div_kernel(uint32_t n_per_thr
         if (__float_as_uint(fast.x) != __float_as_uint(exact) && !(fast.x == 0.0f && exact == 0.0f)) bad += 1;
         if (__float_as_uint(fast.y) != __float_as_uint(exact2) && !(fast.y == 0.0f && exact2 == 0.0f)) bad += 1;
         if (__float_as_uint(div_shared(n, d, y)) != __float_as_uint(fast.x)) bad += 1;
+        // sincosf must return what sinf and cosf return: the samplers' angles are in [0, 2*pi], test a wider range
+        const float angle = __uint_as_float((g & 0x80000000u) | ((118u + (h >> 11) % 16u) << 23) | (mix32(h + 3u) & 0x7FFFFFu));
+        float sn, cs;
+        sincosf(angle, &sn, &cs);
+        if (__float_as_uint(sn) != __float_as_uint(sinf(angle)) || __float_as_uint(cs) != __float_as_uint(cosf(angle))) bad += 1;
     }
     atomicAdd(&out[0], (unsigned long long)bad);
     atomicAdd(&out[1], (unsigned long long)tested);
@@ -1033,10 +1038,6 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     StageTimer timer;
     SceneCheck chk;
     if (check_scene(sc, chk) != HIPRZ_OK) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: " + chk.error);
-    std::vector<uint32_t>& skip = chk.skip;
-    struct {
-        std::vector<uint32_t>& world_leaves;
-    } check{chk.world_leaves};
     const uint32_t world_depth = chk.world_depth, mesh_depth = chk.mesh_depth;
     c->stack_entries = world_depth + mesh_depth + 2u;
     c->dscene.world_stack_entries = world_depth + 1u;
@@ -1081,6 +1082,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     std::vector<hiprz_instance> dinstances(sc->instances, sc->instances + sc->n_instances);
     for (auto& in : dinstances) {
         if (in.blas_root < sc->n_nodes) in.blas_root = new_index[in.blas_root];
+        in.pad0 = (in.scale[0] == 1.0f && in.scale[1] == 1.0f && in.scale[2] == 1.0f) ? 1u : 0u;  // x / 1.0f == x: the walk skips it
         const float v[6] = {in.bb_min[0], in.bb_max[0], in.bb_min[1], in.bb_max[1], in.bb_min[2], in.bb_max[2]};
         in.bb_min[0] = v[0], in.bb_min[1] = v[1], in.bb_min[2] = v[2];
         std::memcpy(&in.pad2, &v[3], 4);
@@ -1089,8 +1091,22 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     d.off_nodes = append(dnodes.data(), sizeof(hiprz_node) * dnodes.size());
     d.off_tlas_order = append(sc->tlas_order, sizeof(uint32_t) * sc->n_tlas_order);
     d.off_instances = append(dinstances.data(), sizeof(hiprz_instance) * dinstances.size());
-    d.off_tris = append(sc->tris, sizeof(hiprz_tri) * sc->n_tris);
-    d.off_tri_attrs = append(sc->tri_attrs, sizeof(hiprz_tri_attr) * sc->n_tris);
+    // device triangles hold v1 and the edges v2 - v1, v3 - v1; v2 and v3 themselves (normal mapping only) move into
+    // the padding words of the attribute record
+    std::vector<hiprz_tri> dtris(sc->tris, sc->tris + sc->n_tris);
+    std::vector<hiprz_tri_attr> dattrs(sc->tri_attrs, sc->tri_attrs + sc->n_tris);
+    for (uint32_t i = 0; i < sc->n_tris; ++i) {
+        hiprz_tri& t = dtris[i];
+        hiprz_tri_attr& a = dattrs[i];
+        a.pad0 = t.v2[0], a.pad1 = t.v2[1], a.pad2 = t.v2[2], a.pad3 = t.v3[0], a.pad4[0] = t.v3[1], a.pad4[1] = t.v3[2];
+        for (int k = 0; k < 3; ++k) {
+            const float v2 = t.v2[k], v3 = t.v3[k];
+            t.v2[k] = v2 - t.v1[k];
+            t.v3[k] = v3 - t.v1[k];
+        }
+    }
+    d.off_tris = append(dtris.data(), sizeof(hiprz_tri) * dtris.size());
+    d.off_tri_attrs = append(dattrs.data(), sizeof(hiprz_tri_attr) * dattrs.size());
     d.off_materials = append(sc->materials, sizeof(hiprz_material) * sc->n_materials);
     d.off_inst_materials = append(sc->inst_materials, sizeof(int32_t) * sc->n_inst_materials);
     if (blob.size() > 0xFFFFFFF0ull) return fail(c, HIPRZ_ERR_INVALID, "scene geometry exceeds 4 GiB");

@@ -50,6 +50,7 @@ namespace hiprz {
 #include "hiprz_portable_math.h"
 #define RZ_SINF(x) hiprz_pm_sinf(x)
 #define RZ_COSF(x) hiprz_pm_cosf(x)
+#define RZ_SINCOSF(x, s, c) ((s) = hiprz_pm_sinf(x), (c) = hiprz_pm_cosf(x))
 #define RZ_ACOSF(x) hiprz_pm_acosf(x)
 #define RZ_ASINF(x) hiprz_pm_asinf(x)
 #define RZ_ATAN2F(y, x) hiprz_pm_atan2f(y, x)
@@ -58,6 +59,9 @@ namespace hiprz {
 #else
 #define RZ_SINF(x) sinf(x)
 #define RZ_COSF(x) cosf(x)
+// sine and cosine of one angle with ONE argument reduction; ocml's sincosf returns bit-for-bit what sinf and cosf
+// return separately (checked on the device by hiprz_selftest)
+#define RZ_SINCOSF(x, s, c) sincosf((x), &(s), &(c))
 #define RZ_ACOSF(x) acosf(x)
 #define RZ_ASINF(x) asinf(x)
 #define RZ_ATAN2F(y, x) atan2f(y, x)
@@ -237,9 +241,9 @@ RZ_DEV bool box_hit(v3 mn, v3 mx, const Ray& r) {
 }
 
 // --- Moller-Trumbore: mesh_component.cpp:52-114 -----------------------------------------
-RZ_DEV bool tri_hit(v3 v1, v3 v2, v3 vv3, const Ray& r, float& t_out, float& b1_out, float& b2_out, float& det_out) {
-    const v3 edge1 = v2 - v1;
-    const v3 edge2 = vv3 - v1;
+// The device triangle record carries v1 and the two edges v2 - v1, v3 - v1 (computed on upload with the same fp32
+// subtraction the reference performs per test, mesh_component.cpp:56-57).
+RZ_DEV bool tri_hit(v3 v1, v3 edge1, v3 edge2, const Ray& r, float& t_out, float& b1_out, float& b2_out, float& det_out) {
     const v3 pvec = cross(r.d, edge2);
     float det = dot(edge1, pvec);
     det += float(uint32_t(det > -1.0e-7f) & uint32_t(det < 1.0e-7f)) * 1.0e-7f;
@@ -268,6 +272,7 @@ RZ_DEV void load_instance_box(const DScene& s, uint32_t i, float4& b0, float4& b
 struct InstanceXform {
     v3 position, scale, xa, ya, za;
     uint32_t blas_root;
+    bool unit_scale;  // scale == (1,1,1): dividing by it is the identity and is skipped
 };
 RZ_DEV InstanceXform load_instance_xform(const DScene& s, uint32_t i) {
     const float4 a = s.instances[7 * i + 0], b = s.instances[7 * i + 1], c = s.instances[7 * i + 2],
@@ -275,6 +280,7 @@ RZ_DEV InstanceXform load_instance_xform(const DScene& s, uint32_t i) {
     InstanceXform x;
     x.position = xyz(a), x.blas_root = __float_as_uint(a.w);
     x.scale = xyz(b);
+    x.unit_scale = __float_as_uint(d.w) != 0u;  // pad0 of the device copy (set on upload)
     x.xa = xyz(c), x.ya = xyz(d), x.za = xyz(e);
     return x;
 }
@@ -441,10 +447,10 @@ RZ_DEV bool box_hit(float4 b0, float4 b1, const WalkRay& r) {
     const float tmax = min_lt(min_lt(max_gt(t1, t2), max_gt(t3, t4)), max_gt(t5, t6));
     return !(tmax < r.near_ || tmin > tmax || tmin > r.far_);
 }
-RZ_DEV bool tri_hit(v3 v1, v3 v2, v3 vv3, const WalkRay& r, float& t, float& b1, float& b2, float& det) {
+RZ_DEV bool tri_hit(v3 v1, v3 edge1, v3 edge2, const WalkRay& r, float& t, float& b1, float& b2, float& det) {
     Ray q;
     q.o = r.o, q.d = r.d, q.near_ = r.near_, q.far_ = r.far_;
-    return tri_hit(v1, v2, vv3, q, t, b1, b2, det);
+    return tri_hit(v1, edge1, edge2, q, t, b1, b2, det);
 }
 
 // closest-hit (ANY = false: traverseWorld + closestIntersection, cpu_engine_kernel.cpp:254-352)
@@ -501,8 +507,12 @@ RZ_DEV int walk_threaded(const DScene& s, Ray& ray, Hit& hit, Counters& cnt) {
                 const InstanceXform x = load_instance_xform(s, inst);
                 world_o = cur.o, world_d = cur.d, world_near = cur.near_;
                 if constexpr (!ANY) ray.far_ = cur.far_;
-                cur.o = transform_backward(x.xa, x.ya, x.za, cur.o - x.position) / x.scale;
-                cur.d = transform_backward(x.xa, x.ya, x.za, cur.d) / x.scale;
+                cur.o = transform_backward(x.xa, x.ya, x.za, cur.o - x.position);
+                cur.d = transform_backward(x.xa, x.ya, x.za, cur.d);
+                if (!x.unit_scale) {
+                    cur.o = cur.o / x.scale;
+                    cur.d = cur.d / x.scale;
+                }
                 len = magnitude(cur.d);
                 cur.near_ = cur.near_ * len;
                 cur.far_ = cur.far_ * len;
@@ -561,8 +571,12 @@ struct LdsStack {
 // cpu_engine_kernel.cpp:307-312 / :442-445 on a prepared ray.  Returns the length factor.
 template <bool RCP>
 RZ_DEV float to_local(const InstanceXform& x, const WalkRay& g, WalkRay& l, bool scene_fast) {
-    l.o = transform_backward(x.xa, x.ya, x.za, g.o - x.position) / x.scale;
-    l.d = transform_backward(x.xa, x.ya, x.za, g.d) / x.scale;
+    l.o = transform_backward(x.xa, x.ya, x.za, g.o - x.position);
+    l.d = transform_backward(x.xa, x.ya, x.za, g.d);
+    if (!x.unit_scale) {
+        l.o = l.o / x.scale;
+        l.d = l.d / x.scale;
+    }
     const float len = magnitude(l.d);
     l.near_ = g.near_ * len;
     l.far_ = g.far_ * len;
@@ -1098,7 +1112,7 @@ RZ_DEV void analyze_intersection(const DScene& s, const Hit& hit, Surface& sf, M
     const v3 scale = xyz(i1), xa = xyz(i2), ya = xyz(i3), za = xyz(i4);
     const uint32_t material_base = __float_as_uint(i1.w), material_count = __float_as_uint(i2.w);
 
-    const float4 ta = s.tris[3 * hit.triangle], tb = s.tris[3 * hit.triangle + 1], tc = s.tris[3 * hit.triangle + 2];
+    const float4 ta = s.tris[3 * hit.triangle];
     const uint32_t flags = __float_as_uint(ta.w);
     const float4* at = s.tri_attrs + 6 * size_t(hit.triangle);
 
@@ -1128,7 +1142,8 @@ RZ_DEV void analyze_intersection(const DScene& s, const Hit& hit, Surface& sf, M
     }
     if (m.normal_map >= 0 && has_texcrds) {  // Triangle::mapNormal, mesh_component.cpp:132-167
         const col4 map_color = fetch_rgba8<COUNT>(s, m.normal_map, sf.u, sf.v, cnt);
-        const v3 v1 = xyz(ta), v2 = xyz(tb), vv3 = xyz(tc);
+        // v2 and v3 ride in the padding of the device attribute record (the triangle record holds edges)
+        const v3 v1 = xyz(ta), v2 = V3(at[0].w, at[1].w, at[2].w), vv3 = V3(at[3].w, uv3.z, uv3.w);
         const v3 edge1 = (v2 - v1) * scale;
         const v3 edge2 = (vv3 - v1) * scale;
         const float duv1x = uv12.z - uv12.x, duv1y = uv12.w - uv12.y;
@@ -1167,8 +1182,10 @@ RZ_DEV v3 cosine_sample_hemisphere(float r1, float r2, v3 vN) {
     const float phi = r1 * 6.283185f;
     const float theta = r2;
     const float sqrt_theta = sqrtf(theta);
-    const v3 a = (vX * sqrt_theta) * RZ_COSF(phi);
-    const v3 b = (vY * sqrt_theta) * RZ_SINF(phi);
+    float sin_phi, cos_phi;
+    RZ_SINCOSF(phi, sin_phi, cos_phi);
+    const v3 a = (vX * sqrt_theta) * cos_phi;
+    const v3 b = (vY * sqrt_theta) * sin_phi;
     const v3 c = vN * sqrtf(1.0f - theta);
     return (a + b) + c;
 }
@@ -1177,10 +1194,12 @@ RZ_DEV v3 sample_sphere(float r1, float r2, v3 vN) {
     local_coordinate(vN, vX, vY);
     const float phi = r1 * 6.283185f;
     const float theta = RZ_ACOSF(1.0f - 2.0f * r2);
-    const float sin_theta = RZ_SINF(theta);
-    const v3 a = (vX * sin_theta) * RZ_COSF(phi);
-    const v3 b = (vY * sin_theta) * RZ_SINF(phi);
-    const v3 c = vN * RZ_COSF(theta);
+    float sin_theta, cos_theta, sin_phi, cos_phi;
+    RZ_SINCOSF(theta, sin_theta, cos_theta);
+    RZ_SINCOSF(phi, sin_phi, cos_phi);
+    const v3 a = (vX * sin_theta) * cos_phi;
+    const v3 b = (vY * sin_theta) * sin_phi;
+    const v3 c = vN * cos_theta;
     return (a + b) + c;
 }
 RZ_DEV v3 sample_hemisphere(float r1, float r2, v3 vN) { return sample_sphere(r1, r2 * 0.5f, vN); }
@@ -1189,7 +1208,9 @@ RZ_DEV v3 sample_disk(float r1, float r2, v3 vN, float radius) {
     local_coordinate(vN, vX, vY);
     const float phi = r1 * 2.0f * RZ_PI_F;
     const float mag = sqrtf(r2);
-    return ((vX * RZ_SINF(phi) + vY * RZ_COSF(phi)) * mag) * radius;
+    float sin_phi, cos_phi;
+    RZ_SINCOSF(phi, sin_phi, cos_phi);
+    return ((vX * sin_phi + vY * cos_phi) * mag) * radius;
 }
 RZ_DEV float fresnel_specular_ratio(v3 vN, v3 vI, float n1, float n2, float& fx, float& fy) {
     const float ratio = n1 / n2;
@@ -1276,6 +1297,7 @@ RZ_DEV v3 sample_direction(v3 ray_d, uint32_t& ray_material, Surface& sf, Rng& r
 template <int MODE, bool COUNT>
 RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, uint32_t* lds_column, v3 ray_d, uint32_t ray_material,
                                 v3 point, v3 next_dir, const Surface& sf, Rng& rng, Counters& cnt) {
+    if (s.n_direct_lights == 0u && s.n_spot_lights == 0u) return splat(0.0f);  // both samplers return 0 before they read vS_pdf (:703, :758)
     const float vS_pdf = brdf(ray_d, sf, next_dir);
     col4 direct_total = splat(0.0f);
     if (s.n_direct_lights != 0) {  // directLightSampling :745-791
@@ -1393,7 +1415,9 @@ RZ_DEV void generate_antialiased_ray(const DCamera& c, Ray& ray, uint32_t px, ui
     const v3 focal_point = dir * c.focal_distance;
     const float aperture_angle = rng.unsignedUniform() * 2.0f * RZ_PI_F;
     const float aperture_sample = sqrtf(rng.unsignedUniform()) * c.aperture;
-    const v3 origin = V3(aperture_sample * RZ_SINF(aperture_angle), aperture_sample * RZ_COSF(aperture_angle), 0.0f);
+    float sin_a, cos_a;
+    RZ_SINCOSF(aperture_angle, sin_a, cos_a);
+    const v3 origin = V3(aperture_sample * sin_a, aperture_sample * cos_a, 0.0f);
     dir = focal_point - origin;
     const v3 xa = ld3(c.x_axis), ya = ld3(c.y_axis), za = ld3(c.z_axis);
     ray.o = transform_forward(xa, ya, za, origin) + ld3(c.position);
