@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--config", default="B", help="scene preset of rayzath_amd/scenes.py (B = the quoted config)")
     ap.add_argument("--traversal", type=int, default=-1, help="-1 per-scene choice (default), 1 nested walk with LDS stack, 2 workgroup-binned, 0 threaded")
     ap.add_argument("--pipeline", type=int, default=-1, help="0 fused pass kernel, 1 trace + shade kernels (-1: library default)")
+    ap.add_argument("--ray-sort", type=int, default=-1, help="-1 auto, 0 off, 1 on")
     ap.add_argument("--no-xcd-swizzle", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-gather", action="store_true", help="check the gathered frame against an unsharded render (N > 1)")
@@ -112,6 +113,7 @@ def main():
     ctx.set_traversal_mode(args.traversal)
     if args.pipeline >= 0:
         ctx.set_pipeline(args.pipeline)
+    ctx.set_ray_sort(args.ray_sort)
     if args.no_xcd_swizzle:
         ctx.set_xcd_swizzle(False)
     ctx.set_shard(rank, world)

@@ -278,6 +278,11 @@ int hiprz_set_lds_scene(hiprz_ctx* ctx, int mode);
 /* 1 (default) = a lean trace kernel followed by a shade kernel, with a 20-byte hit record per pixel passed
  * through device memory; 0 = one fused pass kernel.  Identical results. */
 int hiprz_set_pipeline(hiprz_ctx* ctx, int pipeline);
+/* Reorder rays between passes (split pipeline): the shade kernel emits a sort key per pixel (cell of the next
+ * ray's origin + quantised direction), a device radix sort turns the keys into a permutation, and the trace kernel
+ * walks the rays in that order so that a wave's rays visit the same nodes.  -1 = automatic (on for scenes that are
+ * not staged in LDS and have many instances), 0 = off, 1 = on.  Only the assignment of rays to threads changes; results are identical. */
+int hiprz_set_ray_sort(hiprz_ctx* ctx, int mode);
 /* XCD-aware workgroup -> tile mapping of the pass kernels (default off — it unbalances scenes whose cost is
  * concentrated in one image region): each of the 8 XCDs works through one
  * contiguous band of the owned tiles, so its L2 holds that band's part of the trees.  Execution order only. */

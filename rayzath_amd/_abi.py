@@ -112,6 +112,7 @@ ENTRY_POINTS = {
     "hiprz_set_lds_scene": (C.c_int, [P, C.c_int]),
     "hiprz_set_pipeline": (C.c_int, [P, C.c_int]),
     "hiprz_traversal_mode": (C.c_int, [P, C.POINTER(C.c_int)]),
+    "hiprz_set_ray_sort": (C.c_int, [P, C.c_int]),
     "hiprz_set_xcd_swizzle": (C.c_int, [P, C.c_int]),
     "hiprz_set_graph": (C.c_int, [P, C.c_int]),
     "hiprz_reset": (C.c_int, [P]),

@@ -101,6 +101,8 @@ struct DScene {
     uint32_t off_nodes, off_tlas_order, off_instances, off_tris, off_tri_attrs, off_materials, off_inst_materials;
     uint32_t world_stack_entries;  // LDS stack entries per lane the world tree needs / the deepest mesh tree needs
     uint32_t mesh_stack_entries;
+    float bounds_min[3];           // world box (root of the world tree) and 32 / extent per axis: cells of the ray sort key
+    float bounds_scale[3];
     uint32_t top_count;            // MODE 3: the first top_count nodes (+ their links) are staged in LDS by every workgroup
     const uint32_t* node_skip;     // link to the node that follows a node's subtree (same numbering as `nodes`)
 };
@@ -145,6 +147,8 @@ struct DFrame {
     uint32_t tiles_x;      // 32x8-pixel tiles per row
     uint32_t rank, world;  // tile sharding
     uint32_t n_local_tiles;
+    uint32_t* sort_key;    // shade kernel: sort key of the pixel's NEXT ray (nullptr = ray reordering off)
+    const uint32_t* perm;  // trace kernel: thread i walks the ray of local pixel perm[i] (nullptr = identity)
     uint32_t xcd_swizzle;  // 1: workgroup b works on owned tile (b % 8) * ceil(n/8) + b / 8 (see pixel_of_thread)
 };
 
@@ -1463,6 +1467,42 @@ RZ_DEV PixelId pixel_of_thread(const DFrame& f, const DCamera& c, uint32_t block
     p.local = lt * 256u + tid;
     p.active = lt < f.n_local_tiles && p.x < c.width && p.y < c.height;
     return p;
+}
+
+// PixelId of a local (tile-major) pixel index — the trace kernel's mapping when rays are walked in sorted order
+RZ_DEV PixelId pixel_of_local(const DFrame& f, const DCamera& c, uint32_t local) {
+    const uint32_t lt = local >> 8, tid = local & 255u;
+    const uint32_t tile = lt * f.world + f.rank;
+    const uint32_t tx = tile % f.tiles_x, ty = tile / f.tiles_x;
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    PixelId p;
+    p.x = tx * 32u + wave * 8u + (lane & 7u);
+    p.y = ty * 8u + (lane >> 3);
+    p.local = local;
+    p.active = lt < f.n_local_tiles && p.x < c.width && p.y < c.height;
+    return p;
+}
+
+// Sort key of a ray: 15-bit Morton code of the origin's cell in a 32^3 grid over the world box, then 3 bits per
+// direction component.  Rays with equal keys start close together and point the same way, so a wave that takes 64
+// consecutive rays of the sorted order walks the same nodes (coherent fetches, less divergence).  The key only
+// decides WHICH THREAD walks a ray; results do not depend on it.
+RZ_DEV uint32_t spread3(uint32_t v) {  // 5 bits -> every third bit
+    v = (v | (v << 8)) & 0x0000F00Fu;
+    v = (v | (v << 4)) & 0x000C30C3u;
+    v = (v | (v << 2)) & 0x00249249u;
+    return v;
+}
+RZ_DEV uint32_t ray_sort_key(const DScene& s, v3 o, v3 d) {
+    const float cx = fminf(fmaxf((o.x - s.bounds_min[0]) * s.bounds_scale[0], 0.0f), 31.0f);
+    const float cy = fminf(fmaxf((o.y - s.bounds_min[1]) * s.bounds_scale[1], 0.0f), 31.0f);
+    const float cz = fminf(fmaxf((o.z - s.bounds_min[2]) * s.bounds_scale[2], 0.0f), 31.0f);
+    const uint32_t morton = spread3(uint32_t(cx)) | (spread3(uint32_t(cy)) << 1) | (spread3(uint32_t(cz)) << 2);
+    const float inv = 1.0f / fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), 1.0e-30f));
+    const uint32_t qx = uint32_t(fminf(fmaxf(d.x * inv * 3.99f + 4.0f, 0.0f), 7.0f));
+    const uint32_t qy = uint32_t(fminf(fmaxf(d.y * inv * 3.99f + 4.0f, 0.0f), 7.0f));
+    const uint32_t qz = uint32_t(fminf(fmaxf(d.z * inv * 3.99f + 4.0f, 0.0f), 7.0f));
+    return (morton << 9) | (qx << 6) | (qy << 3) | qz;
 }
 
 }  // namespace hiprz

@@ -177,6 +177,9 @@ class Context:
     def untile_rgba8(self, src_ptr, rank, world, dst_ptr):
         self._check(self.lib.hiprz_untile_rgba8(self._ctx, src_ptr, rank, world, dst_ptr))
 
+    def set_ray_sort(self, mode):
+        self._check(self.lib.hiprz_set_ray_sort(self._ctx, mode))
+
     def set_xcd_swizzle(self, enabled):
         self._check(self.lib.hiprz_set_xcd_swizzle(self._ctx, int(enabled)))
 

@@ -172,6 +172,24 @@ def test_split_pipeline_equals_fused(built, mode):
             assert np.array_equal(out[0][2][k], out[1][2][k]), k
 
 
+def test_ray_reordering_changes_nothing_but_the_order(built):
+    """Sorted walk order (keys from the shade kernel, radix sort, permutation) == pixel order, bit for bit."""
+    for world, depth, mode in ((scenes.cornell_sphere(160, 90, 40), 6, 3), (scenes.living_room(96, 64, 16), 5, 3), (scenes.cornell_box(100, 60), 4, 1)):
+        flat, cam = flatten(world), camera_struct(world.camera)
+        cfg = RenderConfig(LightSampling(1, 1), Tracing(depth, 4)).struct()
+        out = []
+        for sort in (0, 1):
+            c = Context(0)
+            c.set_traversal_mode(mode), c.set_lds_scene(0), c.set_ray_sort(sort)
+            c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+            counters = c.render_counted(2)
+            c.render(4), c.render(4)   # graph capture + replay include the sort
+            out.append((c.read_accum(), c.read_state(), counters))
+        assert np.array_equal(out[0][0], out[1][0]) and out[0][2] == out[1][2]
+        for k in out[0][1]:
+            assert np.array_equal(out[0][1][k], out[1][1][k]), k
+
+
 def test_graph_replay_equals_eager_launches(built):
     world = scenes.cornell_box(160, 96)
     flat, cam = flatten(world), camera_struct(world.camera)
