@@ -192,7 +192,7 @@ def main():
             "config": {"workload": preset["note"], "resolution": [W, H], "max_depth": preset["max_depth"], "passes_per_step": RPP,
                        "triangles": int(len(flat.tris)), "instances": int(len(flat.instances)),
                        "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
-                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned", 3: "skip-links+lds-top-cache"}[ctx.traversal_mode()],
+                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned", 3: "skip-links+lds-top-cache", 4: "persistent-lanes"}[ctx.traversal_mode()],
                        "pipeline": "fused" if args.pipeline == 0 else "trace+shade"},
             "spp_per_s": spp_per_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,

@@ -265,7 +265,9 @@ int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
 /* Tree-walk variant of the pass kernel.  -1 (default) = chosen per scene; 1 = nested loops with a
  * per-lane stack in LDS; 2 = workgroup-binned (rays advance in rounds, the (ray, instance) visits of
  * a round are compacted and sorted by instance in LDS and processed by dense waves); 0 = threaded
- * (skip links + instance pseudo-nodes, no stack).  All visit the same boxes and triangles in the
+ * (skip links + instance pseudo-nodes, no stack); 3 = nested walk on skip links with the tree tops cached in
+ * LDS; 4 = persistent lanes (a workgroup owns a pool of rays, a lane that finishes its ray takes the next one)
+ * on the flat walk graph with postponed leaves.  All visit the same boxes and triangles in the
  * same per-ray order and give identical results. */
 int hiprz_set_traversal_mode(hiprz_ctx* ctx, int mode);
 int hiprz_traversal_mode(hiprz_ctx* ctx, int* effective_mode_out); /* valid after hiprz_upload_scene */

@@ -77,6 +77,129 @@ RZ_DEV void load_path(const DFrame& f, const DCamera& cam, const PixelId& p, Pat
     }
 }
 
+// pool = local pixel slots [pool_begin, pool_end) (through f.perm when rays are sorted); results go to f.hit0/hit1.
+template <bool FIRST, bool COUNT>
+__device__ __forceinline__ void trace_persistent(const DScene& s, const WalkTop& top, const DCamera& cam, const DFrame& f,
+                                                 uint32_t* pool_next, uint32_t pool_begin, uint32_t pool_end, Counters& cnt) {
+    const bool scene_fast = s.fast_div != 0u;
+    // per-ray state
+    bool has_ray = false, pool_empty = false;
+    uint32_t pixel = 0u;
+    WalkRay cur;
+    cur.o = cur.d = cur.y = V3(0.0f, 0.0f, 1.0f), cur.near_ = cur.far_ = 0.0f, cur.fast = false;
+    v3 world_o = cur.o, world_d = cur.d;
+    float world_near = 0.0f, world_far = 0.0f, len = 1.0f;
+    uint32_t n = RZ_END, ret = RZ_END, inst = 0u;
+    bool in_mesh = false, found_here = false, root_missed = false;
+    Hit hit;
+    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
+    uint32_t guard = 0u;
+
+    while (true) {
+        // ---- refill ----
+        if (!has_ray && !pool_empty) {
+            const uint32_t slot = pool_begin + atomicAdd(pool_next, 1u);
+            if (slot >= pool_end) {
+                pool_empty = true;
+            } else {
+                const PixelId p = pixel_of_local(f, cam, (!FIRST && f.perm) ? f.perm[slot] : slot);
+                pixel = p.local;
+                if (p.active) {
+                    PathState ps;
+                    load_path<FIRST>(f, cam, p, ps);
+                    cur.o = ps.ray.o, cur.d = ps.ray.d, cur.near_ = ps.ray.near_, cur.far_ = ps.ray.far_;
+                    prepare<true>(cur, scene_fast);
+                    world_o = cur.o, world_d = cur.d, world_near = cur.near_, world_far = cur.far_;
+                    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
+                    in_mesh = false, found_here = false, root_missed = false;
+                    n = s.n_instances ? s.tlas_root : RZ_END;
+                    if (s.n_instances == 0u) root_missed = true;
+                    has_ray = true;
+                }
+            }
+        }
+        if (!__any(has_ray)) {
+            if (__all(pool_empty)) break;
+            continue;
+        }
+        RZ_GUARD(guard);
+
+        // ---- node phase: step until this lane holds a leaf or its ray has ended ----
+        uint32_t leaf_begin = 0u, leaf_end = 0u;
+        while (has_ray && leaf_end == leaf_begin) {
+            if (n == RZ_END) {
+                if (in_mesh) {  // leave the instance: cpu_engine_kernel.cpp:320-329
+                    if (found_here) {
+                        hit.instance = int32_t(inst);
+                        world_near = cur.near_ / len;
+                        world_far = cur.far_ / len;
+                    }
+                    cur.o = world_o, cur.d = world_d, cur.near_ = world_near, cur.far_ = world_far;
+                    prepare<true>(cur, scene_fast);
+                    in_mesh = false;
+                    n = ret;
+                    continue;
+                }
+                // the ray's walk is complete: publish the hit record (rz_trace_kernel's layout)
+                const int found = root_missed ? 0 : (hit.instance >= 0 ? 2 : 1);
+                f.hit0[pixel] = make_float4(world_far, hit.bx, hit.by, __uint_as_float(hit.triangle));
+                f.hit1[pixel] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
+                has_ray = false;
+                break;
+            }
+            float4 n0, n1;
+            uint32_t link;
+            fetch_walk_node(s, top, n, n0, n1, link);
+            RZ_COUNT(box_tests);
+            if (box_hit<true>(n0, n1, cur)) {
+                const uint32_t a = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+                const uint32_t type = meta >> RZ_WALK_TYPE_SHIFT;
+                if (type == RZ_WALK_INNER || type == RZ_WALK_CHAIN) {
+                    n = a;
+                } else if (type == RZ_WALK_INSTANCE) {  // enter: cpu_engine_kernel.cpp:307-319
+                    inst = a;
+                    const InstanceXform x = load_instance_xform(s, inst);
+                    world_o = cur.o, world_d = cur.d, world_near = cur.near_, world_far = cur.far_;
+                    cur.o = transform_backward(x.xa, x.ya, x.za, cur.o - x.position);
+                    cur.d = transform_backward(x.xa, x.ya, x.za, cur.d);
+                    if (!x.unit_scale) {
+                        cur.o = cur.o / x.scale;
+                        cur.d = cur.d / x.scale;
+                    }
+                    len = magnitude(cur.d);
+                    cur.near_ = cur.near_ * len;
+                    cur.far_ = cur.far_ * len;
+                    cur.d = cur.d * (1.0f / len);
+                    prepare<true>(cur, scene_fast);
+                    in_mesh = true, found_here = false;
+                    ret = link;
+                    n = x.blas_root;
+                } else {  // triangle leaf: hold it
+                    leaf_begin = a, leaf_end = a + (meta & RZ_WALK_COUNT_MASK);
+                    n = link;
+                }
+            } else {
+                if (n == s.tlas_root) root_missed = true;  // cpu_engine_kernel.cpp:283
+                n = link;
+            }
+        }
+
+        // ---- leaf phase ----
+        for (uint32_t i = leaf_begin; i < leaf_end; ++i) {
+            const float4 ta = s.tris[3 * i], tb = s.tris[3 * i + 1], tc = s.tris[3 * i + 2];
+            float t, b1, b2, det;
+            RZ_COUNT(tri_tests);
+            if (tri_hit(xyz(ta), xyz(tb), xyz(tc), cur, t, b1, b2, det)) {
+                cur.far_ = t;
+                hit.triangle = i;
+                hit.external = det > 0.0f;
+                hit.bx = b1, hit.by = b2;
+                found_here = true;
+            }
+        }
+    }
+}
+
 // closest hit of the segment with the selected walk; MODE 2 must be reached by all 256 threads
 template <int MODE, bool COUNT, bool RCP>
 RZ_DEV int trace_path(const DScene& s, unsigned char* workspace, uint32_t* lds_column, bool active, Ray& ray, Hit& hit, Counters& cnt) {
@@ -261,6 +384,25 @@ __global__ void __launch_bounds__(256, RZ_TRACE_MIN_WAVES) rz_trace_kernel(const
         f.hit0[p.local] = make_float4(ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
         f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
     }
+    flush_counters<COUNT>(f, 0u, cnt);
+}
+
+// MODE 4 trace kernel: persistent lanes over a per-workgroup pool of RZ_POOL_FACTOR * 256 rays
+template <bool FIRST, bool COUNT>
+__global__ void __launch_bounds__(256, RZ_TRACE_MIN_WAVES) rz_trace_persistent_kernel(const DScene s, const DCamera cam, const DFrame f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
+    float4* ln = reinterpret_cast<float4*>(rz_lds);
+    uint32_t* ls = reinterpret_cast<uint32_t*>(rz_lds + s.wtop_count * 32u);
+    uint32_t* pool_next = ls + s.wtop_count;
+    for (uint32_t i = threadIdx.x; i < 2u * s.wtop_count; i += 256u) ln[i] = s.wnodes[i];
+    for (uint32_t i = threadIdx.x; i < s.wtop_count; i += 256u) ls[i] = s.wskip[i];
+    if (threadIdx.x == 0u) *pool_next = 0u;
+    __syncthreads();
+    const uint32_t pool_rays = 256u * RZ_POOL_FACTOR, n_slots = f.n_local_tiles * 256u;
+    const uint32_t pool_begin = blockIdx.x * pool_rays, pool_end = pool_begin + pool_rays < n_slots ? pool_begin + pool_rays : n_slots;
+    Counters cnt;
+    const WalkTop top{ln, ls, s.wtop_count};
+    trace_persistent<FIRST, COUNT>(s, top, cam, f, pool_next, pool_begin, pool_end, cnt);
     flush_counters<COUNT>(f, 0u, cnt);
 }
 
@@ -657,7 +799,7 @@ bool sort_enabled(const hiprz_ctx* c) {
     if (c->sort_rays == 1) return true;
     // measured (1920x1080+, MODE 3): many small instances (config E, 46) 33.9 -> 26.5 ms per pass with sorting; one big
     // mesh (config D) 3.7 -> 4.6 ms, config C unchanged.  So: on when the world tree has many instances.
-    return !use_lds_scene(c) && effective_mode(c) == 3 && c->dscene.n_instances >= 16u;
+    return !use_lds_scene(c) && effective_mode(c) >= 3 && c->dscene.n_instances >= 16u;
 }
 
 DFrame make_frame(hiprz_ctx* c, bool counted) {
@@ -684,7 +826,10 @@ DConfig make_config(const hiprz_ctx* c) {
 // and the nested walk is faster (config C: 1 668 vs 2 450 us).
 int effective_mode(const hiprz_ctx* c) {
     if (c->traversal_mode >= 0) return c->traversal_mode;
-    if (!c->lds_scene && c->pipeline == 1) return 3;  // records do not fit LDS: skip-link walk + cached tree tops
+    // records do not fit LDS: nested skip-link walk with cached tree tops.  (MODE 4, persistent lanes on the flat walk
+    // graph, is selectable but measured slower — config D 6.1 vs 3.5 ms: once lanes are desynchronised every loop
+    // iteration pays for the instance-entry / exit / refill blocks.)
+    if (!c->lds_scene && c->pipeline == 1) return 3;
     return c->dscene.mesh_stack_entries <= 2u ? 2 : 1;
 }
 
@@ -706,7 +851,7 @@ void launch_pass(hiprz_ctx* c, const DFrame& f) {
     const bool lds_scene = use_lds_scene(c);
     const size_t blob = lds_scene ? c->dscene.hot_bytes : 0u;
     int mode = effective_mode(c);
-    if (mode == 3 && (lds_scene || c->pipeline != 1)) mode = 1;  // the top cache is for scenes that are not staged whole, in the trace kernel
+    if ((mode == 3 || mode == 4) && (lds_scene || c->pipeline != 1)) mode = 1;  // the top cache is for scenes that are not staged whole, in the trace kernel
     const size_t stack_lds = size_t(c->stack_entries) * 256u * sizeof(uint32_t);
     const size_t walk_lds = mode == 2 ? size_t(BinnedLds::bytes_host(c->dscene.world_stack_entries, c->dscene.mesh_stack_entries))
                             : mode == 1 ? stack_lds : 0u;
@@ -716,7 +861,10 @@ void launch_pass(hiprz_ctx* c, const DFrame& f) {
         else hipLaunchKernelGGL(kernel_global, grid, block, (lds_bytes), c->stream, __VA_ARGS__);                   \
     } while (0)
     if (c->pipeline == 1) {
-        if (mode == 3) hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 3, false>), grid, block, TopCache::bytes_host(c->dscene.top_count), c->stream, c->dscene, c->dcamera, f);
+        if (mode == 4) {
+            const uint32_t pools = (c->n_local_tiles + RZ_POOL_FACTOR - 1u) / RZ_POOL_FACTOR;
+            hipLaunchKernelGGL((rz_trace_persistent_kernel<FIRST, COUNT>), dim3(pools), block, c->dscene.wtop_count * 36u + 16u, c->stream, c->dscene, c->dcamera, f);
+        } else if (mode == 3) hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 3, false>), grid, block, TopCache::bytes_host(c->dscene.top_count), c->stream, c->dscene, c->dcamera, f);
         else if (mode == 2) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 2, true>), (rz_trace_kernel<FIRST, COUNT, 2, false>), walk_lds, c->dscene, c->dcamera, f);
         else if (mode == 1) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 1, true>), (rz_trace_kernel<FIRST, COUNT, 1, false>), walk_lds, c->dscene, c->dcamera, f);
         else RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 0, true>), (rz_trace_kernel<FIRST, COUNT, 0, false>), walk_lds, c->dscene, c->dcamera, f);
@@ -1200,6 +1348,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
         d.bounds_scale[a] = hi > lo ? 32.0f / (hi - lo) : 0.0f;
     }
     d.top_count = std::min<uint32_t>(sc->n_nodes, kTopCacheNodes);
+    d.wtop_count = std::min<uint32_t>(uint32_t(wnodes.size()), kTopCacheNodes);
     d.n_spot_lights = sc->n_spot_lights;
     d.n_direct_lights = sc->n_direct_lights;
     // Stage the blob in LDS when three workgroups per CU (the kernel's register-limited residency)
@@ -1271,7 +1420,7 @@ int hiprz_set_shard(hiprz_ctx* c, uint32_t rank, uint32_t world) {
 int hiprz_set_traversal_mode(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
     c->graph_valid = false;
-    if (mode < -1 || mode > 3) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: -1 = auto, 0 = threaded, 1 = LDS stack, 2 = workgroup-binned, 3 = skip links + LDS-cached tree tops");
+    if (mode < -1 || mode > 4) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: -1 = auto, 0 = threaded, 1 = LDS stack, 2 = workgroup-binned, 3 = skip links + LDS-cached tree tops, 4 = persistent lanes on the flat walk graph");
     c->traversal_mode = mode;
     return HIPRZ_OK;
 }

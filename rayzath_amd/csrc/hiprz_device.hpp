@@ -26,6 +26,9 @@ namespace hiprz {
 #ifndef RZ_MIN_WAVES
 #define RZ_MIN_WAVES 4
 #endif
+#ifndef RZ_POOL_FACTOR  // MODE 4: rays per workgroup pool = 256 * RZ_POOL_FACTOR
+#define RZ_POOL_FACTOR 8u
+#endif
 #ifndef RZ_TRACE_MIN_WAVES
 #define RZ_TRACE_MIN_WAVES 5
 #endif
@@ -103,6 +106,7 @@ struct DScene {
     uint32_t mesh_stack_entries;
     float bounds_min[3];           // world box (root of the world tree) and 32 / extent per axis: cells of the ray sort key
     float bounds_scale[3];
+    uint32_t wtop_count;           // MODE 4: the same for the walk graph (wnodes / wskip)
     uint32_t top_count;            // MODE 3: the first top_count nodes (+ their links) are staged in LDS by every workgroup
     const uint32_t* node_skip;     // link to the node that follows a node's subtree (same numbering as `nodes`)
 };
@@ -973,33 +977,44 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                 const float len = to_local<RCP>(x, g, lr, scene_fast);
                 bool found = false;
                 uint32_t m = x.blas_root;
-                while (m != RZ_END) {  // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352
-                    RZ_GUARD(guard);
-                    float4 m0, m1;
-                    uint32_t mlink;
-                    fetch_node(s, top, m, m0, m1, mlink);
-                    RZ_COUNT(box_tests);
-                    if (box_hit<RCP>(m0, m1, lr)) {
-                        const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
-                        if (!(mmeta & HIPRZ_NODE_LEAF)) {
-                            m = mbegin;
+                // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352, as a "while-while" walk: every lane
+                // steps through nodes until it HOLDS a leaf (or is done); only then do the lanes test their triangles,
+                // together.  (With the leaf loop nested in the node loop some lane is at a leaf in almost every step and
+                // the whole wave waits through its triangles: 11 % lane utilisation on the 301 k-triangle mesh.)
+                while (true) {
+                    uint32_t leaf_begin = 0u, leaf_end = 0u;
+                    while (m != RZ_END) {
+                        RZ_GUARD(guard);
+                        float4 m0, m1;
+                        uint32_t mlink;
+                        fetch_node(s, top, m, m0, m1, mlink);
+                        RZ_COUNT(box_tests);
+                        if (box_hit<RCP>(m0, m1, lr)) {
+                            const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
+                            if (!(mmeta & HIPRZ_NODE_LEAF)) {
+                                m = mbegin;
+                                continue;
+                            }
+                            leaf_begin = mbegin, leaf_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
+                            m = mlink;
+                            if (leaf_end > leaf_begin) break;  // hold this leaf
                             continue;
                         }
-                        const uint32_t mend = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
-                        for (uint32_t j = mbegin; j < mend; ++j) {
-                            const float4 a = s.tris[3 * j], b = s.tris[3 * j + 1], c = s.tris[3 * j + 2];
-                            float t, b1, b2, det;
-                            RZ_COUNT(tri_tests);
-                            if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
-                                lr.far_ = t;
-                                hit.triangle = j;
-                                hit.external = det > 0.0f;
-                                hit.bx = b1, hit.by = b2;
-                                found = true;
-                            }
+                        m = mlink;
+                    }
+                    if (leaf_end == leaf_begin) break;  // walk finished without another leaf
+                    for (uint32_t j = leaf_begin; j < leaf_end; ++j) {
+                        const float4 a = s.tris[3 * j], b = s.tris[3 * j + 1], c = s.tris[3 * j + 2];
+                        float t, b1, b2, det;
+                        RZ_COUNT(tri_tests);
+                        if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
+                            lr.far_ = t;
+                            hit.triangle = j;
+                            hit.external = det > 0.0f;
+                            hit.bx = b1, hit.by = b2;
+                            found = true;
                         }
                     }
-                    m = mlink;
                 }
                 if (found) {
                     hit.instance = int32_t(inst);
@@ -1014,6 +1029,27 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
     }
     ray.near_ = g.near_, ray.far_ = g.far_;
     return hit.instance >= 0 ? 2 : 1;
+}
+
+
+// ---- MODE 4: persistent lanes on the flat walk graph ----
+// A wave is as slow as its slowest ray, and the cost of a ray is heavy-tailed (config D: 7x between the mean and the
+// slowest of 64), so one-ray-per-lane leaves ~87 % of the lanes idle.  Here a workgroup owns a POOL of rays and every
+// lane runs a flat loop over the walk graph of MODE 0 (world nodes, INSTANCE pseudo-nodes and mesh nodes are all "test
+// a box, follow a link"); a lane whose ray is finished takes the next ray of the pool (LDS atomic) at the top of the
+// loop, so lanes stay busy until the pool is empty.  Leaves are postponed: lanes step through nodes until each HOLDS a
+// leaf (or its ray ended), then all test their triangles together.  Per ray the sequence of tests is the reference's.
+struct WalkTop {  // the first `count` walk-graph nodes + links, staged in LDS
+    const float4* nodes;
+    const uint32_t* skip;
+    uint32_t count;
+};
+RZ_DEV void fetch_walk_node(const DScene& s, const WalkTop& top, uint32_t n, float4& n0, float4& n1, uint32_t& link) {
+    if (n < top.count) {
+        n0 = top.nodes[2 * n], n1 = top.nodes[2 * n + 1], link = top.skip[n];
+    } else {
+        n0 = s.wnodes[2 * n], n1 = s.wnodes[2 * n + 1], link = s.wskip[n];
+    }
 }
 
 // Returns 0 = no instances / root box missed (the reference returns before it computes the

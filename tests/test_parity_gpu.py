@@ -29,8 +29,8 @@ def _run_both(world, max_depth, passes, mode=0, spot=1, direct=1, seed=20240501)
     cfg = RenderConfig(LightSampling(spot, direct), Tracing(max_depth, passes), seed).struct()
     ctx = Context(0)
     ctx.set_traversal_mode(mode)
-    if mode == 3:
-        ctx.set_lds_scene(0)  # the skip-link walk with cached tree tops is for scenes that are not staged whole
+    if mode >= 3:
+        ctx.set_lds_scene(0)  # modes 3 and 4 are for scenes that are not staged whole in LDS
     ctx.upload_scene(flat)
     ctx.upload_camera(cam)
     ctx.set_config(cfg)
@@ -58,7 +58,7 @@ def _compare(ctx, ref, tag):
     return report
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_first_pass_is_bit_exact_where_no_libm_is_involved(built, mode):
     world = scenes.cornell_box(256, 256)
     ctx, ref = _run_both(world, 4, 1, mode)
@@ -76,7 +76,7 @@ def test_first_pass_is_bit_exact_where_no_libm_is_involved(built, mode):
     assert ctx.ray_count() == ref.traced_rays == 256 * 256
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
 def test_cornell_config_a(built, mode):
     """BASELINE config A: Cornell box 256x256, depth 4, until >= 4 finished samples everywhere."""
     world = scenes.cornell_box(256, 256)
@@ -113,7 +113,7 @@ def test_lights_glass_scattering_scene(built):
     assert rep["alpha_equal"] >= 0.98 and rep["rgb_close"] >= 0.97
 
 
-@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("mode", [1, 3, 4])
 def test_sphere_scene_hits(built, mode):
     """Config-C-like: 6 240-triangle sphere with per-vertex normals, deep mesh tree."""
     world = scenes.cornell_sphere(320, 180, 80)
@@ -174,7 +174,7 @@ def test_split_pipeline_equals_fused(built, mode):
 
 def test_ray_reordering_changes_nothing_but_the_order(built):
     """Sorted walk order (keys from the shade kernel, radix sort, permutation) == pixel order, bit for bit."""
-    for world, depth, mode in ((scenes.cornell_sphere(160, 90, 40), 6, 3), (scenes.living_room(96, 64, 16), 5, 3), (scenes.cornell_box(100, 60), 4, 1)):
+    for world, depth, mode in ((scenes.cornell_sphere(160, 90, 40), 6, 3), (scenes.living_room(96, 64, 16), 5, 4), (scenes.cornell_box(100, 60), 4, 1)):
         flat, cam = flatten(world), camera_struct(world.camera)
         cfg = RenderConfig(LightSampling(1, 1), Tracing(depth, 4)).struct()
         out = []
@@ -227,14 +227,14 @@ def test_shared_reciprocal_division_is_exact(built):
 
 
 @pytest.mark.parametrize("name", ["cornell_128", "living_room_96x64", "sphere_160x90"])
-@pytest.mark.parametrize("mode", [3, 2, 1, 0])
+@pytest.mark.parametrize("mode", [4, 3, 2, 1, 0])
 def test_gpu_matches_committed_golden(built, name, mode):
     """Same comparison without the oracle in the loop: committed fixtures (tests/golden)."""
     from test_golden_oracle import load_golden
     g, flat, cam, cfg = load_golden(name)
     ctx = Context(0)
     ctx.set_traversal_mode(mode)
-    if mode == 3:
+    if mode >= 3:
         ctx.set_lds_scene(0)
     ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(cfg)
     first = ctx.render_counted(1)
