@@ -158,7 +158,9 @@ def main():
         alpha_before = float(ctx.read_accum()[..., 3].sum())
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == args.steps - 1:
+            ctx.time_kernels(True)  # the last timed step also records per-kernel events (eager launches instead of the graph)
         step()
     fence()
     elapsed = time.perf_counter() - t0
@@ -168,18 +170,31 @@ def main():
     elapsed = float(t.item())
 
     kernel_ms, launches = ctx.kernel_time_ms()
+    breakdown = ctx.kernel_breakdown_ms()  # trace / shade kernel times of the last timed step
+    ctx.time_kernels(False)
     rays = args.steps * RPP * W * H
     result = None
     if rank == 0:
         spp_per_s = None
         if alpha_before is not None:
             spp_per_s = (float(ctx.read_accum()[..., 3].sum()) - alpha_before) / (W * H) / elapsed
-        # work counters of the same kernel, same state, outside the timed region
+        # work counters of the same kernels, same state, outside the timed region
         counters = ctx.render_counted(RPP)
         ctx.kernel_time_ms()
-        bytes_per_launch = algorithmic_bytes(counters) / RPP
-        avg_kernel_s = kernel_ms / 1e3 / max(launches, 1)
-        achieved = bytes_per_launch / avg_kernel_s / 1e9
+        bytes_per_pass = algorithmic_bytes(counters) / RPP
+        avg_pass_s = kernel_ms / 1e3 / max(launches, 1)
+        split = args.pipeline != 0
+        if split and breakdown[2]:
+            # dominant kernel = the BVH-traversal kernel.  Its algorithmic bytes: the ray it reads (40 B of path state) and
+            # the hit record it writes (20 B) per segment + 32 B per box test + 36 B per triangle test of the closest-hit
+            # walk (shadow-ray tests run in the shade kernel and are not counted here).
+            kernel_name = "rz_trace_kernel (closest-hit walk)"
+            kernel_s = breakdown[0] / 1e3 / breakdown[2]
+            kernel_bytes = (60 * counters["segments"] + 32 * (counters["box_tests"] - counters["shadow_box_tests"])
+                            + 36 * (counters["tri_tests"] - counters["shadow_tri_tests"])) / RPP
+        else:
+            kernel_name, kernel_s, kernel_bytes = "rz_pass_kernel (fused pass)", avg_pass_s, bytes_per_pass
+        achieved = kernel_bytes / kernel_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
         if os.path.exists(tpath) and world == 1:
@@ -196,9 +211,11 @@ def main():
                        "pipeline": "fused" if args.pipeline == 0 else "trace+shade"},
             "spp_per_s": spp_per_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
-                         "traffic": traffic, "kernel": "one pass = rz_trace_kernel + rz_shade_kernel (cumulative)" if args.pipeline != 0 else "rz_pass_kernel (cumulative)",
-                         "avg_launch_us": avg_kernel_s * 1e6,
-                         "algorithmic_bytes_per_launch": bytes_per_launch, "segments_per_launch": counters["segments"] / RPP,
+                         "traffic": traffic, "kernel": kernel_name, "avg_launch_us": kernel_s * 1e6,
+                         "algorithmic_bytes_per_launch": kernel_bytes, "segments_per_launch": counters["segments"] / RPP,
+                         "shade_kernel_avg_launch_us": breakdown[1] / breakdown[2] * 1e3 if split and breakdown[2] else None,
+                         "whole_pass": {"avg_us": avg_pass_s * 1e6, "algorithmic_bytes": bytes_per_pass,
+                                        "achieved": bytes_per_pass / avg_pass_s / 1e9, "frac": bytes_per_pass / avg_pass_s / 1e9 / PEAK_HBM_GBS},
                          "box_tests_per_segment": counters["box_tests"] / max(counters["segments"], 1),
                          "tri_tests_per_segment": counters["tri_tests"] / max(counters["segments"], 1)},
         }

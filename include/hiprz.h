@@ -236,6 +236,8 @@ typedef struct hiprz_counters {
     uint64_t light_samples; /* light samples evaluated (NEE loop iterations) */
     uint64_t texel_fetches; /* TextureBuffer::fetch calls */
     uint64_t finished;      /* paths finished (alpha increments, cpu_engine_kernel.cpp:82) */
+    uint64_t shadow_box_tests; /* the part of box_tests done for shadow rays (anyIntersection) */
+    uint64_t shadow_tri_tests; /* the part of tri_tests done for shadow rays */
 } hiprz_counters;
 
 typedef struct hiprz_ctx hiprz_ctx;
@@ -340,6 +342,12 @@ int hiprz_selftest(hiprz_ctx* ctx, uint32_t cases_per_thread, uint32_t seed, uin
 
 /* --- timing (TimeTable, engine_parts.hpp:34-74; Engine::debugInfo, rayzath.cpp:96-113) --- */
 int hiprz_timings(hiprz_ctx* ctx, char* buf, size_t len);
+/* Kernel-level timing of the split pipeline: while hiprz_time_kernels(ctx, 1) is set, a batch of cumulative passes is
+ * launched eagerly (not from the captured graph) with events before the trace kernel, between the two kernels and
+ * after the shade kernel of each pass; hiprz_kernel_breakdown_ms returns the summed durations of the LAST such batch
+ * and its pass count. */
+int hiprz_time_kernels(hiprz_ctx* ctx, int enabled);
+int hiprz_kernel_breakdown_ms(hiprz_ctx* ctx, double* trace_ms, double* shade_ms, uint32_t* passes);
 /* Average device time of the pass kernel since the last call, from hip events recorded on the
  * context's stream around every hiprz_render() batch. */
 int hiprz_kernel_time_ms(hiprz_ctx* ctx, double* total_ms, uint64_t* launches);

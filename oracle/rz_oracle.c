@@ -526,12 +526,14 @@ static void any_mesh(const kctx* k, uint32_t node_idx, const ray_t* ray, float* 
     if (*mask < 1.0e-4f) return;
     const hiprz_node* node = &k->s->nodes[node_idx];
     COUNT(k, box_tests, 1);
+    COUNT(k, shadow_box_tests, 1);
     if (!box_hit(node->bb_min, node->bb_max, ray)) return;
     if (node_is_leaf(node)) {
         const uint32_t end = node->begin + node_count(node);
         for (uint32_t i = node->begin; i < end; ++i) {
             float t, b1, b2, det;
             COUNT(k, tri_tests, 1);
+            COUNT(k, shadow_tri_tests, 1);
             if (tri_hit(&k->s->tris[i], ray, &t, &b1, &b2, &det)) {
                 *mask *= 0.0f;
                 return;
@@ -545,6 +547,7 @@ static void any_mesh(const kctx* k, uint32_t node_idx, const ray_t* ray, float* 
 static float any_instance(const kctx* k, uint32_t inst_idx, const ray_t* ray) {
     const hiprz_instance* in = &k->s->instances[inst_idx];
     COUNT(k, box_tests, 1);
+    COUNT(k, shadow_box_tests, 1);
     if (!box_hit(in->bb_min, in->bb_max, ray)) return 1.0f;
     ray_t local = *ray;
     transform_g2l(in, &local);
@@ -567,12 +570,14 @@ static void any_world(const kctx* k, uint32_t node_idx, const ray_t* ray, float*
     } else {
         const hiprz_node* first = &k->s->nodes[node->begin];
         COUNT(k, box_tests, 1);
+    COUNT(k, shadow_box_tests, 1);
         if (box_hit(first->bb_min, first->bb_max, ray)) {
             any_world(k, node->begin, ray, mask);
             if (*mask < 1.0e-4f) return;
         }
         const hiprz_node* second = &k->s->nodes[node->begin + 1];
         COUNT(k, box_tests, 1);
+    COUNT(k, shadow_box_tests, 1);
         if (box_hit(second->bb_min, second->bb_max, ray)) any_world(k, node->begin + 1, ray, mask);
     }
 }
@@ -582,6 +587,7 @@ static float any_intersection(const kctx* k, const ray_t* ray) {
     if (s->n_instances == 0) return 0.0f;
     const hiprz_node* root = &s->nodes[s->tlas_root];
     COUNT(k, box_tests, 1);
+    COUNT(k, shadow_box_tests, 1);
     if (!box_hit(root->bb_min, root->bb_max, ray)) return 1.0f;
     float mask = 1.0f;
     any_world(k, s->tlas_root, ray, &mask);
@@ -1128,6 +1134,8 @@ static void counters_add(hiprz_counters* a, const hiprz_counters* b) {
     a->light_samples += b->light_samples;
     a->texel_fetches += b->texel_fetches;
     a->finished += b->finished;
+    a->shadow_box_tests += b->shadow_box_tests;
+    a->shadow_tri_tests += b->shadow_tri_tests;
 }
 
 void rzo_render_pass(const hiprz_scene* scene, const hiprz_camera* camera, const hiprz_config* config,

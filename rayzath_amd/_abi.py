@@ -79,7 +79,7 @@ class Config(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("segments", "box_tests", "tri_tests", "hits", "shadow_rays", "light_samples",
-                                          "texel_fetches", "finished")]
+                                          "texel_fetches", "finished", "shadow_box_tests", "shadow_tri_tests")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -136,6 +136,8 @@ ENTRY_POINTS = {
     "hiprz_pick": (C.c_int, [P, U32, U32, C.POINTER(I32), C.POINTER(I32)]),
     "hiprz_selftest": (C.c_int, [P, U32, U32, C.POINTER(U64), C.POINTER(U64)]),
     "hiprz_timings": (C.c_int, [P, C.c_char_p, SZ]),
+    "hiprz_time_kernels": (C.c_int, [P, C.c_int]),
+    "hiprz_kernel_breakdown_ms": (C.c_int, [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(U32)]),
     "hiprz_kernel_time_ms": (C.c_int, [P, C.POINTER(C.c_double), C.POINTER(U64)]),
     "hiprz_build_mesh_tree": (C.c_int, [C.POINTER(MeshDesc), P, U32, C.POINTER(U32), P, P]),
     "hiprz_build_world_tree": (C.c_int, [P, P, U32, P, U32, C.POINTER(U32), P, C.POINTER(U32)]),

@@ -312,10 +312,10 @@ RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& 
 template <bool COUNT>
 RZ_DEV void flush_counters(const DFrame& f, uint32_t segments, const Counters& cnt) {
     if constexpr (COUNT) {
-        uint32_t v[8] = {segments,        cnt.box_tests,     cnt.tri_tests,     cnt.hits,
-                         cnt.shadow_rays, cnt.light_samples, cnt.texel_fetches, cnt.finished};
+        uint32_t v[10] = {segments,        cnt.box_tests,     cnt.tri_tests,     cnt.hits,     cnt.shadow_rays,
+                          cnt.light_samples, cnt.texel_fetches, cnt.finished, cnt.shadow_box_tests, cnt.shadow_tri_tests};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 10; ++k) {
             uint32_t x = v[k];
             for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
             if ((threadIdx.x & 63u) == 0u && x) atomicAdd(&f.counters[k], (unsigned long long)x);
@@ -665,6 +665,9 @@ struct hiprz_ctx {
     DeviceArray<uint8_t> sort_temp;
     size_t sort_temp_bytes = 0;
     int sort_rays = -1;  // -1 auto (on for scenes walked with MODE 3), 0 off, 1 on
+    bool time_kernels = false;  // record events around the trace and the shade kernel of every pass of a batch
+    std::vector<hipEvent_t> kernel_events;
+    uint32_t kernel_event_passes = 0;
     bool use_graph = true;
     bool xcd_swizzle = false;  // measured: banding the image per XCD concentrates the expensive region on few XCDs (D: 4.3 -> 5.1 ms)
 
@@ -844,7 +847,7 @@ bool use_lds_scene(const hiprz_ctx* c) {
 }
 
 template <bool FIRST, bool COUNT>
-void launch_pass(hiprz_ctx* c, const DFrame& f) {
+void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_shade = nullptr) {
     // with the XCD swizzle the grid is padded to a multiple of 8 workgroups (the extra ones find no tile)
     const dim3 grid(c->xcd_swizzle ? ((c->n_local_tiles + 7u) / 8u) * 8u : c->n_local_tiles), block(256);
     const DConfig cfg = make_config(c);
@@ -868,6 +871,7 @@ void launch_pass(hiprz_ctx* c, const DFrame& f) {
         else if (mode == 2) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 2, true>), (rz_trace_kernel<FIRST, COUNT, 2, false>), walk_lds, c->dscene, c->dcamera, f);
         else if (mode == 1) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 1, true>), (rz_trace_kernel<FIRST, COUNT, 1, false>), walk_lds, c->dscene, c->dcamera, f);
         else RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 0, true>), (rz_trace_kernel<FIRST, COUNT, 0, false>), walk_lds, c->dscene, c->dcamera, f);
+        if (between_trace_and_shade) (void)hipEventRecord(between_trace_and_shade, c->stream);
         RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, true>), (rz_shade_kernel<FIRST, COUNT, false>), stack_lds, c->dscene, c->dcamera, cfg, f);
     } else {
         // the fused kernel's shadow rays use the stack walk: its columns must exist in every mode
@@ -935,7 +939,7 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     const DFrame f = make_frame(c, counted);
     hipEvent_t e0 = take_event(c), e1 = take_event(c);
     RZ_HIP(c, hipEventRecord(e0, c->stream));
-    if (c->use_graph && !counted && !c->reset_pending && n_passes >= 2) {
+    if (c->use_graph && !c->time_kernels && !counted && !c->reset_pending && n_passes >= 2) {
         // steady state: one graph launch instead of 2 * n_passes kernel launches
         if (!c->graph_valid || c->graph_passes != n_passes) {
             drop_graph(c);
@@ -954,7 +958,29 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
         c->ray_count += uint64_t(n_passes) * c->owned_pixels;
         return finish_batch(c, e0, e1, n_passes, timer);
     }
+    // kernel-level timing (bench.py's roofline): events before the trace kernel, between the two kernels and after the
+    // shade kernel of every pass.  Event timing does not work from inside a captured graph, so a timed batch is launched
+    // eagerly.
+    const bool timed = c->time_kernels && c->pipeline == 1 && !counted && !c->reset_pending;
+    if (timed) {
+        while (c->kernel_events.size() < size_t(3 * n_passes)) {
+            hipEvent_t e = nullptr;
+            (void)hipEventCreate(&e);
+            c->kernel_events.push_back(e);
+        }
+        c->kernel_event_passes = n_passes;
+    }
     for (uint32_t i = 0; i < n_passes; ++i) {
+        if (timed) {
+            (void)hipEventRecord(c->kernel_events[3 * i], c->stream);
+            launch_pass<false, false>(c, f, c->kernel_events[3 * i + 1]);
+            (void)hipEventRecord(c->kernel_events[3 * i + 2], c->stream);
+            launch_sort(c);
+            hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+            c->passes += 1;
+            c->ray_count += c->owned_pixels;
+            continue;
+        }
         if (c->reset_pending) {
             hipLaunchKernelGGL(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
             if (counted) launch_pass<true, true>(c, f);
@@ -1201,7 +1227,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     c->device = device_id;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = c->pass_dev.resize(1);
-    if (e == hipSuccess) e = c->counters_dev.resize(8);
+    if (e == hipSuccess) e = c->counters_dev.resize(16);
     if (e == hipSuccess) e = c->pick_dev.resize(2);
     if (e == hipSuccess) e = hipMemsetAsync(c->pass_dev.ptr, 0, sizeof(uint32_t), c->stream);
     if (e != hipSuccess) {
@@ -1223,6 +1249,7 @@ int hiprz_destroy(hiprz_ctx* c) {
         (void)hipEventDestroy(p.second);
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    for (auto e : c->kernel_events) (void)hipEventDestroy(e);
     c->hot.release(), c->wnodes.release(), c->wskip.release(), c->node_skip.release(), c->textures.release();
     c->texels.release(), c->spot_lights.release(), c->direct_lights.release();
     release_frame(c);
@@ -1484,14 +1511,15 @@ int hiprz_render_counted(hiprz_ctx* c, uint32_t n_passes, hiprz_counters* out) {
     if (!c) return HIPRZ_ERR_INVALID;
     if (!out) return fail(c, HIPRZ_ERR_INVALID, "render_counted: out is null");
     (void)hipSetDevice(c->device);
-    RZ_HIP(c, hipMemsetAsync(c->counters_dev.ptr, 0, 8 * sizeof(unsigned long long), c->stream));
+    RZ_HIP(c, hipMemsetAsync(c->counters_dev.ptr, 0, 16 * sizeof(unsigned long long), c->stream));
     const int rc = render_impl(c, n_passes, true);
     if (rc != HIPRZ_OK) return rc;
-    unsigned long long v[8];
+    unsigned long long v[10];
     RZ_HIP(c, hipMemcpyAsync(v, c->counters_dev.ptr, sizeof v, hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));
     out->segments = v[0], out->box_tests = v[1], out->tri_tests = v[2], out->hits = v[3];
     out->shadow_rays = v[4], out->light_samples = v[5], out->texel_fetches = v[6], out->finished = v[7];
+    out->shadow_box_tests = v[8], out->shadow_tri_tests = v[9];
     return HIPRZ_OK;
 }
 
@@ -1681,6 +1709,30 @@ int hiprz_timings(hiprz_ctx* c, char* buf, size_t len) {
     if (!c || !buf || len == 0) return HIPRZ_ERR_INVALID;
     const std::string s = c->timings.str();
     std::snprintf(buf, len, "%s", s.c_str());
+    return HIPRZ_OK;
+}
+
+int hiprz_time_kernels(hiprz_ctx* c, int enabled) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    c->graph_valid = false;
+    c->time_kernels = enabled != 0;
+    return HIPRZ_OK;
+}
+
+int hiprz_kernel_breakdown_ms(hiprz_ctx* c, double* trace_ms, double* shade_ms, uint32_t* passes) {
+    if (!c || !trace_ms || !shade_ms || !passes) return HIPRZ_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    *trace_ms = *shade_ms = 0.0;
+    *passes = 0;
+    if (c->pipeline != 1) return HIPRZ_OK;
+    for (uint32_t i = 0; i < c->kernel_event_passes; ++i) {
+        float a = 0, b = 0;
+        RZ_HIP(c, hipEventElapsedTime(&a, c->kernel_events[3 * i], c->kernel_events[3 * i + 1]));
+        RZ_HIP(c, hipEventElapsedTime(&b, c->kernel_events[3 * i + 1], c->kernel_events[3 * i + 2]));
+        *trace_ms += a, *shade_ms += b;
+    }
+    *passes = c->kernel_event_passes;
     return HIPRZ_OK;
 }
 

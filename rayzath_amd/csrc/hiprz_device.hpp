@@ -229,6 +229,7 @@ struct Ray {
 
 struct Counters {
     uint32_t box_tests = 0, tri_tests = 0, hits = 0, shadow_rays = 0, light_samples = 0, texel_fetches = 0, finished = 0;
+    uint32_t shadow_box_tests = 0, shadow_tri_tests = 0;
 };
 #define RZ_COUNT(field) \
     if constexpr (COUNT) cnt.field++
@@ -685,6 +686,7 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
         RZ_GUARD(guard);
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_COUNT(box_tests);
+        RZ_COUNT(shadow_box_tests);
         if (box_hit<false>(n0, n1, g)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             if (!(meta & HIPRZ_NODE_LEAF)) {
@@ -697,6 +699,7 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
                 float4 ib0, ib1;
                 load_instance_box(s, inst, ib0, ib1);
                 RZ_COUNT(box_tests);
+        RZ_COUNT(shadow_box_tests);
                 if (!box_hit<false>(ib0, ib1, g)) continue;
                 const InstanceXform x = load_instance_xform(s, inst);
                 WalkRay lr;
@@ -708,6 +711,7 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
                     RZ_GUARD(guard);
                     const float4 m0 = s.nodes[2 * m], m1 = s.nodes[2 * m + 1];
                     RZ_COUNT(box_tests);
+        RZ_COUNT(shadow_box_tests);
                     if (box_hit<false>(m0, m1, lr)) {
                         const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                         if (!(mmeta & HIPRZ_NODE_LEAF)) {
@@ -719,6 +723,7 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
                             const float4 a = s.tris[3 * j], b = s.tris[3 * j + 1], c = s.tris[3 * j + 2];
                             float t, b1, b2, det;
                             RZ_COUNT(tri_tests);
+                            RZ_COUNT(shadow_tri_tests);
                             if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) return 0.0f;
                         }
                     }

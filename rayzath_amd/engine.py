@@ -156,6 +156,15 @@ class Context:
         self._check(self.lib.hiprz_timings(self._ctx, buf, len(buf)))
         return buf.value.decode()
 
+    def time_kernels(self, enabled=True):
+        self._check(self.lib.hiprz_time_kernels(self._ctx, int(enabled)))
+
+    def kernel_breakdown_ms(self):
+        """(trace kernel ms, shade kernel ms, passes) of the last batch of cumulative passes (split pipeline)."""
+        t, s_, n = C.c_double(), C.c_double(), C.c_uint32()
+        self._check(self.lib.hiprz_kernel_breakdown_ms(self._ctx, C.byref(t), C.byref(s_), C.byref(n)))
+        return t.value, s_.value, n.value
+
     def kernel_time_ms(self):
         """(total device ms, passes) of the pass kernel since the last call (hip events on the ctx stream)."""
         t, n = C.c_double(), C.c_uint64()

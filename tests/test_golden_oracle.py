@@ -41,7 +41,8 @@ def test_oracle_reproduces_golden(built, name):
 def test_golden_counters_are_consistent():
     for name in NAMES:
         g, flat, cam, cfg = load_golden(name)
-        seg, box, tri, hits, shadow, lights, texels, finished = (int(x) for x in g["counters_first"] + g["counters_rest"])
+        seg, box, tri, hits, shadow, lights, texels, finished, shadow_box, shadow_tri = (int(x) for x in g["counters_first"] + g["counters_rest"])
+        assert shadow_box <= box and shadow_tri <= tri and (shadow_box > 0) == (shadow > 0)
         px = cam.width * cam.height
         assert seg == int(g["passes"]) * px
         assert finished == int(g["accum"][..., 3].sum())          # alpha counts finished paths
