@@ -69,8 +69,9 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="B", help="scene preset of rayzath_amd/scenes.py (B = the quoted config)")
-    ap.add_argument("--traversal", type=int, default=-1, help="-1 per-scene choice (default), 1 nested walk with LDS stack, 2 workgroup-binned, 0 threaded")
-    ap.add_argument("--pipeline", type=int, default=-1, help="0 fused pass kernel, 1 trace + shade kernels (-1: library default)")
+    ap.add_argument("--traversal", type=int, default=-1, help="-1 per-scene choice (default), 1 nested walk with LDS stack, 2 workgroup-binned, 0 threaded, 3 skip links + LDS tree tops, 4 persistent lanes, 5 = 3 in requeue rounds")
+    ap.add_argument("--requeue", type=str, default="", help="mode 5 schedule: comma-separated lane thresholds per bailing round")
+    ap.add_argument("--pipeline", type=int, default=-1, help="0 fused pass kernel, 1 trace + shade kernels, 2 resident batch kernel (-1: chosen per scene)")
     ap.add_argument("--ray-sort", type=int, default=-1, help="-1 auto, 0 off, 1 on")
     ap.add_argument("--no-xcd-swizzle", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -111,6 +112,8 @@ def main():
 
     ctx = Context(local_rank)
     ctx.set_traversal_mode(args.traversal)
+    if args.requeue:
+        ctx.set_requeue_schedule([int(t) for t in args.requeue.split(",") if t != ""])
     if args.pipeline >= 0:
         ctx.set_pipeline(args.pipeline)
     ctx.set_ray_sort(args.ray_sort)
@@ -171,6 +174,7 @@ def main():
 
     kernel_ms, launches = ctx.kernel_time_ms()
     breakdown = ctx.kernel_breakdown_ms()  # trace / shade kernel times of the last timed step
+    requeue_counts = [c for c in ctx.requeue_counts()[1:] if c] if ctx.traversal_mode() == 5 else None
     ctx.time_kernels(False)
     rays = args.steps * RPP * W * H
     result = None
@@ -183,8 +187,32 @@ def main():
         ctx.kernel_time_ms()
         bytes_per_pass = algorithmic_bytes(counters) / RPP
         avg_pass_s = kernel_ms / 1e3 / max(launches, 1)
-        split = args.pipeline != 0
-        if split and breakdown[2]:
+        pipeline = ctx.pipeline()
+        split = pipeline == 1
+        traversal_kernel = None
+        if pipeline == 2 and breakdown[2]:
+            # dominant (only) kernel: the resident batch kernel — one launch takes every tile through the RPP passes of the
+            # step.  Algorithmic bytes: SURVEY.md §8d's per-segment figure x the segments of the launch.
+            kernel_name = "rz_batch_kernel (resident: all passes of a step)"
+            kernel_s = breakdown[0] / 1e3
+            kernel_bytes = algorithmic_bytes(counters)
+            # the BVH-traversal kernel on its own (north_star's 30 % target): the same step through the split pipeline,
+            # outside the timed region
+            ctx.set_pipeline(1)
+            ctx.render(RPP)
+            ctx.time_kernels(True)
+            ctx.render(RPP)
+            tb = ctx.kernel_breakdown_ms()
+            ctx.time_kernels(False)
+            ctx.set_pipeline(args.pipeline)
+            if tb[2]:
+                t_bytes = (60 * counters["segments"] + 32 * (counters["box_tests"] - counters["shadow_box_tests"])
+                           + 36 * (counters["tri_tests"] - counters["shadow_tri_tests"])) / RPP
+                t_s = tb[0] / 1e3 / tb[2]
+                traversal_kernel = {"kernel": "rz_trace_kernel (closest-hit walk, split pipeline)", "avg_launch_us": t_s * 1e6,
+                                    "algorithmic_bytes_per_launch": t_bytes, "achieved": t_bytes / t_s / 1e9,
+                                    "frac": t_bytes / t_s / 1e9 / PEAK_HBM_GBS, "shade_kernel_avg_launch_us": tb[1] / tb[2] * 1e3}
+        elif split and breakdown[2]:
             # dominant kernel = the BVH-traversal kernel.  Its algorithmic bytes: the ray it reads (40 B of path state) and
             # the hit record it writes (20 B) per segment + 32 B per box test + 36 B per triangle test of the closest-hit
             # walk (shadow-ray tests run in the shade kernel and are not counted here).
@@ -198,7 +226,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
         if os.path.exists(tpath) and world == 1:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(kernel_name.split(" ")[0], {}).get("hbm_bytes_per_launch")
         result = {
             "metric": "Mrays/s (path segments, primary+secondary) at 1920x1080 depth 8" if args.config == "B" else f"Mrays/s config {args.config}",
             "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -207,12 +235,15 @@ def main():
             "config": {"workload": preset["note"], "resolution": [W, H], "max_depth": preset["max_depth"], "passes_per_step": RPP,
                        "triangles": int(len(flat.tris)), "instances": int(len(flat.instances)),
                        "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
-                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned", 3: "skip-links+lds-top-cache", 4: "persistent-lanes"}[ctx.traversal_mode()],
-                       "pipeline": "fused" if args.pipeline == 0 else "trace+shade"},
+                       "requeued_rays_per_round": requeue_counts,
+                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned", 3: "skip-links+lds-top-cache", 4: "persistent-lanes", 5: "skip-links+requeue-rounds"}[ctx.traversal_mode()],
+                       "pipeline": {0: "fused (one kernel per pass)", 1: "trace+shade (two kernels per pass)", 2: "resident (one kernel per step)"}[pipeline]},
             "spp_per_s": spp_per_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": traffic, "kernel": kernel_name, "avg_launch_us": kernel_s * 1e6,
-                         "algorithmic_bytes_per_launch": kernel_bytes, "segments_per_launch": counters["segments"] / RPP,
+                         "algorithmic_bytes_per_launch": kernel_bytes,
+                         "segments_per_launch": counters["segments"] / (1 if pipeline == 2 else RPP),
+                         "traversal_kernel": traversal_kernel,
                          "shade_kernel_avg_launch_us": breakdown[1] / breakdown[2] * 1e3 if split and breakdown[2] else None,
                          "whole_pass": {"avg_us": avg_pass_s * 1e6, "algorithmic_bytes": bytes_per_pass,
                                         "achieved": bytes_per_pass / avg_pass_s / 1e9, "frac": bytes_per_pass / avg_pass_s / 1e9 / PEAK_HBM_GBS},

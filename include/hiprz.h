@@ -269,9 +269,15 @@ int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
  * a round are compacted and sorted by instance in LDS and processed by dense waves); 0 = threaded
  * (skip links + instance pseudo-nodes, no stack); 3 = nested walk on skip links with the tree tops cached in
  * LDS; 4 = persistent lanes (a workgroup owns a pool of rays, a lane that finishes its ray takes the next one)
- * on the flat walk graph with postponed leaves.  All visit the same boxes and triangles in the
- * same per-ray order and give identical results. */
+ * on the flat walk graph with postponed leaves; 5 = the walk of 3 in rounds: a ray whose wave has run thin stops,
+ * is queued (48 B of walk state) and resumed by the next round's kernel in a dense wave.  All visit the same boxes
+ * and triangles in the same per-ray order and give identical results. */
 int hiprz_set_traversal_mode(hiprz_ctx* ctx, int mode);
+/* Mode 5 schedule: thresholds[r] (0..64) = lanes of a wave that must remain inside a mesh walk during round r for
+ * it to go on; otherwise they are queued for round r+1.  After n_rounds (<= 30) rounds a final round finishes every ray. */
+int hiprz_set_requeue_schedule(hiprz_ctx* ctx, const uint32_t* thresholds, uint32_t n_rounds);
+/* Diagnostics: counts_out[r] = rays the most recent pass queued for round r (r >= 1; up to 32 entries). */
+int hiprz_requeue_counts(hiprz_ctx* ctx, uint32_t* counts_out, uint32_t n);
 int hiprz_traversal_mode(hiprz_ctx* ctx, int* effective_mode_out); /* valid after hiprz_upload_scene */
 
 /* Stage the scene's geometry + shading records into LDS in every workgroup (ds_read instead of
@@ -279,9 +285,13 @@ int hiprz_traversal_mode(hiprz_ctx* ctx, int* effective_mode_out); /* valid afte
  * 1 = whenever they fit one workgroup.  Results are identical either way. */
 int hiprz_set_lds_scene(hiprz_ctx* ctx, int mode);
 
-/* 1 (default) = a lean trace kernel followed by a shade kernel, with a 20-byte hit record per pixel passed
- * through device memory; 0 = one fused pass kernel.  Identical results. */
+/* How the passes of hiprz_render are packaged into kernels.  1 = per pass a lean trace kernel followed by a shade
+ * kernel, with a 20-byte hit record per pixel passed through device memory; 0 = per pass one fused kernel;
+ * 2 = resident: ONE kernel per hiprz_render call — a workgroup takes its 32x8 tile through all the passes, path state
+ * and accumulator stay on chip, the tone-mapped pixel is written on the way out (hiprz_tonemap then has nothing to do);
+ * -1 (default) = 2 for scenes staged in LDS, else 1.  Identical results. */
 int hiprz_set_pipeline(hiprz_ctx* ctx, int pipeline);
+int hiprz_pipeline(hiprz_ctx* ctx, int* effective_pipeline_out); /* valid after hiprz_upload_scene */
 /* Reorder rays between passes (split pipeline): the shade kernel emits a sort key per pixel (cell of the next
  * ray's origin + quantised direction), a device radix sort turns the keys into a permutation, and the trace kernel
  * walks the rays in that order so that a wave's rays visit the same nodes.  -1 = automatic (on for scenes that are

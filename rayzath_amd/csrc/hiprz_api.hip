@@ -221,19 +221,20 @@ RZ_DEV int trace_path(const DScene& s, unsigned char* workspace, uint32_t* lds_c
     }
 }
 
-// everything of traceRay after the closest hit + accumulation + next-segment state (active lanes only)
-template <bool FIRST, bool COUNT>
-RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& cfg, const DFrame& f, const PixelId& p, PathState& ps,
-                            int found, const Hit& hit, uint32_t* lds_column, Counters& cnt) {
+// everything of traceRay after the closest hit (active lanes only): returns the segment's radiance and whether the path
+// goes on, and leaves the NEXT segment's ray / colour / material / depth in `ps` (TracingResult::repositionRay, or a fresh
+// antialiased camera ray when the path ended).  ps.ray.far_ must hold the hit distance.
+template <bool COUNT>
+RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cfg, const PixelId& p, PathState& ps, uint32_t pass,
+                          int found, const Hit& hit, uint32_t* lds_column, Counters& cnt, col4& final_color, bool& path_continues) {
     Ray& ray = ps.ray;
     col4& ray_color = ps.color;
     uint32_t& ray_material = ps.material;
     uint32_t& depth = ps.depth;
-    const uint32_t pass = FIRST ? 0u : *f.pass;
     const uint32_t pixel_idx = p.y * cam.width + p.x;
     Rng rng(float(p.x) / float(cam.width), float(p.y) / float(cam.height), seed_value(cfg.seed, pass, (pixel_idx + depth) & 255u));
 
-    col4 final_color = splat(0.0f);
+    final_color = splat(0.0f);
     Surface sf;
     sf.surface_material = sf.behind_material = HIPRZ_MATERIAL_WORLD;
     sf.u = sf.v = 0.0f;
@@ -260,7 +261,6 @@ RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& 
     if (sf.emission > 0.0f) final_color = final_color + (ray_color * sf.color) * sf.emission;
 
     v3 point = V3(0.0f, 0.0f, 0.0f), next_direction = V3(0.0f, 0.0f, 0.0f);
-    const float hit_distance = ray.far_;
     if (found != 2) {
         depth = 255u;  // TracingState::endPath
     } else {
@@ -279,7 +279,30 @@ RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& 
         final_color = final_color + (direct * ray_color) * lerp(splat(1.0f), sf.color, sf.metalness);
         ray_color = lerp(ray_color, ray_color * sf.color, sf.tint_factor);  // ColorF::Blend
     }
-    const bool path_continues = depth < cfg.max_depth;
+    path_continues = depth < cfg.max_depth;
+    if (path_continues) {  // TracingResult::repositionRay
+        ray.o = point;
+        ray.d = next_direction;
+    } else {
+        RZ_COUNT(finished);
+        generate_antialiased_ray(cam, ray, p.x, p.y, rng);
+        ray_material = HIPRZ_MATERIAL_WORLD;
+        ray_color = splat(1.0f);
+        depth = 0u;
+    }
+}
+
+// shade_segment + accumulation + next-segment state to HBM (renderFirstPass / renderCumulativePass after traceRay)
+template <bool FIRST, bool COUNT>
+RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& cfg, const DFrame& f, const PixelId& p, PathState& ps,
+                            int found, const Hit& hit, uint32_t* lds_column, Counters& cnt) {
+    const float hit_distance = ps.ray.far_;
+    col4 final_color;
+    bool path_continues;
+    shade_segment<COUNT>(s, cam, cfg, p, ps, FIRST ? 0u : *f.pass, found, hit, lds_column, cnt, final_color, path_continues);
+    const Ray& ray = ps.ray;
+    const col4& ray_color = ps.color;
+    const uint32_t ray_material = ps.material, depth = ps.depth;
 
     // ---- accumulate ----
     col4 value;
@@ -293,16 +316,6 @@ RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& 
     f.accum[p.local] = make_float4(value.r, value.g, value.b, value.a);
 
     // ---- next segment ----
-    if (path_continues) {  // TracingResult::repositionRay
-        ray.o = point;
-        ray.d = next_direction;
-    } else {
-        RZ_COUNT(finished);
-        generate_antialiased_ray(cam, ray, p.x, p.y, rng);
-        ray_material = HIPRZ_MATERIAL_WORLD;
-        ray_color = splat(1.0f);
-        depth = 0u;
-    }
     f.st0[p.local] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
     f.st1[p.local] = make_float4(ray.d.y, ray.d.z, ray_color.r, ray_color.g);
     f.st2[p.local] = make_float2(ray_color.b, __uint_as_float((ray_material & 0xFFFFu) | (depth << 16)));
@@ -359,6 +372,73 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene
     flush_counters<COUNT>(f, p.active ? 1u : 0u, cnt);
 }
 
+// ---- resident pipeline ----
+// Pixels never interact, so a workgroup can take its tile through ALL the cumulative passes of a render batch in one
+// launch: path state and accumulator stay in registers (parked in LDS during the binned walk) and cross HBM once per
+// batch instead of once per pass, there is one launch per batch instead of two or three per pass, and the tone-mapped
+// pixel is written on the way out.  Per pixel the arithmetic is that of n_passes launches of the fused kernel: the
+// direction is re-normalised at the start of every segment as load_path does after reading it back, and the
+// accumulator grows by the same sequence of additions.
+template <bool COUNT, int MODE, bool LDS_SCENE>
+__global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_batch_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f,
+                                                                      uint32_t n_passes, uint32_t park_offset) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
+    DScene s = scene_in;
+    unsigned char* workspace = rz_lds + stage_scene<LDS_SCENE>(s, rz_lds);
+    uint32_t* lds_column = stack_column<MODE>(workspace);
+    const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
+    Counters cnt;
+    PathState ps;
+    load_path<false>(f, cam, p, ps);
+    // the accumulator lives in LDS for the whole batch (touched once per pass); colour / material / depth join it
+    // there while the binned walk runs
+    uint32_t* park = reinterpret_cast<uint32_t*>(workspace + park_offset) + threadIdx.x;
+    {
+        const float4 acc = p.active ? f.accum[p.local] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        park[4 * 256] = __float_as_uint(acc.x), park[5 * 256] = __float_as_uint(acc.y);
+        park[6 * 256] = __float_as_uint(acc.z), park[7 * 256] = __float_as_uint(acc.w);
+    }
+    const uint32_t pass0 = *f.pass;
+    for (uint32_t i = 0; i < n_passes; ++i) {
+        if (i != 0u && p.active) {  // what load_path does with the state the previous pass stored
+            ps.ray.d = normalized(ps.ray.d);
+            ps.ray.near_ = 0.0f, ps.ray.far_ = RZ_FLT_MAX;
+            if (ps.depth == 0u) ps.ray.near_ = cam.near_, ps.ray.far_ = cam.far_;
+        }
+        Hit hit;
+        int found;
+        if constexpr (MODE == 2) {
+            park[0 * 256] = __float_as_uint(ps.color.r), park[1 * 256] = __float_as_uint(ps.color.g);
+            park[2 * 256] = __float_as_uint(ps.color.b), park[3 * 256] = ps.material | (ps.depth << 16);
+            found = trace_path<MODE, COUNT, RZ_BATCH_SHARED_RCP != 0>(s, workspace, lds_column, p.active, ps.ray, hit, cnt);
+            ps.color = col4{__uint_as_float(park[0 * 256]), __uint_as_float(park[1 * 256]), __uint_as_float(park[2 * 256]), 1.0f};
+            const uint32_t bits = park[3 * 256];
+            ps.material = bits & 0xFFFFu, ps.depth = bits >> 16;
+        } else {
+            found = trace_path<MODE, COUNT, RZ_BATCH_SHARED_RCP != 0>(s, workspace, lds_column, p.active, ps.ray, hit, cnt);
+        }
+        if (p.active) {
+            col4 final_color;
+            bool path_continues;
+            shade_segment<COUNT>(s, cam, cfg, p, ps, pass0 + i, found, hit, lds_column, cnt, final_color, path_continues);
+            park[4 * 256] = __float_as_uint(__uint_as_float(park[4 * 256]) + final_color.r);
+            park[5 * 256] = __float_as_uint(__uint_as_float(park[5 * 256]) + final_color.g);
+            park[6 * 256] = __float_as_uint(__uint_as_float(park[6 * 256]) + final_color.b);
+            park[7 * 256] = __float_as_uint(__uint_as_float(park[7 * 256]) + float(!path_continues));
+        }
+    }
+    if (p.active) {
+        const float4 acc = make_float4(__uint_as_float(park[4 * 256]), __uint_as_float(park[5 * 256]), __uint_as_float(park[6 * 256]),
+                                       __uint_as_float(park[7 * 256]));
+        f.accum[p.local] = acc;
+        f.st0[p.local] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.d.x);
+        f.st1[p.local] = make_float4(ps.ray.d.y, ps.ray.d.z, ps.color.r, ps.color.g);
+        f.st2[p.local] = make_float2(ps.color.b, __uint_as_float((ps.material & 0xFFFFu) | (ps.depth << 16)));
+        f.rgba8[p.local] = tonemap(col4{acc.x, acc.y, acc.z, acc.w}, cam.aperture, cam.exposure_time);
+    }
+    flush_counters<COUNT>(f, p.active ? n_passes : 0u, cnt);
+}
+
 // ---- split pipeline ----
 // hit record: hit0 = (far, b1, b2, bits(triangle)), hit1 = instance | found << 29 | external << 31
 template <bool FIRST, bool COUNT, int MODE, bool LDS_SCENE>
@@ -381,6 +461,91 @@ __global__ void __launch_bounds__(256, RZ_TRACE_MIN_WAVES) rz_trace_kernel(const
     Hit hit;
     const int found = trace_path<MODE, COUNT, RZ_TRACE_SHARED_RCP != 0>(s, workspace, lds_column, p.active, ray, hit, cnt);
     if (p.active) {
+        f.hit0[p.local] = make_float4(ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
+        f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
+    }
+    flush_counters<COUNT>(f, 0u, cnt);
+}
+
+// MODE 5 trace kernels: round 0 walks every owned pixel's ray, round r > 0 the rays round r-1 left unfinished.
+// Queue record r of a round (48 B, SoA): q0 = (pixel slot, world leaf, tlas_order slot, mesh node), q1 = (near, far,
+// mesh-space far, bits(found | external << 1)), q2 = (b1, b2, bits(triangle), bits(instance)).
+struct DRequeue {
+    const uint4* in0;
+    const float4* in1;
+    const float4* in2;
+    uint4* out0;
+    float4* out1;
+    float4* out2;
+    uint32_t* counts;    // counts[r] = rays queued FOR round r (counts[0] unused)
+    uint32_t round;
+    uint32_t threshold;  // lanes that must remain in a mesh walk for it to go on (this round)
+};
+template <bool FIRST, bool COUNT, bool ROUND0, bool CAN_BAIL>
+__global__ void __launch_bounds__(256, RZ_TRACE_MIN_WAVES) rz_trace_requeue_kernel(const DScene s, const DCamera cam, const DFrame f, const DRequeue q) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    uint32_t n_in = 0u;
+    if constexpr (!ROUND0) {
+        n_in = q.counts[q.round];
+        if (blockIdx.x * 256u >= n_in) return;  // whole workgroup: nothing queued for it
+    }
+    float4* ln = reinterpret_cast<float4*>(rz_lds);
+    uint32_t* ls = reinterpret_cast<uint32_t*>(rz_lds + s.top_count * 32u);
+    for (uint32_t i = threadIdx.x; i < 2u * s.top_count; i += 256u) ln[i] = s.nodes[i];
+    for (uint32_t i = threadIdx.x; i < s.top_count; i += 256u) ls[i] = s.node_skip[i];
+    __syncthreads();
+    const TopCache top{ln, ls, s.top_count};
+
+    Counters cnt;
+    PixelId p;
+    Ray ray;
+    Hit hit;
+    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
+    WalkResume rs;
+    rs.n = s.tlas_root, rs.i = 0u, rs.m = RZ_END, rs.in_mesh = false, rs.found = false, rs.lr_far = 0.0f;
+    if constexpr (ROUND0) {
+        p = (!FIRST && f.perm) ? pixel_of_local(f, cam, f.perm[slot]) : pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
+        PathState ps;
+        load_path<FIRST>(f, cam, p, ps);
+        ray = ps.ray;
+    } else {
+        const bool queued = slot < n_in;
+        const uint4 r0 = queued ? q.in0[slot] : make_uint4(0u, 0u, 0u, 0u);
+        p = pixel_of_local(f, cam, r0.x);
+        if (!queued) p.active = false;
+        PathState ps;
+        load_path<FIRST>(f, cam, p, ps);
+        ray = ps.ray;
+        if (queued) {
+            const float4 r1 = q.in1[slot], r2 = q.in2[slot];
+            const uint32_t bits = __float_as_uint(r1.w);
+            ray.near_ = r1.x, ray.far_ = r1.y;
+            rs.n = r0.y, rs.i = r0.z, rs.m = r0.w, rs.in_mesh = true, rs.found = (bits & 1u) != 0u, rs.lr_far = r1.z;
+            hit.bx = r2.x, hit.by = r2.y, hit.triangle = __float_as_uint(r2.z), hit.instance = int32_t(__float_as_uint(r2.w));
+            hit.external = (bits & 2u) != 0u;
+        }
+    }
+    int found = 0;
+    if (p.active && s.n_instances != 0u) found = closest_hit_requeue<COUNT, RZ_TRACE_SHARED_RCP != 0, CAN_BAIL>(s, top, ray, hit, rs, q.threshold, cnt);
+    if constexpr (CAN_BAIL) {
+        // unfinished rays -> next round's queue, one atomic per wave
+        const bool bailed = found == 3;
+        const unsigned long long mask = __ballot(bailed);
+        if (mask) {
+            const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+            uint32_t base = 0u;
+            if (lane == uint32_t(__ffsll((long long)mask) - 1)) base = atomicAdd(&q.counts[q.round + 1u], uint32_t(__popcll(mask)));
+            base = __shfl(base, __ffsll((long long)mask) - 1);
+            if (bailed) {
+                const uint32_t o = base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
+                q.out0[o] = make_uint4(p.local, rs.n, rs.i, rs.m);
+                q.out1[o] = make_float4(ray.near_, ray.far_, rs.lr_far, __uint_as_float((rs.found ? 1u : 0u) | (hit.external ? 2u : 0u)));
+                q.out2[o] = make_float4(hit.bx, hit.by, __uint_as_float(hit.triangle), __uint_as_float(uint32_t(hit.instance)));
+            }
+        }
+    }
+    if (p.active && found != 3) {
         f.hit0[p.local] = make_float4(ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
         f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
     }
@@ -436,6 +601,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScen
 // the pass index lives on the device so a captured graph replays without new arguments.
 __global__ void rz_pass_update_kernel(uint32_t* pass) { *pass += 1u; }
 __global__ void rz_pass_reset_kernel(uint32_t* pass) { *pass = 0u; }
+__global__ void rz_pass_add_kernel(uint32_t* pass, uint32_t n) { *pass += n; }
 
 // toneMap (cuda_postprocess_kernel.cu:38-93; CPU: cpu_engine_renderer.cpp:224-235)
 __global__ void __launch_bounds__(256) rz_tonemap_tiles_kernel(const float4* accum, uint32_t* rgba8, uint32_t n, float aperture,
@@ -638,7 +804,13 @@ struct hiprz_ctx {
     uint64_t owned_pixels = 0;
     DeviceArray<float4> st0, st1, accum, hit0;
     DeviceArray<uint32_t> hit1;
-    int pipeline = 1;  // 0 fused, 1 split (trace kernel -> shade kernel; measured 10-20 % faster on configs B, C, D)
+    // 0 fused (one kernel per pass), 1 split (trace kernel -> shade kernel per pass), 2 resident (one kernel per batch
+    // of passes).  -1: resident when the scene is staged in LDS (config B: as fast as split on a whole frame, 2.26 ms per
+    // 8 passes, and 0.34 vs 0.45 ms on an eighth of it — per-pass launch/ramp/tail costs vanish), else split (10-20 % faster
+    // than fused on configs C, D; the resident kernel has no LDS room for the tree-top cache).
+    int pipeline_setting = -1;
+    int pipeline = 1;  // resolved by resolve_pipeline() at upload / set time
+    bool rgba8_valid = false;  // the resident kernel tone-maps on its way out: hiprz_tonemap has nothing to do
     DeviceArray<float2> st2;
     DeviceArray<float> depth;
     DeviceArray<uint32_t> rgba8;
@@ -654,6 +826,12 @@ struct hiprz_ctx {
     uint32_t passes = 0;
     uint64_t ray_count = 0;
     int traversal_mode = -1;  // -1 = choose per scene (effective_mode)
+    // MODE 5: two ping-pong ray queues (48 B per entry, one entry per owned pixel each), per-round counters and the
+    // schedule: requeue_thresholds[r] = lanes that must remain in a mesh walk during round r (the final round never bails)
+    DeviceArray<uint4> rq0[2];
+    DeviceArray<float4> rq1[2], rq2[2];
+    DeviceArray<uint32_t> rq_counts;
+    std::vector<uint32_t> requeue_thresholds{40u, 40u, 32u, 32u, 24u, 16u};
 
     // hipGraph of one batch of cumulative passes ([pass kernel, pass update] x n): replayed while nothing that
     // the captured kernel arguments depend on has changed (scene, camera, config, shard, variants)
@@ -738,6 +916,7 @@ struct TreeCheck {
 void release_frame(hiprz_ctx* c) {
     c->st0.release(), c->st1.release(), c->st2.release(), c->accum.release(), c->depth.release(), c->rgba8.release();
     c->hit0.release(), c->hit1.release();
+    for (int k = 0; k < 2; ++k) c->rq0[k].release(), c->rq1[k].release(), c->rq2[k].release();
     c->sort_keys.release(), c->sort_keys_out.release(), c->sort_iota.release(), c->sort_perm.release(), c->sort_temp.release();
     c->image_f4.release(), c->state_md.release(), c->state_ray.release();
 }
@@ -795,7 +974,9 @@ int allocate_frame(hiprz_ctx* c) {
 }
 
 int effective_mode(const hiprz_ctx* c);
+void resolve_pipeline(hiprz_ctx* c);
 bool use_lds_scene(const hiprz_ctx* c);
+bool resident_active(const hiprz_ctx* c) { return c->pipeline == 2; }
 // rays are reordered where the walk is bound by scattered fetches: scenes not staged in LDS, split pipeline
 bool sort_enabled(const hiprz_ctx* c) {
     if (c->pipeline != 1 || c->sort_rays == 0) return false;
@@ -836,6 +1017,16 @@ int effective_mode(const hiprz_ctx* c) {
     return c->dscene.mesh_stack_entries <= 2u ? 2 : 1;
 }
 
+void resolve_pipeline(hiprz_ctx* c) {
+    if (c->pipeline_setting >= 0) c->pipeline = c->pipeline_setting;
+    else {
+        // resident needs blob + walk workspace + 8 KiB of parked state per workgroup, four workgroups per CU
+        const size_t lds = size_t(c->dscene.hot_bytes) + size_t(c->stack_entries) * 1024u + BinnedLds::kFixedBytes + 8u * 1024u;
+        const bool mode_ok = c->traversal_mode == -1 || c->traversal_mode == 1 || c->traversal_mode == 2;  // walks the batch kernel has
+        c->pipeline = (c->have_scene && c->lds_scene && c->lds_scene_override != 0 && mode_ok && lds <= 40u * 1024u) ? 2 : 1;
+    }
+}
+
 constexpr uint32_t kTopCacheNodes = 682u;  // 682 x 36 B = 24 KiB per workgroup: ~9 levels of every tree, 5 workgroups per CU
 
 constexpr size_t kLdsSceneLimit = 52u * 1024u;  // per workgroup: 3 x 52 KiB < 160 KiB per CU
@@ -854,7 +1045,7 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
     const bool lds_scene = use_lds_scene(c);
     const size_t blob = lds_scene ? c->dscene.hot_bytes : 0u;
     int mode = effective_mode(c);
-    if ((mode == 3 || mode == 4) && (lds_scene || c->pipeline != 1)) mode = 1;  // the top cache is for scenes that are not staged whole, in the trace kernel
+    if (mode >= 3 && (lds_scene || c->pipeline != 1)) mode = 1;  // the top cache is for scenes that are not staged whole, in the trace kernel
     const size_t stack_lds = size_t(c->stack_entries) * 256u * sizeof(uint32_t);
     const size_t walk_lds = mode == 2 ? size_t(BinnedLds::bytes_host(c->dscene.world_stack_entries, c->dscene.mesh_stack_entries))
                             : mode == 1 ? stack_lds : 0u;
@@ -867,6 +1058,21 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
         if (mode == 4) {
             const uint32_t pools = (c->n_local_tiles + RZ_POOL_FACTOR - 1u) / RZ_POOL_FACTOR;
             hipLaunchKernelGGL((rz_trace_persistent_kernel<FIRST, COUNT>), dim3(pools), block, c->dscene.wtop_count * 36u + 16u, c->stream, c->dscene, c->dcamera, f);
+        } else if (mode == 5) {
+            // round 0 over all owned pixels, then one launch per scheduled round over the rays the previous one queued
+            // (the grid is sized for the worst case; workgroups past the queue's end return at once)
+            const uint32_t rounds = uint32_t(c->requeue_thresholds.size());
+            const size_t top_lds = TopCache::bytes_host(c->dscene.top_count);
+            (void)hipMemsetAsync(c->rq_counts.ptr, 0, (rounds + 2u) * sizeof(uint32_t), c->stream);
+            for (uint32_t r = 0; r <= rounds; ++r) {
+                const int in = int((r + 1u) & 1u), out = int(r & 1u);
+                DRequeue q{c->rq0[in].ptr, c->rq1[in].ptr, c->rq2[in].ptr, c->rq0[out].ptr, c->rq1[out].ptr, c->rq2[out].ptr,
+                           c->rq_counts.ptr, r, r < rounds ? c->requeue_thresholds[r] : 0u};
+                if (r == 0 && rounds > 0) hipLaunchKernelGGL((rz_trace_requeue_kernel<FIRST, COUNT, true, true>), grid, block, top_lds, c->stream, c->dscene, c->dcamera, f, q);
+                else if (r == 0) hipLaunchKernelGGL((rz_trace_requeue_kernel<FIRST, COUNT, true, false>), grid, block, top_lds, c->stream, c->dscene, c->dcamera, f, q);
+                else if (r < rounds) hipLaunchKernelGGL((rz_trace_requeue_kernel<FIRST, COUNT, false, true>), grid, block, top_lds, c->stream, c->dscene, c->dcamera, f, q);
+                else hipLaunchKernelGGL((rz_trace_requeue_kernel<FIRST, COUNT, false, false>), grid, block, top_lds, c->stream, c->dscene, c->dcamera, f, q);
+            }
         } else if (mode == 3) hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 3, false>), grid, block, TopCache::bytes_host(c->dscene.top_count), c->stream, c->dscene, c->dcamera, f);
         else if (mode == 2) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 2, true>), (rz_trace_kernel<FIRST, COUNT, 2, false>), walk_lds, c->dscene, c->dcamera, f);
         else if (mode == 1) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 1, true>), (rz_trace_kernel<FIRST, COUNT, 1, false>), walk_lds, c->dscene, c->dcamera, f);
@@ -881,6 +1087,33 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
         else RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 0, true>), (rz_pass_kernel<FIRST, COUNT, 0, false>), fused_lds, c->dscene, c->dcamera, cfg, f);
     }
 #undef RZ_LAUNCH
+}
+
+// resident pipeline: all `n` cumulative passes of the batch in one launch (+ one launch that advances the pass index)
+template <bool COUNT>
+void launch_batch(hiprz_ctx* c, const DFrame& f, uint32_t n, hipEvent_t before = nullptr, hipEvent_t after = nullptr) {
+    const dim3 grid(c->xcd_swizzle ? ((c->n_local_tiles + 7u) / 8u) * 8u : c->n_local_tiles), block(256);
+    const DConfig cfg = make_config(c);
+    const bool lds_scene = use_lds_scene(c);
+    const size_t blob = lds_scene ? c->dscene.hot_bytes : 0u;
+    int mode = effective_mode(c);
+    if (mode != 2) mode = 1;
+    const size_t stack_lds = size_t(c->stack_entries) * 256u * sizeof(uint32_t);
+    const size_t walk_lds = mode == 2 ? size_t(BinnedLds::bytes_host(c->dscene.world_stack_entries, c->dscene.mesh_stack_entries)) : stack_lds;
+    const size_t park = 8u * 1024u;
+    const size_t lds = blob + walk_lds + park;
+    const uint32_t park_offset = uint32_t(walk_lds);
+    if (before) (void)hipEventRecord(before, c->stream);
+    if (mode == 2) {
+        if (lds_scene) hipLaunchKernelGGL((rz_batch_kernel<COUNT, 2, true>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);
+        else hipLaunchKernelGGL((rz_batch_kernel<COUNT, 2, false>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);
+    } else {
+        if (lds_scene) hipLaunchKernelGGL((rz_batch_kernel<COUNT, 1, true>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);
+        else hipLaunchKernelGGL((rz_batch_kernel<COUNT, 1, false>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);
+    }
+    if (after) (void)hipEventRecord(after, c->stream);
+    hipLaunchKernelGGL(rz_pass_add_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr, n);
+    c->rgba8_valid = true;
 }
 
 hipEvent_t take_event(hiprz_ctx* c) {
@@ -936,9 +1169,48 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     if (!c->have_scene || !c->have_camera) return fail(c, HIPRZ_ERR_STATE, "render before scene and camera upload");
     if (n_passes == 0 || c->n_local_tiles == 0) return HIPRZ_OK;
     StageTimer timer;
+    if (effective_mode(c) == 5 && c->pipeline == 1 && !use_lds_scene(c)) {
+        const size_t n = size_t(c->n_local_tiles) * 256u;
+        for (int k = 0; k < 2; ++k) {
+            RZ_HIP(c, c->rq0[k].resize(n));
+            RZ_HIP(c, c->rq1[k].resize(n));
+            RZ_HIP(c, c->rq2[k].resize(n));
+        }
+        RZ_HIP(c, c->rq_counts.resize(32));
+    }
     const DFrame f = make_frame(c, counted);
     hipEvent_t e0 = take_event(c), e1 = take_event(c);
     RZ_HIP(c, hipEventRecord(e0, c->stream));
+    c->rgba8_valid = false;
+    if (c->pipeline == 2) {
+        uint32_t remaining = n_passes;
+        if (c->reset_pending) {  // renderFirstPass: the fused kernel
+            hipLaunchKernelGGL(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+            if (counted) launch_pass<true, true>(c, f);
+            else launch_pass<true, false>(c, f);
+            hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+            c->reset_pending = false;
+            c->passes = 1;
+            c->ray_count = c->owned_pixels;
+            remaining -= 1u;
+        }
+        if (remaining) {
+            c->kernel_event_passes = 0;
+            if (counted) launch_batch<true>(c, f, remaining);
+            else if (c->time_kernels) {  // bench.py's roofline: the batch kernel's own duration
+                while (c->kernel_events.size() < 3u) {
+                    hipEvent_t e = nullptr;
+                    (void)hipEventCreate(&e);
+                    c->kernel_events.push_back(e);
+                }
+                launch_batch<false>(c, f, remaining, c->kernel_events[0], c->kernel_events[1]);
+                c->kernel_event_passes = remaining;
+            } else launch_batch<false>(c, f, remaining);
+            c->passes += remaining;
+            c->ray_count += uint64_t(remaining) * c->owned_pixels;
+        }
+        return finish_batch(c, e0, e1, n_passes, timer);
+    }
     if (c->use_graph && !c->time_kernels && !counted && !c->reset_pending && n_passes >= 2) {
         // steady state: one graph launch instead of 2 * n_passes kernel launches
         if (!c->graph_valid || c->graph_passes != n_passes) {
@@ -1253,7 +1525,7 @@ int hiprz_destroy(hiprz_ctx* c) {
     c->hot.release(), c->wnodes.release(), c->wskip.release(), c->node_skip.release(), c->textures.release();
     c->texels.release(), c->spot_lights.release(), c->direct_lights.release();
     release_frame(c);
-    c->pass_dev.release(), c->counters_dev.release(), c->pick_dev.release();
+    c->pass_dev.release(), c->counters_dev.release(), c->pick_dev.release(), c->rq_counts.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return HIPRZ_OK;
@@ -1382,6 +1654,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     // still fit into the CU's 160 KiB together with their traversal stacks.
     c->lds_scene = size_t(d.hot_bytes) + size_t(c->stack_entries) * 1024u + BinnedLds::kFixedBytes <= kLdsSceneLimit;
     c->have_scene = true;
+    resolve_pipeline(c);
     c->reset_pending = true;  // world changed => accumulation restarts (cpu_engine_renderer.cpp:108-112)
     c->timings.set("upload scene", timer.ms());
     return HIPRZ_OK;
@@ -1447,8 +1720,28 @@ int hiprz_set_shard(hiprz_ctx* c, uint32_t rank, uint32_t world) {
 int hiprz_set_traversal_mode(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
     c->graph_valid = false;
-    if (mode < -1 || mode > 4) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: -1 = auto, 0 = threaded, 1 = LDS stack, 2 = workgroup-binned, 3 = skip links + LDS-cached tree tops, 4 = persistent lanes on the flat walk graph");
+    if (mode < -1 || mode > 5) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: -1 = auto, 0 = threaded, 1 = LDS stack, 2 = workgroup-binned, 3 = skip links + LDS-cached tree tops, 4 = persistent lanes on the flat walk graph, 5 = mode 3 in rounds with ray requeueing");
     c->traversal_mode = mode;
+    resolve_pipeline(c);
+    return HIPRZ_OK;
+}
+
+int hiprz_set_requeue_schedule(hiprz_ctx* c, const uint32_t* thresholds, uint32_t n_rounds) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    c->graph_valid = false;
+    if (n_rounds > 30u || (n_rounds && !thresholds)) return fail(c, HIPRZ_ERR_INVALID, "requeue schedule: at most 30 bailing rounds");
+    for (uint32_t r = 0; r < n_rounds; ++r)
+        if (thresholds[r] > 64u) return fail(c, HIPRZ_ERR_INVALID, "requeue schedule: a threshold is a lane count (0..64)");
+    c->requeue_thresholds.assign(thresholds, thresholds + n_rounds);
+    return HIPRZ_OK;
+}
+
+int hiprz_requeue_counts(hiprz_ctx* c, uint32_t* counts_out, uint32_t n) {
+    if (!c || !counts_out) return HIPRZ_ERR_INVALID;
+    for (uint32_t i = 0; i < n; ++i) counts_out[i] = 0u;
+    if (!c->rq_counts.ptr) return HIPRZ_OK;
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    RZ_HIP(c, hipMemcpy(counts_out, c->rq_counts.ptr, sizeof(uint32_t) * std::min<uint32_t>(n, 32u), hipMemcpyDeviceToHost));
     return HIPRZ_OK;
 }
 
@@ -1457,14 +1750,22 @@ int hiprz_set_lds_scene(hiprz_ctx* c, int mode) {
     c->graph_valid = false;
     if (mode < -1 || mode > 1) return fail(c, HIPRZ_ERR_INVALID, "lds scene: -1 auto, 0 off, 1 on");
     c->lds_scene_override = mode;
+    resolve_pipeline(c);
     return HIPRZ_OK;
 }
 
 int hiprz_set_pipeline(hiprz_ctx* c, int pipeline) {
     if (!c) return HIPRZ_ERR_INVALID;
     c->graph_valid = false;
-    if (pipeline != 0 && pipeline != 1) return fail(c, HIPRZ_ERR_INVALID, "pipeline: 0 = fused pass kernel, 1 = trace kernel + shade kernel");
-    c->pipeline = pipeline;
+    if (pipeline < -1 || pipeline > 2) return fail(c, HIPRZ_ERR_INVALID, "pipeline: -1 = per scene, 0 = fused pass kernel, 1 = trace kernel + shade kernel, 2 = resident (one launch per batch of passes)");
+    c->pipeline_setting = pipeline;
+    resolve_pipeline(c);
+    return HIPRZ_OK;
+}
+
+int hiprz_pipeline(hiprz_ctx* c, int* out) {
+    if (!c || !out) return HIPRZ_ERR_INVALID;
+    *out = c->pipeline;
     return HIPRZ_OK;
 }
 
@@ -1527,6 +1828,7 @@ int hiprz_tonemap(hiprz_ctx* c) {
     if (!c) return HIPRZ_ERR_INVALID;
     if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "tonemap before camera upload");
     (void)hipSetDevice(c->device);
+    if (c->rgba8_valid && !c->reset_pending) return HIPRZ_OK;  // the resident kernel already wrote this frame's pixels
     const uint32_t n = c->n_local_tiles * 256u;
     if (n)
         hipLaunchKernelGGL(rz_tonemap_tiles_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->accum.ptr, c->rgba8.ptr, n,
@@ -1725,6 +2027,15 @@ int hiprz_kernel_breakdown_ms(hiprz_ctx* c, double* trace_ms, double* shade_ms, 
     RZ_HIP(c, hipStreamSynchronize(c->stream));
     *trace_ms = *shade_ms = 0.0;
     *passes = 0;
+    if (resident_active(c)) {  // one launch for all the passes of the batch: reported as "trace"
+        if (c->kernel_event_passes) {
+            float a = 0;
+            RZ_HIP(c, hipEventElapsedTime(&a, c->kernel_events[0], c->kernel_events[1]));
+            *trace_ms = a;
+            *passes = c->kernel_event_passes;
+        }
+        return HIPRZ_OK;
+    }
     if (c->pipeline != 1) return HIPRZ_OK;
     for (uint32_t i = 0; i < c->kernel_event_passes; ++i) {
         float a = 0, b = 0;

@@ -23,6 +23,9 @@ namespace hiprz {
 #ifndef RZ_TRACE_SHARED_RCP   // ... in the split pipeline's trace kernel (lean enough not to spill with it)
 #define RZ_TRACE_SHARED_RCP 1
 #endif
+#ifndef RZ_BATCH_SHARED_RCP   // ... in the resident pipeline's batch kernel
+#define RZ_BATCH_SHARED_RCP 1
+#endif
 #ifndef RZ_MIN_WAVES
 #define RZ_MIN_WAVES 4
 #endif
@@ -1036,6 +1039,122 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
     return hit.instance >= 0 ? 2 : 1;
 }
 
+// ---- MODE 5: the MODE 3 walk in ROUNDS, with ray requeueing ----
+// A wave lasts as long as its slowest ray and ray cost is heavy-tailed (config D: the slowest of 64 rays is ~12x the mean;
+// 13 % lane utilisation in MODE 3).  Here a lane that is inside a mesh walk with fewer than `threshold` companions left in
+// that loop stops ("bails"): it stores its walk state (world leaf, slot, mesh node, closest hit so far: 48 B) into a queue
+// and the NEXT round's kernel resumes those rays in dense waves.  The last round never bails.  A ray executes exactly the
+// tests of MODE 3, in the same order, whichever round they happen in: resuming re-derives the mesh-space ray from the same
+// inputs (same instructions) and re-tests nothing.
+struct WalkResume {
+    uint32_t n, i, m;  // world-tree leaf, slot in tlas_order, next mesh node
+    bool in_mesh, found;
+    float lr_far;      // mesh-space far (closest hit so far in this mesh)
+};
+#define RZ_REQUEUE_MIN_STEPS 2u
+// returns 0 root box missed, 1 nothing hit, 2 hit, 3 bailed (rs + ray.near_/far_ + hit hold the state to resume from)
+template <bool COUNT, bool RCP, bool CAN_BAIL>
+RZ_DEV int closest_hit_requeue(const DScene& s, const TopCache& top, Ray& ray, Hit& hit, WalkResume& rs, uint32_t threshold, Counters& cnt) {
+    const bool scene_fast = s.fast_div != 0u;
+    WalkRay g;
+    g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
+    prepare<RCP>(g, scene_fast);
+    uint32_t n = rs.n, guard = 0u;
+    bool resume = rs.in_mesh;
+    while (n != RZ_END) {
+        RZ_GUARD(guard);
+        float4 n0, n1;
+        uint32_t link;
+        fetch_node(s, top, n, n0, n1, link);
+        const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+        uint32_t i = begin;
+        if (resume) {
+            i = rs.i;  // n is the leaf the ray was in: its box test is done
+        } else {
+            RZ_COUNT(box_tests);
+            if (!box_hit<RCP>(n0, n1, g)) {
+                if (n == s.tlas_root) return 0;  // root box missed (cpu_engine_kernel.cpp:283)
+                n = link;
+                continue;
+            }
+            if (!(meta & HIPRZ_NODE_LEAF)) {
+                n = begin;
+                continue;
+            }
+        }
+        const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
+        for (; i < end; ++i) {
+            const uint32_t inst = s.tlas_order[i];
+            if (!resume) {
+                float4 ib0, ib1;
+                load_instance_box(s, inst, ib0, ib1);
+                RZ_COUNT(box_tests);
+                if (!box_hit<RCP>(ib0, ib1, g)) continue;
+            }
+            const InstanceXform x = load_instance_xform(s, inst);
+            WalkRay lr;
+            const float len = to_local<RCP>(x, g, lr, scene_fast);
+            bool found = false;
+            uint32_t m = x.blas_root;
+            if (resume) {
+                found = rs.found, m = rs.m, lr.far_ = rs.lr_far;
+                resume = false;
+            }
+            uint32_t steps = 0u;
+            while (true) {
+                if constexpr (CAN_BAIL) {
+                    if (steps >= RZ_REQUEUE_MIN_STEPS && uint32_t(__popcll(__ballot(1))) < threshold) {
+                        rs.n = n, rs.i = i, rs.m = m, rs.in_mesh = true, rs.found = found, rs.lr_far = lr.far_;
+                        ray.near_ = g.near_, ray.far_ = g.far_;
+                        return 3;
+                    }
+                    steps += 1u;
+                }
+                uint32_t leaf_begin = 0u, leaf_end = 0u;
+                while (m != RZ_END) {
+                    RZ_GUARD(guard);
+                    float4 m0, m1;
+                    uint32_t mlink;
+                    fetch_node(s, top, m, m0, m1, mlink);
+                    RZ_COUNT(box_tests);
+                    if (box_hit<RCP>(m0, m1, lr)) {
+                        const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
+                        if (!(mmeta & HIPRZ_NODE_LEAF)) {
+                            m = mbegin;
+                            continue;
+                        }
+                        leaf_begin = mbegin, leaf_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
+                        m = mlink;
+                        if (leaf_end > leaf_begin) break;
+                        continue;
+                    }
+                    m = mlink;
+                }
+                if (leaf_end == leaf_begin) break;
+                for (uint32_t j = leaf_begin; j < leaf_end; ++j) {
+                    const float4 a = s.tris[3 * j], b = s.tris[3 * j + 1], c = s.tris[3 * j + 2];
+                    float t, b1, b2, det;
+                    RZ_COUNT(tri_tests);
+                    if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
+                        lr.far_ = t;
+                        hit.triangle = j;
+                        hit.external = det > 0.0f;
+                        hit.bx = b1, hit.by = b2;
+                        found = true;
+                    }
+                }
+            }
+            if (found) {
+                hit.instance = int32_t(inst);
+                g.near_ = lr.near_ / len;
+                g.far_ = lr.far_ / len;
+            }
+        }
+        n = link;
+    }
+    ray.near_ = g.near_, ray.far_ = g.far_;
+    return hit.instance >= 0 ? 2 : 1;
+}
 
 // ---- MODE 4: persistent lanes on the flat walk graph ----
 // A wave is as slow as its slowest ray, and the cost of a ray is heavy-tailed (config D: 7x between the mean and the

@@ -82,6 +82,21 @@ class Context:
     def set_pipeline(self, pipeline):
         self._check(self.lib.hiprz_set_pipeline(self._ctx, pipeline))
 
+    def set_requeue_schedule(self, thresholds):
+        """Mode 5: lanes that must remain in a mesh walk per bailing round (see include/hiprz.h)."""
+        arr = (C.c_uint32 * max(len(thresholds), 1))(*thresholds)
+        self._check(self.lib.hiprz_set_requeue_schedule(self._ctx, arr, len(thresholds)))
+
+    def pipeline(self):
+        v = C.c_int()
+        self._check(self.lib.hiprz_pipeline(self._ctx, C.byref(v)))
+        return v.value
+
+    def requeue_counts(self, n=32):
+        arr = (C.c_uint32 * n)()
+        self._check(self.lib.hiprz_requeue_counts(self._ctx, arr, n))
+        return list(arr)
+
     def traversal_mode(self):
         v = C.c_int()
         self._check(self.lib.hiprz_traversal_mode(self._ctx, C.byref(v)))

@@ -172,6 +172,29 @@ def test_split_pipeline_equals_fused(built, mode):
             assert np.array_equal(out[0][2][k], out[1][2][k]), k
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_resident_pipeline_equals_split(built, mode):
+    """One launch per batch (state and accumulator in registers across passes, tone map on the way out) == one or two
+    launches per pass, bit for bit: accumulator, path state, RGBA8 and counters; also sharded."""
+    for world, depth in ((scenes.cornell_box(160, 96), 4), (scenes.living_room(96, 64, 16), 5), (scenes.cornell_sphere(128, 72, 32), 6)):
+        flat, cam = flatten(world), camera_struct(world.camera)
+        cfg = RenderConfig(LightSampling(2, 1), Tracing(depth, 4)).struct()
+        for shard in ((0, 1), (1, 3)):
+            out = []
+            for pipeline in (1, 2):
+                c = Context(0)
+                c.set_traversal_mode(mode), c.set_pipeline(pipeline), c.set_shard(*shard)
+                c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+                counters = [c.render_counted(3), c.render_counted(2)]
+                c.render(5), c.render(1), c.render(4)
+                c.tonemap()
+                out.append((c.read_accum(), c.read_rgba8(), c.read_state(), counters))
+            assert out[0][3] == out[1][3]
+            assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+            for k in out[0][2]:
+                assert np.array_equal(out[0][2][k], out[1][2][k]), k
+
+
 def test_ray_reordering_changes_nothing_but_the_order(built):
     """Sorted walk order (keys from the shade kernel, radix sort, permutation) == pixel order, bit for bit."""
     for world, depth, mode in ((scenes.cornell_sphere(160, 90, 40), 6, 3), (scenes.living_room(96, 64, 16), 5, 4), (scenes.cornell_box(100, 60), 4, 1)):
@@ -188,6 +211,30 @@ def test_ray_reordering_changes_nothing_but_the_order(built):
         assert np.array_equal(out[0][0], out[1][0]) and out[0][2] == out[1][2]
         for k in out[0][1]:
             assert np.array_equal(out[0][1][k], out[1][1][k]), k
+
+
+@pytest.mark.parametrize("schedule", [[64, 64, 64, 64, 64, 64, 64, 64], [32, 16], [1], []])
+def test_requeue_rounds_equal_single_walk(built, schedule):
+    """MODE 5 (rays stop when their wave runs thin, are queued and resumed in dense waves by the next round) gives the
+    results AND the work counters of the uninterrupted MODE 3 walk, whatever the schedule — [64]*8 stops every mesh walk
+    after two steps in each of eight rounds, [] never stops."""
+    for world, depth in ((scenes.cornell_sphere(160, 90, 40), 6), (scenes.living_room(96, 64, 16), 5)):
+        flat, cam = flatten(world), camera_struct(world.camera)
+        cfg = RenderConfig(LightSampling(1, 1), Tracing(depth, 4)).struct()
+        out = []
+        for mode in (3, 5):
+            c = Context(0)
+            c.set_traversal_mode(mode), c.set_lds_scene(0), c.set_ray_sort(0)
+            if mode == 5:
+                c.set_requeue_schedule(schedule)
+            c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+            counters = [c.render_counted(1), c.render_counted(2)]
+            c.render(4), c.render(4)   # graph capture + replay
+            out.append((c.read_accum(), c.read_depth(), c.read_state(), counters))
+        assert out[0][3] == out[1][3]
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        for k in out[0][2]:
+            assert np.array_equal(out[0][2][k], out[1][2][k]), k
 
 
 def test_graph_replay_equals_eager_launches(built):
@@ -227,7 +274,7 @@ def test_shared_reciprocal_division_is_exact(built):
 
 
 @pytest.mark.parametrize("name", ["cornell_128", "living_room_96x64", "sphere_160x90"])
-@pytest.mark.parametrize("mode", [4, 3, 2, 1, 0])
+@pytest.mark.parametrize("mode", [5, 4, 3, 2, 1, 0])
 def test_gpu_matches_committed_golden(built, name, mode):
     """Same comparison without the oracle in the loop: committed fixtures (tests/golden)."""
     from test_golden_oracle import load_golden

@@ -5,7 +5,7 @@ set -eo pipefail
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$R/build/ab; mkdir -p $OUT
 cd $R/rayzath_amd/csrc
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. --offload-arch=gfx950 -fno-gpu-rdc"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -I../../include -I. --offload-arch=gfx950 -fhip-fp32-correctly-rounded-divide-sqrt -fno-gpu-rdc"
 while [ $# -ge 2 ]; do
   name=$1; defs=$2; shift 2
   ( /opt/rocm/bin/hipcc $FLAGS $defs -c hiprz_api.hip -o $OUT/api_$name.o -Rpass-analysis=kernel-resource-usage 2>&1 | grep -E "Function Name|     VGPRs:|Occupancy" | sed 's/.*remark: *//; s/\[-Rpass.*//' | grep -A2 "rz_pass_kernelILb0ELb0ELi1ELb1" | tr '\n' ' '; echo " <- $name"
