@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="B", help="scene preset of rayzath_amd/scenes.py (B = the quoted config)")
     ap.add_argument("--traversal", type=int, default=-1, help="-1 per-scene choice (default), 1 nested walk with LDS stack, 2 workgroup-binned, 0 threaded, 3 skip links + LDS tree tops, 4 persistent lanes, 5 = 3 in requeue rounds")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather on the render stream instead of overlapping it with the next step's rendering")
     ap.add_argument("--requeue", type=str, default="", help="mode 5 schedule: comma-separated lane thresholds per bailing round")
     ap.add_argument("--pipeline", type=int, default=-1, help="0 fused pass kernel, 1 trace + shade kernels, 2 resident batch kernel (-1: chosen per scene)")
     ap.add_argument("--ray-sort", type=int, default=-1, help="-1 auto, 0 off, 1 on")
@@ -123,7 +124,7 @@ def main():
     ctx.upload_scene(flat)
     ctx.upload_camera(cam)
     ctx.set_config(cfg)
-    frame = ShardedFrame(ctx, rank, world, W, H, dist if world > 1 else None, torch.device("cuda", local_rank))
+    frame = ShardedFrame(ctx, rank, world, W, H, dist if world > 1 else None, torch.device("cuda", local_rank), overlap=not args.no_overlap)
 
     def step():
         ctx.render(RPP)
@@ -143,7 +144,7 @@ def main():
     if args.verify_gather and world > 1:  # the assembled frame must equal what a single shard-less context renders
         ctx.render(RPP)
         img = frame.gather_accum()
-        ctx.sync()
+        frame.sync()
         if rank == 0:
             ref = Context(local_rank)
             ref.set_traversal_mode(args.traversal)

@@ -339,6 +339,11 @@ int hiprz_untile_rgba8(hiprz_ctx* ctx, const void* src_device_tiles, uint32_t ra
 /* Scatter tile-major float4 tiles of shard (rank, world) into a row-major W*H*16 device image. */
 int hiprz_untile_accum(hiprz_ctx* ctx, const void* src_device_tiles, uint32_t rank, uint32_t world,
                        void* dst_device_image);
+/* The gathered tiles of all `world` shards (shard r starts at src_parts + r * part_stride_bytes; element_bytes 4 =
+ * RGBA8, 16 = float4) -> row-major W*H device image, in one launch on `stream` (a hipStream_t; NULL = the context's
+ * stream) — the stream the gather itself ran on. */
+int hiprz_untile_gathered(hiprz_ctx* ctx, const void* src_parts, uint32_t world, size_t part_stride_bytes, uint32_t element_bytes,
+                          void* dst_device_image, void* stream);
 /* Tone-map a row-major W*H float4 device image into W*H RGBA8 (device pointers). */
 int hiprz_tonemap_image(hiprz_ctx* ctx, const void* src_device_image, void* dst_device_rgba8);
 void* hiprz_stream(hiprz_ctx* ctx); /* the hipStream_t all of the above are enqueued on */

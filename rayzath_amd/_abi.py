@@ -132,6 +132,7 @@ ENTRY_POINTS = {
     "hiprz_local_pixel_capacity": (C.c_int, [P, C.POINTER(SZ)]),
     "hiprz_export_accum_tiles": (C.c_int, [P, P, SZ]),
     "hiprz_export_rgba8_tiles": (C.c_int, [P, P, SZ]),
+    "hiprz_untile_gathered": (C.c_int, [P, C.c_void_p, C.c_uint32, C.c_size_t, C.c_uint32, C.c_void_p, C.c_void_p]),
     "hiprz_untile_rgba8": (C.c_int, [P, P, U32, U32, P]),
     "hiprz_untile_accum": (C.c_int, [P, P, U32, U32, P]),
     "hiprz_tonemap_image": (C.c_int, [P, P, P]),

@@ -629,6 +629,17 @@ __global__ void __launch_bounds__(256) rz_untile_kernel(const T* tiles, T* image
     const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
     if (x < width && y < height) image[size_t(y) * width + x] = tiles[size_t(blockIdx.x) * 256u + threadIdx.x];
 }
+// the gathered tiles of ALL shards (shard r at tiles + r * part_stride elements) -> row-major full frame, one launch
+template <typename T>
+__global__ void __launch_bounds__(256) rz_untile_gathered_kernel(const T* tiles, size_t part_stride, T* image, uint32_t width, uint32_t height,
+                                                                 uint32_t tiles_x, uint32_t n_tiles, uint32_t world) {
+    const uint32_t rank = blockIdx.y, tile = blockIdx.x * world + rank;
+    if (tile >= n_tiles) return;
+    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    if (x < width && y < height) image[size_t(y) * width + x] = tiles[rank * part_stride + size_t(blockIdx.x) * 256u + threadIdx.x];
+}
 __global__ void __launch_bounds__(256) rz_untile_state_kernel(const float4* st0, const float4* st1, const float2* st2, float* ray9,
                                                               uint32_t* md2, uint32_t width, uint32_t height, uint32_t tiles_x,
                                                               uint32_t rank, uint32_t world) {
@@ -1923,6 +1934,29 @@ int hiprz_untile_rgba8(hiprz_ctx* c, const void* src_tiles, uint32_t rank, uint3
         hipLaunchKernelGGL((rz_untile_kernel<uint32_t>), dim3(n_local), dim3(256), 0, c->stream,
                            reinterpret_cast<const uint32_t*>(src_tiles), reinterpret_cast<uint32_t*>(dst_image), c->camera.width,
                            c->camera.height, c->tiles_x, rank, world);
+    RZ_HIP(c, hipGetLastError());
+    return HIPRZ_OK;
+}
+int hiprz_untile_gathered(hiprz_ctx* c, const void* src_parts, uint32_t world, size_t part_stride_bytes, uint32_t element_bytes,
+                          void* dst_image, void* stream) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "untile before camera upload");
+    if (!src_parts || !dst_image || world == 0 || world > 65535u || (element_bytes != 4u && element_bytes != 16u) || part_stride_bytes % element_bytes)
+        return fail(c, HIPRZ_ERR_INVALID, "untile_gathered: bad arguments");
+    (void)hipSetDevice(c->device);
+    const uint32_t n_tiles = c->tiles_x * c->tiles_y;
+    const uint32_t per_rank = (n_tiles + world - 1u) / world;
+    if (part_stride_bytes < size_t(per_rank) * 256u * element_bytes) return fail(c, HIPRZ_ERR_INVALID, "untile_gathered: part stride smaller than a shard");
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    if (n_tiles) {
+        const dim3 grid(per_rank, world);
+        if (element_bytes == 4u)
+            hipLaunchKernelGGL((rz_untile_gathered_kernel<uint32_t>), grid, dim3(256), 0, st, reinterpret_cast<const uint32_t*>(src_parts),
+                               part_stride_bytes / 4u, reinterpret_cast<uint32_t*>(dst_image), c->camera.width, c->camera.height, c->tiles_x, n_tiles, world);
+        else
+            hipLaunchKernelGGL((rz_untile_gathered_kernel<float4>), grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src_parts),
+                               part_stride_bytes / 16u, reinterpret_cast<float4*>(dst_image), c->camera.width, c->camera.height, c->tiles_x, n_tiles, world);
+    }
     RZ_HIP(c, hipGetLastError());
     return HIPRZ_OK;
 }

@@ -1,8 +1,8 @@
 """Multi-GPU frame assembly: one process per GPU, the framebuffer sharded by interleaved
 32x8-pixel tiles (tile t belongs to rank t % world; include/hiprz.h: hiprz_set_shard), the
-scene replicated, and ONE collective per readback: a gather of the tile-major RGBA32F
-accumulators to rank 0 over RCCL (torch.distributed backend "nccl") — SURVEY.md §8e.
-There is no collective on the per-pass data path: pixels are independent.
+scene replicated, and ONE collective per readback: a gather of the tile-major tone-mapped RGBA8
+tiles (or the RGBA32F accumulators) to rank 0 over RCCL (torch.distributed backend "nccl") —
+SURVEY.md §8e.  There is no collective on the per-pass data path: pixels are independent.
 
 The reference has nothing to mirror here (single device: RayZath/cuda_engine_core.cu:17).
 """
@@ -57,13 +57,17 @@ def gather_tiles(local_tiles, rank, world, capacity_max, dist, dst=0):
 class ShardedFrame:
     """Rank-local driver: renders the owned tiles and assembles full frames on rank 0.
 
-    Everything is enqueued on the context's render stream (wrapped as a torch ExternalStream, so RCCL
-    orders itself against it): render -> local tone map -> export tiles -> gather -> untile on rank 0,
-    with no host synchronisation in between.  The default readback gathers the tone-mapped RGBA8 tiles
-    (8.3 MB per 1080p frame in total, 4x less than the RGBA32F accumulators); `gather_accum` moves the
-    float accumulators instead (parity checks, float output)."""
+    Nothing synchronises with the host: render -> local tone map -> export tiles run on the context's
+    render stream (wrapped as a torch ExternalStream), gather -> untile on rank 0 run on a second,
+    high-priority stream that waits for the export (`overlap=True`, the default) — so the collective of
+    frame k overlaps the rendering of frame k+1, the way the reference's CUDA engine hands out the
+    previous frame while the next one renders (cuda_engine_core.cu:115-120, sync == false); the next export
+    waits for the previous gather, so one tile buffer is enough.  `overlap=False` keeps everything on the
+    render stream.  `sync()` waits for both.  The default readback gathers the tone-mapped RGBA8 tiles
+    (8.3 MB per 1080p frame in total, 4x less than the RGBA32F accumulators); `gather_accum` moves the float
+    accumulators instead (parity checks, float output)."""
 
-    def __init__(self, ctx, rank, world, width, height, dist=None, device=None):
+    def __init__(self, ctx, rank, world, width, height, dist=None, device=None, overlap=True):
         import torch
 
         self.ctx, self.rank, self.world, self.dist = ctx, rank, world, dist
@@ -71,11 +75,15 @@ class ShardedFrame:
         tiles_x, tiles_y = tile_grid(width, height)
         self.capacity_max = owned_tile_count(0, world, tiles_x * tiles_y) * TILE_PIXELS
         self.device = device
-        self.stream = torch.cuda.ExternalStream(ctx.stream(), device=device) if device is not None and device.type == "cuda" else None
+        on_gpu = device is not None and device.type == "cuda"
+        self.stream = torch.cuda.ExternalStream(ctx.stream(), device=device) if on_gpu else None
+        self.comm = torch.cuda.Stream(device=device, priority=-1) if on_gpu and overlap and world > 1 else self.stream
         self.local8 = torch.zeros((self.capacity_max, 1), dtype=torch.int32, device=device)
         self.local = None
         root = rank == 0
-        self.parts8 = [torch.zeros_like(self.local8) for _ in range(world)] if root and world > 1 else None
+        # the gathered shards live in ONE buffer (shard r = row r) so that one launch untiles them all
+        self.all8 = torch.zeros((world, self.capacity_max, 1), dtype=torch.int32, device=device) if root and world > 1 else None
+        self.parts8 = [self.all8[r] for r in range(world)] if self.all8 is not None else None
         self.rgba8 = torch.zeros((height, width), dtype=torch.int32, device=device) if root else None
         self.image = None
 
@@ -87,20 +95,44 @@ class ShardedFrame:
         if self.dist.get_backend() == "gloo":  # one-GPU rehearsal: stage through the host
             self.ctx.sync()
             return gather_tiles(local, self.rank, self.world, self.capacity_max, self.dist)
-        with torch.cuda.stream(self.stream):
+        if self.comm is not self.stream:
+            self.comm.wait_stream(self.stream)  # the export just enqueued on the render stream
+        with torch.cuda.stream(self.comm):
             self.dist.gather(local, gather_list=parts if self.rank == 0 else None, dst=0)
         return parts
+
+    def _before_export(self):
+        """The tile buffer is about to be rewritten: the previous frame's gather must have read it."""
+        if self.comm is not self.stream and self.comm is not None:
+            self.stream.wait_stream(self.comm)
+
+    def _untile(self, parts, gathered, image, element_bytes):
+        """Row-major frame from the gathered shards, behind the gather on its stream."""
+        ctx = self.ctx
+        if gathered is None or parts[0].data_ptr() != gathered.data_ptr():  # world 1, or the host-staged rehearsal path
+            fn = ctx.untile_rgba8 if element_bytes == 4 else ctx.untile_accum
+            for r, part in enumerate(parts):
+                fn(part.data_ptr(), r, self.world, image.data_ptr())
+            return
+        stream = self.comm.cuda_stream if self.comm is not None and self.comm is not self.stream else None
+        ctx.untile_gathered(gathered.data_ptr(), self.world, self.capacity_max * element_bytes, element_bytes, image.data_ptr(), stream)
+
+    def sync(self):
+        """Wait until every enqueued frame has been rendered and (rank 0) assembled."""
+        self.ctx.sync()
+        if self.comm is not None and self.comm is not self.stream:
+            self.comm.synchronize()
 
     def gather(self):
         """Tone-map locally, gather the RGBA8 tiles, assemble the row-major RGBA8 frame on rank 0."""
         ctx = self.ctx
         ctx.tonemap()
+        self._before_export()
         ctx.export_rgba8_tiles(self.local8.data_ptr(), self.local8.numel() * 4)
         parts = self._gather(self.local8, self.parts8)
         if self.rank != 0:
             return None
-        for r, part in enumerate(parts):
-            ctx.untile_rgba8(part.data_ptr(), r, self.world, self.rgba8.data_ptr())
+        self._untile(parts, self.all8, self.rgba8, 4)
         return self.rgba8
 
     def gather_accum(self):
@@ -110,12 +142,13 @@ class ShardedFrame:
         ctx = self.ctx
         if self.local is None:
             self.local = torch.zeros((self.capacity_max, 4), dtype=torch.float32, device=self.device)
-            self.parts = [torch.zeros_like(self.local) for _ in range(self.world)] if self.rank == 0 and self.world > 1 else None
+            self.all = torch.zeros((self.world, self.capacity_max, 4), dtype=torch.float32, device=self.device) if self.rank == 0 and self.world > 1 else None
+            self.parts = [self.all[r] for r in range(self.world)] if self.all is not None else None
             self.image = torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=self.device) if self.rank == 0 else None
+        self._before_export()
         ctx.export_accum_tiles(self.local.data_ptr(), self.local.numel() * 4)
         parts = self._gather(self.local, self.parts)
         if self.rank != 0:
             return None
-        for r, part in enumerate(parts):
-            ctx.untile_accum(part.data_ptr(), r, self.world, self.image.data_ptr())
+        self._untile(parts, self.all, self.image, 16)
         return self.image

@@ -198,6 +198,9 @@ class Context:
     def export_rgba8_tiles(self, dst_ptr, nbytes):
         self._check(self.lib.hiprz_export_rgba8_tiles(self._ctx, dst_ptr, nbytes))
 
+    def untile_gathered(self, src_ptr, world, part_stride_bytes, element_bytes, dst_ptr, stream=None):
+        self._check(self.lib.hiprz_untile_gathered(self._ctx, src_ptr, world, part_stride_bytes, element_bytes, dst_ptr, stream))
+
     def untile_rgba8(self, src_ptr, rank, world, dst_ptr):
         self._check(self.lib.hiprz_untile_rgba8(self._ctx, src_ptr, rank, world, dst_ptr))
 

@@ -10,6 +10,8 @@ indexing bit-exact"):
     crossed a geometric edge because of such an ulp (FRACTION below).
 """
 import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -369,3 +371,15 @@ def test_sharded_bench_path_rehearsal(built):
     line = [l for l in proc.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["n_gpus"] == 2 and res["value"] > 0 and res["scaling"] == "strong"
+
+
+@pytest.mark.parametrize("overlap", [1, 0])
+def test_sharded_frame_streams_with_in_process_collective(built, overlap):
+    """ShardedFrame's stream choreography (export on the render stream, gather + one-launch untile on the comm stream,
+    next export waiting for the previous gather) with both shards of a 2-GPU job living in one process: the collective is
+    a stand-in that copies the shards' tile buffers on whatever stream torch has current, as RCCL would.  Runs in a child
+    process because torch has to initialise the GPU before the library does."""
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "inprocess_gather_check.py")
+    r = subprocess.run([sys.executable, script, str(overlap)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "frames equal" in r.stdout
