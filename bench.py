@@ -237,7 +237,7 @@ def main():
                        "triangles": int(len(flat.tris)), "instances": int(len(flat.instances)),
                        "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
                        "requeued_rays_per_round": requeue_counts,
-                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned", 3: "skip-links+lds-top-cache", 4: "persistent-lanes", 5: "skip-links+requeue-rounds"}[ctx.traversal_mode()],
+                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned", 3: "skip-links+lds-top-cache", 4: "persistent-lanes", 5: "skip-links+requeue-rounds", 6: "wave-pool"}[ctx.traversal_mode()],
                        "pipeline": {0: "fused (one kernel per pass)", 1: "trace+shade (two kernels per pass)", 2: "resident (one kernel per step)"}[pipeline]},
             "spp_per_s": spp_per_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,

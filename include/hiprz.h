@@ -276,6 +276,10 @@ int hiprz_set_traversal_mode(hiprz_ctx* ctx, int mode);
 /* Mode 5 schedule: thresholds[r] (0..64) = lanes of a wave that must remain inside a mesh walk during round r for
  * it to go on; otherwise they are queued for round r+1.  After n_rounds (<= 30) rounds a final round finishes every ray. */
 int hiprz_set_requeue_schedule(hiprz_ctx* ctx, const uint32_t* thresholds, uint32_t n_rounds);
+/* Diagnostics: the split pipeline's trace kernel records the start and end time (100 MHz device clock) of each of its
+ * workgroups; start_end_out[2*b], [2*b+1] = those of workgroup b in the most recent pass.  Enable after the camera upload. */
+int hiprz_set_workgroup_timing(hiprz_ctx* ctx, int enabled);
+int hiprz_read_workgroup_times(hiprz_ctx* ctx, uint64_t* start_end_out, uint32_t n_workgroups);
 /* Diagnostics: counts_out[r] = rays the most recent pass queued for round r (r >= 1; up to 32 entries). */
 int hiprz_requeue_counts(hiprz_ctx* ctx, uint32_t* counts_out, uint32_t n);
 int hiprz_traversal_mode(hiprz_ctx* ctx, int* effective_mode_out); /* valid after hiprz_upload_scene */

@@ -112,6 +112,7 @@ struct DScene {
     uint32_t wtop_count;           // MODE 4: the same for the walk graph (wnodes / wskip)
     uint32_t top_count;            // MODE 3: the first top_count nodes (+ their links) are staged in LDS by every workgroup
     const uint32_t* node_skip;     // link to the node that follows a node's subtree (same numbering as `nodes`)
+    uint32_t walk_k, walk_l;       // MODE 3 mesh walk: node steps / triangle tests per lane per round (0 = unbounded)
 };
 
 // Re-point the blob sections at a staged copy (LDS).
@@ -157,6 +158,7 @@ struct DFrame {
     uint32_t* sort_key;    // shade kernel: sort key of the pixel's NEXT ray (nullptr = ray reordering off)
     const uint32_t* perm;  // trace kernel: thread i walks the ray of local pixel perm[i] (nullptr = identity)
     uint32_t xcd_swizzle;  // 1: workgroup b works on owned tile (b % 8) * ceil(n/8) + b / 8 (see pixel_of_thread)
+    unsigned long long* wg_times;  // diagnostics (hiprz_set_workgroup_timing): [2 * workgroup] = start, end of the trace kernel's workgroups (100 MHz clock)
 };
 
 struct v3 {
@@ -383,6 +385,19 @@ RZ_DEV bool exponent_in(float x, int lo, int hi) {
 RZ_DEV bool zero_or_exponent_in(float x, int lo, int hi) {
     return (__float_as_uint(x) & 0x7FFFFFFFu) == 0u || exponent_in(x, lo, hi);
 }
+#ifdef RZ_PHASE_STATS  // diagnostic build: wave-level executions and active lanes of the MODE 3 walk's steps (tools/phase_stats.py)
+__device__ unsigned long long rz_phase[16];
+#define RZ_PHASE(k)                                                                                        \
+    do {                                                                                                   \
+        const unsigned long long rz_a = __ballot(1);                                                       \
+        if (int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) == __ffsll((long long)rz_a) - 1) { \
+            atomicAdd(&rz_phase[2 * (k)], 1ull);                                                           \
+            atomicAdd(&rz_phase[2 * (k) + 1], (unsigned long long)__popcll(rz_a));                         \
+        }                                                                                                  \
+    } while (0)
+#else
+#define RZ_PHASE(k)
+#endif
 struct WalkRay {
     v3 o, d, y;  // y = refined reciprocal of d (valid when `fast`)
     float near_, far_;
@@ -429,7 +444,7 @@ RZ_DEV bool box_hit(float4 b0, float4 b1, const WalkRay& r) {
 #ifdef RZ_BOXPATH_STATS
     if (SHARED_RCP) {
         const unsigned long long active = __ballot(1), fast = __ballot(r.fast);
-        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) {
+        if (int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) == __ffsll((long long)active) - 1) {  // first ACTIVE lane
             atomicAdd(&rz_boxpath[fast == active ? 0 : 1], 1ull);
             atomicAdd(&rz_boxpath[2], (unsigned long long)__popcll(active));
             atomicAdd(&rz_boxpath[3], (unsigned long long)__popcll(active & ~fast));
@@ -966,6 +981,7 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
         float4 n0, n1;
         uint32_t link;
         fetch_node(s, top, n, n0, n1, link);
+        RZ_PHASE(0);
         RZ_COUNT(box_tests);
         if (box_hit<RCP>(n0, n1, g)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
@@ -978,24 +994,33 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                 const uint32_t inst = s.tlas_order[i];
                 float4 ib0, ib1;
                 load_instance_box(s, inst, ib0, ib1);
+                RZ_PHASE(1);
                 RZ_COUNT(box_tests);
                 if (!box_hit<RCP>(ib0, ib1, g)) continue;
+                RZ_PHASE(2);
                 const InstanceXform x = load_instance_xform(s, inst);
                 WalkRay lr;
                 const float len = to_local<RCP>(x, g, lr, scene_fast);
                 bool found = false;
                 uint32_t m = x.blas_root;
-                // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352, as a "while-while" walk: every lane
-                // steps through nodes until it HOLDS a leaf (or is done); only then do the lanes test their triangles,
-                // together.  (With the leaf loop nested in the node loop some lane is at a leaf in almost every step and
-                // the whole wave waits through its triangles: 11 % lane utilisation on the 301 k-triangle mesh.)
+                // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352, as a "while-while" walk in bounded
+                // rounds: lanes without a leaf step through nodes until they HOLD one (at most walk_k steps per round), then the
+                // lanes that hold a leaf test its triangles (at most walk_l per round), together.  With the leaf loop nested in
+                // the node loop some lane is at a leaf in almost every step and the whole wave waits through its triangles (11 %
+                // lane utilisation on the 301 k-triangle mesh); with unbounded phases the wave waits for the lane with the longest
+                // search, then for the one with the fullest leaf.  0 = unbounded.
+                uint32_t tj = 0u, tj_end = 0u;  // the held leaf's remaining triangles
+                const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? s.walk_l : 0xFFFFFFFFu;
                 while (true) {
-                    uint32_t leaf_begin = 0u, leaf_end = 0u;
-                    while (m != RZ_END) {
+                    RZ_PHASE(5);
+                    uint32_t k = 0u;
+                    while (tj == tj_end && m != RZ_END && k < kmax) {
                         RZ_GUARD(guard);
+                        k += 1u;
                         float4 m0, m1;
                         uint32_t mlink;
                         fetch_node(s, top, m, m0, m1, mlink);
+                        RZ_PHASE(3);
                         RZ_COUNT(box_tests);
                         if (box_hit<RCP>(m0, m1, lr)) {
                             const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
@@ -1003,21 +1028,20 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                                 m = mbegin;
                                 continue;
                             }
-                            leaf_begin = mbegin, leaf_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
-                            m = mlink;
-                            if (leaf_end > leaf_begin) break;  // hold this leaf
-                            continue;
+                            tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
                         }
                         m = mlink;
                     }
-                    if (leaf_end == leaf_begin) break;  // walk finished without another leaf
-                    for (uint32_t j = leaf_begin; j < leaf_end; ++j) {
-                        const float4 a = s.tris[3 * j], b = s.tris[3 * j + 1], c = s.tris[3 * j + 2];
+                    if (tj == tj_end && m == RZ_END) break;  // walk finished
+                    uint32_t l = 0u;
+                    for (; tj < tj_end && l < lmax; ++tj, ++l) {
+                        const float4 a = s.tris[3 * tj], b = s.tris[3 * tj + 1], c = s.tris[3 * tj + 2];
                         float t, b1, b2, det;
+                        RZ_PHASE(4);
                         RZ_COUNT(tri_tests);
                         if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
                             lr.far_ = t;
-                            hit.triangle = j;
+                            hit.triangle = tj;
                             hit.external = det > 0.0f;
                             hit.bx = b1, hit.by = b2;
                             found = true;

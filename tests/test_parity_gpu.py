@@ -276,7 +276,7 @@ def test_shared_reciprocal_division_is_exact(built):
 
 
 @pytest.mark.parametrize("name", ["cornell_128", "living_room_96x64", "sphere_160x90"])
-@pytest.mark.parametrize("mode", [5, 4, 3, 2, 1, 0])
+@pytest.mark.parametrize("mode", [6, 5, 4, 3, 2, 1, 0])
 def test_gpu_matches_committed_golden(built, name, mode):
     """Same comparison without the oracle in the loop: committed fixtures (tests/golden)."""
     from test_golden_oracle import load_golden
