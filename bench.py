@@ -217,7 +217,7 @@ def main():
             # dominant kernel = the BVH-traversal kernel.  Its algorithmic bytes: the ray it reads (40 B of path state) and
             # the hit record it writes (20 B) per segment + 32 B per box test + 36 B per triangle test of the closest-hit
             # walk (shadow-ray tests run in the shade kernel and are not counted here).
-            kernel_name = "rz_trace_kernel (closest-hit walk)"
+            kernel_name = {3: "rz_trace_skip_kernel", 5: "rz_trace_requeue_kernel", 6: "rz_trace_pool_kernel"}.get(ctx.traversal_mode(), "rz_trace_kernel") + " (closest-hit walk)"
             kernel_s = breakdown[0] / 1e3 / breakdown[2]
             kernel_bytes = (60 * counters["segments"] + 32 * (counters["box_tests"] - counters["shadow_box_tests"])
                             + 36 * (counters["tri_tests"] - counters["shadow_tri_tests"])) / RPP

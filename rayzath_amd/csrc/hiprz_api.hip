@@ -225,9 +225,9 @@ RZ_DEV int trace_path(const DScene& s, unsigned char* workspace, uint32_t* lds_c
 // everything of traceRay after the closest hit (active lanes only): returns the segment's radiance and whether the path
 // goes on, and leaves the NEXT segment's ray / colour / material / depth in `ps` (TracingResult::repositionRay, or a fresh
 // antialiased camera ray when the path ended).  ps.ray.far_ must hold the hit distance.
-template <bool COUNT>
+template <bool COUNT, int SHADOW = 1>
 RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cfg, const PixelId& p, PathState& ps, uint32_t pass,
-                          int found, const Hit& hit, uint32_t* lds_column, Counters& cnt, col4& final_color, bool& path_continues) {
+                          int found, const Hit& hit, const ShadowCtx& lds_column, Counters& cnt, col4& final_color, bool& path_continues) {
     Ray& ray = ps.ray;
     col4& ray_color = ps.color;
     uint32_t& ray_material = ps.material;
@@ -276,7 +276,7 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
         next_direction = sample_direction(ray.d, ray_material, sf, rng);
         point = (ray.o + ray.d * ray.far_) + sf.normal * (0.0001f * ray.far_);
 
-        const col4 direct = direct_illumination<1, COUNT>(s, cfg, lds_column, ray.d, ray_material, point, next_direction, sf, rng, cnt);
+        const col4 direct = direct_illumination<SHADOW, COUNT>(s, cfg, lds_column, ray.d, ray_material, point, next_direction, sf, rng, cnt);
         final_color = final_color + (direct * ray_color) * lerp(splat(1.0f), sf.color, sf.metalness);
         ray_color = lerp(ray_color, ray_color * sf.color, sf.tint_factor);  // ColorF::Blend
     }
@@ -294,13 +294,13 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
 }
 
 // shade_segment + accumulation + next-segment state to HBM (renderFirstPass / renderCumulativePass after traceRay)
-template <bool FIRST, bool COUNT>
+template <bool FIRST, bool COUNT, int SHADOW = 1>
 RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& cfg, const DFrame& f, const PixelId& p, PathState& ps,
-                            int found, const Hit& hit, uint32_t* lds_column, Counters& cnt) {
+                            int found, const Hit& hit, const ShadowCtx& lds_column, Counters& cnt) {
     const float hit_distance = ps.ray.far_;
     col4 final_color;
     bool path_continues;
-    shade_segment<COUNT>(s, cam, cfg, p, ps, FIRST ? 0u : *f.pass, found, hit, lds_column, cnt, final_color, path_continues);
+    shade_segment<COUNT, SHADOW>(s, cam, cfg, p, ps, FIRST ? 0u : *f.pass, found, hit, lds_column, cnt, final_color, path_continues);
     const Ray& ray = ps.ray;
     const col4& ray_color = ps.color;
     const uint32_t ray_material = ps.material, depth = ps.depth;
@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene
     } else {
         found = trace_path<MODE, COUNT, RZ_FUSED_SHARED_RCP != 0>(s, workspace, lds_column, p.active, ps.ray, hit, cnt);
     }
-    if (p.active) shade_and_store<FIRST, COUNT>(s, cam, cfg, f, p, ps, found, hit, lds_column, cnt);
+    if (p.active) shade_and_store<FIRST, COUNT>(s, cam, cfg, f, p, ps, found, hit, ShadowCtx{lds_column, TopCache{nullptr, nullptr, 0u}}, cnt);
     flush_counters<COUNT>(f, p.active ? 1u : 0u, cnt);
 }
 
@@ -421,7 +421,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_batch_kernel(const DScen
         if (p.active) {
             col4 final_color;
             bool path_continues;
-            shade_segment<COUNT>(s, cam, cfg, p, ps, pass0 + i, found, hit, lds_column, cnt, final_color, path_continues);
+            shade_segment<COUNT>(s, cam, cfg, p, ps, pass0 + i, found, hit, ShadowCtx{lds_column, TopCache{nullptr, nullptr, 0u}}, cnt, final_color, path_continues);
             park[4 * 256] = __float_as_uint(__uint_as_float(park[4 * 256]) + final_color.r);
             park[5 * 256] = __float_as_uint(__uint_as_float(park[5 * 256]) + final_color.g);
             park[6 * 256] = __float_as_uint(__uint_as_float(park[6 * 256]) + final_color.b);
@@ -789,12 +789,23 @@ __global__ void __launch_bounds__(256, RZ_TRACE_MIN_WAVES) rz_trace_persistent_k
     flush_counters<COUNT>(f, 0u, cnt);
 }
 
-template <bool FIRST, bool COUNT, bool LDS_SCENE>
-__global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f) {
+// SHADOW: the shadow-ray walk — 1 = nested loops with the per-lane LDS stack (scenes staged in LDS), 3 = skip links with the
+// tree tops staged in LDS instead of a stack (everything else; `top_n` nodes).
+template <bool FIRST, bool COUNT, bool LDS_SCENE, int SHADOW>
+__global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f, uint32_t top_n) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
     DScene s = scene_in;
     unsigned char* workspace = rz_lds + stage_scene<LDS_SCENE>(s, rz_lds);
-    uint32_t* lds_column = stack_column<1>(workspace);
+    ShadowCtx shadow{stack_column<1>(workspace), TopCache{nullptr, nullptr, 0u}};
+    if constexpr (SHADOW == 3) {
+        float4* ln = reinterpret_cast<float4*>(workspace);
+        uint32_t* ls = reinterpret_cast<uint32_t*>(workspace + top_n * 32u);
+        for (uint32_t i = threadIdx.x; i < 2u * top_n; i += 256u) ln[i] = s.nodes[i];
+        for (uint32_t i = threadIdx.x; i < top_n; i += 256u) ls[i] = s.node_skip[i];
+        __syncthreads();
+        shadow.lds_column = nullptr;
+        shadow.top = TopCache{ln, ls, top_n};
+    }
     const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
     Counters cnt;
     if (p.active) {
@@ -808,7 +819,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScen
         hit.bx = h0.y, hit.by = h0.z, hit.triangle = __float_as_uint(h0.w);
         hit.instance = found == 2 ? int32_t(h1 & 0x1FFFFFFFu) : -1;
         hit.external = (h1 & 0x80000000u) != 0u;
-        shade_and_store<FIRST, COUNT>(s, cam, cfg, f, p, ps, found, hit, lds_column, cnt);
+        shade_and_store<FIRST, COUNT, SHADOW>(s, cam, cfg, f, p, ps, found, hit, shadow, cnt);
     } else if (f.sort_key && p.local < f.n_local_tiles * 256u) {
         f.sort_key[p.local] = 0x00FFFFFFu;  // slots outside the frame sort to the end
     }
@@ -1075,6 +1086,7 @@ struct hiprz_ctx {
     DeviceArray<unsigned long long> wg_times;  // diagnostics: start / end clock of every trace-kernel workgroup of the last pass
     bool wg_timing = false;
     uint32_t pool_threshold = 32u;  // MODE 6: lanes that must be inside meshes for the mesh phase to go on while others could join
+    int shade_shadow_walk = 3;  // shade kernel of scenes not staged in LDS: 3 = skip links + staged tree tops, 1 = LDS stack (HIPRZ_SHADOW_WALK)
     int trace_wg = 64;    // MODE 3 trace kernel: 64 = one wave per workgroup (rz_trace_skip_kernel); HIPRZ_TRACE_WG=256: the 256-thread kernel
     int trace_waves = 0;  // 0 = by tree size; HIPRZ_TRACE_WAVES = 4 | 6 forces the register budget
     uint32_t n_nodes = 0;
@@ -1330,7 +1342,12 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
         else if (mode == 1) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 1, true>), (rz_trace_kernel<FIRST, COUNT, 1, false>), walk_lds, c->dscene, c->dcamera, f);
         else RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 0, true>), (rz_trace_kernel<FIRST, COUNT, 0, false>), walk_lds, c->dscene, c->dcamera, f);
         if (between_trace_and_shade) (void)hipEventRecord(between_trace_and_shade, c->stream);
-        RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, true>), (rz_shade_kernel<FIRST, COUNT, false>), stack_lds, c->dscene, c->dcamera, cfg, f);
+        // shadow rays: LDS-stack walk on a staged scene, skip-link walk with staged tree tops otherwise (no lights: no walk at all)
+        const bool lights = c->dscene.n_spot_lights + c->dscene.n_direct_lights != 0u;
+        const uint32_t shade_top = std::min<uint32_t>(c->dscene.top_count, kTopCacheNodes);
+        if (lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, 1>), grid, block, blob + stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        else if (lights && c->shade_shadow_walk == 3) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, 3>), grid, block, TopCache::bytes_host(shade_top), c->stream, c->dscene, c->dcamera, cfg, f, shade_top);
+        else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, 1>), grid, block, stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
     } else {
         // the fused kernel's shadow rays use the stack walk: its columns must exist in every mode
         const size_t fused_lds = mode == 0 ? stack_lds : walk_lds;
@@ -1755,6 +1772,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
         if (v == 64 || v == 256) c->trace_wg = v;
     }
     if (const char* w = std::getenv("HIPRZ_TRACE_WAVES")) c->trace_waves = std::atoi(w);
+    if (const char* w = std::getenv("HIPRZ_SHADOW_WALK")) c->shade_shadow_walk = std::atoi(w) == 1 ? 1 : 3;
     c->device = device_id;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = c->pass_dev.resize(1);

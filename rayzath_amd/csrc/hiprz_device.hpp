@@ -1063,6 +1063,82 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
     return hit.instance >= 0 ? 2 : 1;
 }
 
+// anyIntersection (cpu_engine_kernel.cpp:398-481) on skip links, with the tree tops from LDS: the shadow-ray walk of the
+// kernels that have a TopCache.  Same tests in the same order as any_hit_stack; returns the mask's alpha (0 or 1).
+template <bool COUNT, bool RCP>
+RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, Counters& cnt) {
+    const bool scene_fast = s.fast_div != 0u;
+    WalkRay g;
+    g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
+    prepare<RCP>(g, scene_fast);
+    uint32_t n = s.tlas_root, guard = 0u;
+    while (n != RZ_END) {
+        RZ_GUARD(guard);
+        float4 n0, n1;
+        uint32_t link;
+        fetch_node(s, top, n, n0, n1, link);
+        RZ_COUNT(box_tests);
+        RZ_COUNT(shadow_box_tests);
+        if (box_hit<RCP>(n0, n1, g)) {
+            const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+            if (!(meta & HIPRZ_NODE_LEAF)) {
+                n = begin;
+                continue;
+            }
+            const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
+            for (uint32_t i = begin; i < end; ++i) {
+                const uint32_t inst = s.tlas_order[i];
+                float4 ib0, ib1;
+                load_instance_box(s, inst, ib0, ib1);
+                RZ_COUNT(box_tests);
+                RZ_COUNT(shadow_box_tests);
+                if (!box_hit<RCP>(ib0, ib1, g)) continue;
+                const InstanceXform x = load_instance_xform(s, inst);
+                WalkRay lr;
+                to_local<RCP>(x, g, lr, scene_fast);
+                uint32_t m = x.blas_root;
+                // anyIntersection(const Mesh&, ...) :450-481, in the bounded while-while rounds of closest_hit_skip
+                uint32_t tj = 0u, tj_end = 0u;
+                const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? s.walk_l : 0xFFFFFFFFu;
+                while (true) {
+                    uint32_t k = 0u;
+                    while (tj == tj_end && m != RZ_END && k < kmax) {
+                        RZ_GUARD(guard);
+                        k += 1u;
+                        float4 m0, m1;
+                        uint32_t mlink;
+                        fetch_node(s, top, m, m0, m1, mlink);
+                        RZ_COUNT(box_tests);
+                        RZ_COUNT(shadow_box_tests);
+                        if (box_hit<RCP>(m0, m1, lr)) {
+                            const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
+                            if (!(mmeta & HIPRZ_NODE_LEAF)) {
+                                m = mbegin;
+                                continue;
+                            }
+                            tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
+                        }
+                        m = mlink;
+                    }
+                    if (tj == tj_end && m == RZ_END) break;
+                    uint32_t l = 0u;
+                    for (; tj < tj_end && l < lmax; ++tj, ++l) {
+                        const float4 a = s.tris[3 * tj], b = s.tris[3 * tj + 1], c = s.tris[3 * tj + 2];
+                        float t, b1, b2, det;
+                        RZ_COUNT(tri_tests);
+                        RZ_COUNT(shadow_tri_tests);
+                        if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) return 0.0f;
+                    }
+                }
+            }
+        } else if (n == s.tlas_root) {
+            return 1.0f;  // root box missed (:402)
+        }
+        n = link;
+    }
+    return 1.0f;
+}
+
 // ---- MODE 5: the MODE 3 walk in ROUNDS, with ray requeueing ----
 // A wave lasts as long as its slowest ray and ray cost is heavy-tailed (config D: the slowest of 64 rays is ~12x the mean;
 // 13 % lane utilisation in MODE 3).  Here a lane that is inside a mesh walk with fewer than `threshold` companions left in
@@ -1213,12 +1289,23 @@ RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit
     if constexpr (MODE == 0) return walk_threaded<false, COUNT>(s, ray, hit, cnt);
     else return closest_hit_stack<COUNT, RCP>(s, lds_column, ray, hit, cnt);  // MODE 2 calls closest_hit_binned directly
 }
+// what a shadow-ray walk needs besides the scene: the lane's LDS stack column (MODE 1) or the staged tree tops (MODE 3)
+struct ShadowCtx {
+    uint32_t* lds_column;
+    TopCache top;
+};
+#ifndef RZ_SHADE_SHARED_RCP   // packed shared-reciprocal box test in the shade kernel's shadow-ray walk (MODE 3)
+#define RZ_SHADE_SHARED_RCP 1
+#endif
 // anyIntersection(const RangedRay&): returns the shadow mask's alpha (0 or 1)
 template <int MODE, bool COUNT>
-RZ_DEV float any_hit(const DScene& s, uint32_t* lds_column, const Ray& ray, Counters& cnt) {
+RZ_DEV float any_hit(const DScene& s, const ShadowCtx& sc, const Ray& ray, Counters& cnt) {
+    uint32_t* lds_column = sc.lds_column;
     RZ_COUNT(shadow_rays);
     if (s.n_instances == 0) return 0.0f;
-    if constexpr (MODE == 0) {
+    if constexpr (MODE == 3) {
+        return any_hit_skip<COUNT, RZ_SHADE_SHARED_RCP != 0>(s, sc.top, ray, cnt);
+    } else if constexpr (MODE == 0) {
         Ray r = ray;
         Hit unused;
         return float(walk_threaded<true, COUNT>(s, r, unused, cnt));
@@ -1483,7 +1570,7 @@ RZ_DEV v3 sample_direction(v3 ray_d, uint32_t& ray_material, Surface& sf, Rng& r
 
 // --- next-event estimation: cpu_engine_kernel.cpp:690-865 -------------------------------
 template <int MODE, bool COUNT>
-RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, uint32_t* lds_column, v3 ray_d, uint32_t ray_material,
+RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const ShadowCtx& lds_column, v3 ray_d, uint32_t ray_material,
                                 v3 point, v3 next_dir, const Surface& sf, Rng& rng, Counters& cnt) {
     if (s.n_direct_lights == 0u && s.n_spot_lights == 0u) return splat(0.0f);  // both samplers return 0 before they read vS_pdf (:703, :758)
     const float vS_pdf = brdf(ray_d, sf, next_dir);
