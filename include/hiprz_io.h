@@ -1,0 +1,40 @@
+/* hiprz_io.h — C-ABI of the host library (libhiprz_host.so): scene files for the HIPGPU backend.
+ *
+ * Replaces, for this backend's stand-alone host side, what RayZath's core library does in
+ *   Loader::loadScene / JsonLoader::load     (RayZath/loader.cpp:1039-1055, json_loader.cpp:1062-1117)  .json scenes
+ *   OBJLoader::parseOBJ / loadInstances      (RayZath/loader.cpp:667-737, 738-1035)                      .obj geometry
+ *   MTLLoader::parseMTL                      (RayZath/loader.cpp:334-638)                                .mtl materials
+ *   JsonSaver / OBJSaver / MTLSaver          (RayZath/json_saver.cpp, saver.cpp)                         writers
+ * and hands the result over as the POD snapshot hiprz_upload_scene / hiprz_upload_camera take (include/hiprz.h).
+ * The C++ interface underneath is rayzath_amd/csrc/scene_io.hpp.  Plain pointers and sizes only. */
+#ifndef HIPRZ_IO_H
+#define HIPRZ_IO_H
+
+#include "hiprz.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hiprz_scene_file hiprz_scene_file;
+
+/* Load `path`: a .json scene, or an .obj (one instance per `o`/`g`, materials from its mtllibs, default camera).
+ * On success *out owns the flattened scene; on failure (HIPRZ_ERR_INVALID) *out is NULL and hiprz_io_last_error()
+ * says why.  Problems inside the file that the reference only logs (unknown statements, bad indices, missing
+ * maps ...) do not fail the call: read them with hiprz_scene_file_log. */
+int hiprz_scene_file_load(const char* path, hiprz_scene_file** out);
+void hiprz_scene_file_free(hiprz_scene_file* file);
+const hiprz_scene* hiprz_scene_file_scene(const hiprz_scene_file* file);   /* valid until hiprz_scene_file_free */
+const hiprz_camera* hiprz_scene_file_camera(const hiprz_scene_file* file);
+/* "[message] ...\n[warning] ...\n[error] ...\n" in the reference's LoadResult order */
+const char* hiprz_scene_file_log(const hiprz_scene_file* file);
+uint32_t hiprz_scene_file_error_count(const hiprz_scene_file* file);
+uint32_t hiprz_scene_file_warning_count(const hiprz_scene_file* file);
+/* Write the loaded world back: `kind` 0 = .json with inline meshes, 1 = .obj + .mtl next to it. */
+int hiprz_scene_file_save(const hiprz_scene_file* file, const char* path, int kind);
+const char* hiprz_io_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

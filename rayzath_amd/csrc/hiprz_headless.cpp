@@ -1,0 +1,43 @@
+// hiprz_headless — command line of the headless runner (Application/main.cpp:41-77):
+//   hiprz_headless --headless <tasks.json> [report_dir] [-r] [--device N] [--quiet]
+//   hiprz_headless --format <integer>        prints scientificWithPrefix(integer) (used by the tests)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "headless.hpp"
+
+int main(int argc, char** argv) {
+    std::string task_file, report_dir;
+    bool save_images = false, quiet = false, headless = false;
+    int device = 0;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "-h" || a == "--help") {
+            std::printf("usage: %s --headless <task_path> [report_path] [-r|--render] [--device N] [--quiet]\n", argv[0]);
+            return 0;
+        } else if (a == "--format" && i + 1 < argc) {
+            std::printf("%s\n", RayZath::Hip::Headless::scientificWithPrefix(std::strtoull(argv[++i], nullptr, 10)).c_str());
+            return 0;
+        } else if (a == "--headless") {
+            headless = true;
+            if (i + 1 < argc && argv[i + 1][0] != '-') task_file = argv[++i];
+            if (i + 1 < argc && argv[i + 1][0] != '-') report_dir = argv[++i];
+        } else if (a == "-r" || a == "--render") {
+            save_images = true;
+        } else if (a == "--device" && i + 1 < argc) {
+            device = std::atoi(argv[++i]);
+        } else if (a == "--quiet") {
+            quiet = true;
+        } else {
+            std::fprintf(stderr, "unknown argument %s\n", a.c_str());
+            return 2;
+        }
+    }
+    if (!headless || task_file.empty()) {
+        std::fprintf(stderr, "usage: %s --headless <task_path> [report_path] [-r] (this host side has no UI)\n", argv[0]);
+        return 2;
+    }
+    return RayZath::Hip::Headless::run(task_file, report_dir, save_images, device, quiet);
+}

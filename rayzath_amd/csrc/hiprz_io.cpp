@@ -1,0 +1,64 @@
+// hiprz_io.cpp — the C-ABI of include/hiprz_io.h over scene_io.hpp.
+#include "hiprz_io.h"
+
+#include <string>
+
+#include "scene_io.hpp"
+
+using namespace RayZath::Hip;
+
+struct hiprz_scene_file {
+    World world;
+    FlatScene flat;
+    hiprz_scene scene{};
+    hiprz_camera camera{};
+    IO::LoadLog log;
+    std::string log_text;
+};
+
+namespace {
+thread_local std::string g_error;
+}
+
+extern "C" {
+
+int hiprz_scene_file_load(const char* path, hiprz_scene_file** out) {
+    if (out) *out = nullptr;
+    if (!path || !out) return g_error = "null argument", HIPRZ_ERR_INVALID;
+    auto* f = new hiprz_scene_file();
+    try {
+        const std::string p = path;
+        if (p.size() > 4 && p.compare(p.size() - 4, 4, ".obj") == 0) IO::loadObjInstances(p, f->world, f->log);
+        else IO::loadScene(p, f->world, f->log);
+        f->flat = flatten(f->world);
+        f->scene = f->flat.view();
+        f->camera = cameraRecord(f->world.camera);
+        f->log_text = f->log.str();
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        delete f;
+        return HIPRZ_ERR_INVALID;
+    }
+    *out = f;
+    return HIPRZ_OK;
+}
+void hiprz_scene_file_free(hiprz_scene_file* f) { delete f; }
+const hiprz_scene* hiprz_scene_file_scene(const hiprz_scene_file* f) { return f ? &f->scene : nullptr; }
+const hiprz_camera* hiprz_scene_file_camera(const hiprz_scene_file* f) { return f ? &f->camera : nullptr; }
+const char* hiprz_scene_file_log(const hiprz_scene_file* f) { return f ? f->log_text.c_str() : ""; }
+uint32_t hiprz_scene_file_error_count(const hiprz_scene_file* f) { return f ? uint32_t(f->log.errors.size()) : 0u; }
+uint32_t hiprz_scene_file_warning_count(const hiprz_scene_file* f) { return f ? uint32_t(f->log.warnings.size()) : 0u; }
+int hiprz_scene_file_save(const hiprz_scene_file* f, const char* path, int kind) {
+    if (!f || !path) return g_error = "null argument", HIPRZ_ERR_INVALID;
+    try {
+        if (kind == 0) IO::saveScene(path, f->world);
+        else if (kind == 1) IO::saveOBJ(path, f->world);
+        else return g_error = "kind: 0 = .json, 1 = .obj + .mtl", HIPRZ_ERR_INVALID;
+    } catch (const std::exception& e) {
+        g_error = e.what();
+        return HIPRZ_ERR_INVALID;
+    }
+    return HIPRZ_OK;
+}
+const char* hiprz_io_last_error(void) { return g_error.c_str(); }
+}

@@ -397,7 +397,7 @@ def flatten(world, backend=None):
             rec["kind"], rec["height"], rec["width"] = t.kind, t.bitmap.shape[0], t.bitmap.shape[1]
             rec["offset"] = len(pool)
             rec["scale"], rec["translation"], rec["rotation"] = t.scale, t.translation, t.rotation
-            rec["cos_rotation"], rec["sin_rotation"] = F32(np.cos(t.rotation)), F32(np.sin(t.rotation))
+            rec["cos_rotation"], rec["sin_rotation"] = _cosf(F32(t.rotation)), _sinf(F32(t.rotation))
             pool.extend(t.bitmap.tobytes())
             tex_index[id(t)] = len(tex_records)
             tex_records.append(rec)
@@ -458,12 +458,12 @@ def flatten(world, backend=None):
     for i, l in enumerate(world.spot_lights):
         r = spots[i]
         r["position"], r["size"], r["direction"], r["emission"] = l.position, l.size, _normalize3(l.direction), l.emission
-        r["color"], r["angle"], r["cos_angle"] = l.color, l.beam_angle, F32(np.cos(F32(l.beam_angle)))
+        r["color"], r["angle"], r["cos_angle"] = l.color, l.beam_angle, _cosf(F32(l.beam_angle))
     directs = np.zeros(len(world.direct_lights), dtype=_abi.direct_light_dtype)
     for i, l in enumerate(world.direct_lights):
         r = directs[i]
         r["direction"], r["emission"], r["color"] = _normalize3(l.direction), l.emission, l.color
-        r["angular_size"], r["cos_angular_size"] = l.angular_size, F32(np.cos(F32(l.angular_size)))
+        r["angular_size"], r["cos_angular_size"] = l.angular_size, _cosf(F32(l.angular_size))
 
     return FlatScene(
         nodes=np.concatenate(node_parts) if node_parts else np.zeros(0, _abi.node_dtype), tlas_root=0, tlas_order=order,
@@ -492,7 +492,17 @@ def camera_struct(cam, backend=None):
 
 _libm = C.CDLL("libm.so.6")
 _libm.tanf.restype, _libm.tanf.argtypes = C.c_float, [C.c_float]
+_libm.cosf.restype, _libm.cosf.argtypes = C.c_float, [C.c_float]
+_libm.sinf.restype, _libm.sinf.argtypes = C.c_float, [C.c_float]
 
 
 def _tanf(x):
     return F32(_libm.tanf(float(x)))
+
+
+def _cosf(x):  # the C++ host side hoists the same values with std::cos / std::sin on floats: both hosts give the same bits
+    return F32(_libm.cosf(float(x)))
+
+
+def _sinf(x):
+    return F32(_libm.sinf(float(x)))

@@ -1,0 +1,272 @@
+"""Scene files: the C++ readers of the host library (include/hiprz_io.h, after RayZath/json_loader.cpp and
+RayZath/loader.cpp) against the Python scene model — a scene written to .json / .obj / .mtl and read back must flatten to
+the byte-identical snapshot the engine uploads — plus the statements, defaults and conventions the reference's loaders
+implement (OBJ z flip, swapped-winding fans, negative indices, per-mesh component ranges, MTL conversions, JSON colours,
+name references, generate statements, comments)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from rayzath_amd import _abi, scene_io, scenes
+from rayzath_amd._lib import HiprzError
+from rayzath_amd.scene import (Camera, DirectLight, Instance, Material, Mesh, SpotLight, World, camera_struct, flatten,
+                               generate_cube, generate_plane, generate_sphere)
+
+
+def same_snapshot(a, b):
+    for k in a.FIELDS:
+        x, y = getattr(a, k), getattr(b, k)
+        assert x.dtype == y.dtype and x.shape == y.shape, k
+        assert x.tobytes() == y.tobytes(), k
+    assert a.tlas_root == b.tlas_root
+
+
+def test_host_library_exports_every_declared_entry_point():
+    lib = scene_io.host_lib()
+    header = open(os.path.join(os.path.dirname(__file__), "..", "include", "hiprz_io.h")).read()
+    for name in scene_io.IO_ENTRY_POINTS:
+        assert name + "(" in header
+        assert getattr(lib, name) is not None
+
+
+@pytest.mark.parametrize("build", [lambda: scenes.cornell_box(160, 96), lambda: scenes.cornell_sphere(128, 72, 16),
+                                   lambda: scenes.living_room(96, 64, 8)])
+def test_json_scene_round_trip_is_bit_identical(tmp_path, build):
+    """Python model -> .json (inline meshes) -> C++ JsonLoader twin -> flatten == Python flatten, camera included."""
+    world = build()
+    path = str(tmp_path / "scene.json")
+    scene_io.save_scene_json(world, path)
+    loaded = scene_io.load_scene_file(path)
+    assert loaded.errors == 0 and loaded.warnings == 0, loaded.log
+    same_snapshot(flatten(world), loaded.flat)
+    assert bytes(camera_struct(world.camera)) == bytes(loaded.camera)
+    # and the C++ writer: loaded world -> .json -> loaded again
+    again = str(tmp_path / "again.json")
+    loaded.save(again, "json")
+    same_snapshot(loaded.flat, scene_io.load_scene_file(again).flat)
+
+
+def untransformed(world):
+    """.obj carries no instance transforms and no camera: the same world with identity transforms and the default camera."""
+    w = World()
+    for m in world.materials:
+        w.add(m)
+    for inst in world.instances:
+        w.add(Instance(inst.mesh, inst.materials))
+    return w
+
+
+@pytest.mark.parametrize("build", [lambda: scenes.cornell_box(64, 64), lambda: scenes.cornell_sphere(64, 64, 12)])
+def test_obj_mtl_round_trip(tmp_path, build):
+    """Python model -> .obj + .mtl -> OBJLoader twin: z flipped twice, fans re-read in the original corner order, every
+    mesh gets exactly its own range of the file's components; MTL Kd/d/Ni/Pm/Pr/Ke restore the materials."""
+    world = untransformed(build())
+    # MTL colours are floats: use colours that survive c/255 -> uint8(c*255) (the reference truncates, loader.cpp:486-488)
+    for m in world.materials:
+        m.color = tuple(int(np.uint8(np.float32(np.float32(c) / np.float32(255.0)) * np.float32(255.0))) for c in m.color)
+    path = str(tmp_path / "model.obj")
+    scene_io.save_obj(world, path)
+    loaded = scene_io.load_scene_file(path)
+    assert loaded.errors == 0, loaded.log
+    # shared meshes are written once per instance, so compare instance by instance through a world that does the same
+    expanded = World()
+    for m in world.materials:
+        expanded.add(m)
+    for inst in world.instances:
+        mesh = inst.mesh
+        expanded.add(Instance(Mesh(mesh.vertices, mesh.tri_vertices, mesh.texcrds if len(mesh.texcrds) else None,
+                                   mesh.tri_texcrds if len(mesh.texcrds) else None, mesh.normals if len(mesh.normals) else None,
+                                   mesh.tri_normals if len(mesh.normals) else None, mesh.tri_materials), inst.materials))
+    want = flatten(expanded)
+    for k in ("nodes", "tlas_order", "tris", "tri_attrs", "instances", "inst_materials"):
+        assert getattr(want, k).tobytes() == getattr(loaded.flat, k).tobytes(), k
+    # materials: world + default + the library's, in file order
+    got, exp = loaded.flat.materials, want.materials
+    assert len(got) == len(exp)
+    for name in ("color", "metalness", "emission", "ior", "scattering"):
+        assert np.array_equal(got[name], exp[name]), name
+    assert np.allclose(got["roughness"], exp["roughness"], atol=0)
+
+
+def test_obj_statements(tmp_path):
+    """Negative indices, polygons up to 8 corners, v/t/n forms, statements before the first `o`, usemtl slots, zero normals,
+    per-mesh component ranges (loader.cpp:738-1035)."""
+    (tmp_path / "lib.mtl").write_text("newmtl red\nKd 1 0 0\nnewmtl blue\nKd 0 0 1\nNs 10\nTr 0.25\nNi 0.5\n")
+    (tmp_path / "m.obj").write_text("""# comment
+mtllib lib.mtl
+v 9 9 9
+f 1 1 1
+o first
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+v 0.5 1.5 0
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+vn 0 0 1
+vn 0 0 0
+usemtl red
+f 2/1/1 3/2/1 4/3/1 5/4/1 6/4/1
+usemtl blue
+f -5 -4 -3
+g second
+v 2 0 1
+v 3 0 1
+v 3 1 1
+usemtl blue
+f 7//2 8//2 9//2
+bogus statement
+""")
+    log = scene_io.load_scene_file(str(tmp_path / "m.obj"))
+    assert "has to be preceded by object or group declaration" in log.log
+    assert "normal is invalid" in log.log and "Unrecognized statement \"bogus\"" in log.log
+    assert "Value for \"Ni\" was less than 1.0" in log.log
+    f = log.flat
+    assert len(f.instances) == 2 and len(f.tris) == 3 + 1 + 1   # pentagon -> 3 triangles
+    # source order of the pentagon fan: (0, 2, 1), (0, 3, 2), (0, 4, 3) over corners 2 3 4 5 6 -> z flipped
+    tris = f.tris[np.argsort(f.tris["source_index"][:4], kind="stable")] if False else f.tris
+    first = [t for t in tris[:4]]
+    by_src = sorted(first, key=lambda t: int(t["source_index"]))
+    assert np.allclose(by_src[0]["v1"], [0, 0, 0]) and np.allclose(by_src[0]["v2"], [1, 1, 0]) and np.allclose(by_src[0]["v3"], [1, 0, 0])
+    assert np.allclose(by_src[2]["v2"], [0.5, 1.5, 0])
+    # the negative-index face refers to the last five vertices read so far: v2 v3 v4 (file indices), fanned (0, 2, 1)
+    assert np.allclose(by_src[3]["v1"], [0, 0, 0]) and np.allclose(by_src[3]["v2"], [1, 1, 0])
+    # second mesh: z = 1 in the file -> -1; its normal index 2 is the zero normal replaced by (0, 1, 0)
+    second = f.tris[4]
+    assert np.allclose(second["v1"][2], -1.0)
+    assert np.allclose(f.tri_attrs[4]["n1"], [0, 1, 0])
+    # materials: slot 0 = red, slot 1 = blue for the first instance; slot 0 = blue for the second
+    mats = f.materials
+    red, blue = 2, 3
+    assert tuple(mats[red]["color"]) == (255, 0, 0, 255)
+    assert tuple(mats[blue]["color"]) == (0, 0, 255, int(np.uint8(np.float32(0.75) * np.float32(255))))
+    assert np.isclose(mats[blue]["roughness"], 1.0 - np.log10(np.float32(10)) / np.log10(np.float32(1000)))
+    assert mats[blue]["ior"] == 1.0
+    assert list(f.inst_materials[:2]) == [red, blue] and int(f.inst_materials[2]) == blue
+
+
+def test_json_statements(tmp_path):
+    """Colours as floats / ints, references by name, inline material objects, generate statements, comments, world
+    materials, the first ENABLED camera, light defaults (json_loader.cpp)."""
+    (tmp_path / "tri.obj").write_text("o tri\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    doc = """{
+  // a comment, as the reference's parser accepts
+  "Objects": {
+    "Material": [ {"name": "gold", "generate gold": {}}, {"name": "half", "color": [0.5, 0.25, 1.0], "roughness": 7, "ior": 0.2} ],
+    "Mesh": [ {"name": "cube", "generate cube": {}}, {"name": "quad", "generate plane": {"resolution": 4, "width": 2.0, "height": 3.0}},
+              {"name": "ball", "generate sphere": {"resolution": 8, "normals": true, "texcrds": false}}, {"file": "tri.obj"} ],
+    "Camera": [ {"name": "off", "enabled": false, "resolution": [10, 10]},
+                {"name": "on", "position": [0, 1, -3], "resolution": [320, 200], "near far": [0.5, 50.0], "fov": 1.0} ],
+    "SpotLight": [ {"position": [0, 2, 0]} ],
+    "DirectLight": [ {"direction": [0, -1, 1], "color": [255, 0, 0], "size": 0.2} ],
+    "Instance": [ {"name": "a", "Mesh": "cube", "Material": "gold", "position": [1, 2, 3]},
+                  {"name": "b", "Mesh": "quad", "Material": ["half", {"name": "inline", "emission": 5.0}], "scale": [2, 2, 2]},
+                  {"name": "c", "Mesh": "ball", "Material": "nope"},
+                  {"name": "d", "Mesh": "tri"} ],
+    "Group": [ {"name": "g", "objects": ["a"]} ]
+  },
+  "Material": {"color": [10, 20, 30, 0], "emission": 2.5},
+  "DefaultMaterial": {"generate mirror": {}}
+}"""
+    path = tmp_path / "scene.json"
+    path.write_text(doc)
+    s = scene_io.load_scene_file(str(path))
+    f = s.flat
+    assert "Reference to material \"nope\"" in s.log and "Groups are not applied" in s.log
+    assert s.errors == 1
+    m = f.materials
+    assert tuple(m[0]["color"]) == (10, 20, 30, 0) and m[0]["emission"] == 2.5 and m[0]["ior"] == 1.0       # world medium keeps ior 1
+    assert tuple(m[1]["color"]) == (0xF0, 0xF0, 0xF0, 0xFF) and np.isclose(m[1]["metalness"], 0.9)          # default <- mirror
+    gold, half, inline = m[2], m[3], m[4]
+    # "generate ..." is honoured for the world / default material only (loadMaterial, json_loader.cpp:252-281); a material of
+    # the object list goes through doLoadMaterial alone (:190-251), so "generate gold" there leaves the defaults
+    assert tuple(gold["color"]) == (0xC0, 0xC0, 0xC0, 0xFF) and gold["metalness"] == 0.0 and gold["ior"] == 1.5
+    assert tuple(half["color"]) == (127, 63, 255, 255) and half["roughness"] == 1.0 and half["ior"] == 1.0   # clamped
+    assert inline["emission"] == 5.0 and inline["ior"] == 1.5
+    assert s.camera.width == 320 and s.camera.height == 200 and np.isclose(s.camera.near_far[0], 0.5) and np.isclose(s.camera.fov, 1.0)
+    assert len(f.spot_lights) == 1 and f.spot_lights[0]["emission"] == 100.0 and np.isclose(f.spot_lights[0]["size"], 0.5)
+    assert np.allclose(f.direct_lights[0]["direction"], np.array([0, -1, 1]) / np.sqrt(2)) and tuple(f.direct_lights[0]["color"]) == (255, 0, 0, 255)
+    assert len(f.instances) == 4 and np.allclose(f.instances[0]["position"], [1, 2, 3]) and np.allclose(f.instances[1]["scale"], [2, 2, 2])
+    assert len(f.tris) == 12 + 2 + (2 * 8 + 2 * 8 * (8 // 2 - 2)) + 1
+    assert list(f.inst_materials[:3]) == [2, 3, 4]
+    # generated meshes equal the Python restatements of world.cpp (libm vs numpy sin/cos: a few ulp)
+    w = World()
+    w.add(Instance(generate_plane(4, 2.0, 3.0), [], scale=(2, 2, 2)))
+    ref = flatten(w)
+    quad = f.tris[12:14]
+    for k in ("v1", "v2", "v3"):
+        assert np.allclose(np.sort(quad[k], axis=0), np.sort(ref.tris[k], axis=0), atol=1e-6)
+
+
+def test_maps_from_pnm_files(tmp_path):
+    """map_Kd / norm / map_Pr / map_Ke with -o and -s; binary PPM and PGM are decoded, anything else is logged."""
+    rgb = bytes([255, 0, 0, 0, 255, 0, 0, 0, 255, 10, 20, 30])
+    (tmp_path / "t.ppm").write_bytes(b"P6\n# c\n2 2\n255\n" + rgb)
+    (tmp_path / "g.pgm").write_bytes(b"P5 2 1 255\n" + bytes([0, 255]))
+    (tmp_path / "m.mtl").write_text('newmtl a\nmap_Kd -o 0.5 0.25 -s 2 3 t.ppm\nnorm "t.ppm"\nmap_Pr g.pgm\nmap_Ke g.pgm\nmap_Pm missing.png\n')
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\no x\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\n")
+    s = scene_io.load_scene_file(str(tmp_path / "m.obj"))
+    assert "missing.png" in s.log and s.errors == 1
+    f = s.flat
+    mat = f.materials[2]
+    tex, nrm, rough, emis = f.textures[mat["texture"]], f.textures[mat["normal_map"]], f.textures[mat["roughness_map"]], f.textures[mat["emission_map"]]
+    assert mat["metalness_map"] == -1
+    assert (tex["width"], tex["height"], tex["kind"]) == (2, 2, _abi.TEX_RGBA8)
+    assert np.allclose(tex["translation"], [0.5, 0.25]) and np.allclose(tex["scale"], [2, 3])
+    texels = f.texels
+    assert list(texels[tex["offset"]:tex["offset"] + 8]) == [255, 0, 0, 255, 0, 255, 0, 255]
+    assert list(texels[nrm["offset"]:nrm["offset"] + 8]) == [255, 0, 0, 255, 0, 1, 0, 255]        # green negated (loader.cpp:54-66)
+    assert rough["kind"] == _abi.TEX_R8 and list(texels[rough["offset"]:rough["offset"] + 2]) == [0, 255]
+    e = np.frombuffer(texels[emis["offset"]:emis["offset"] + 8].tobytes(), dtype=np.float32)
+    assert emis["kind"] == _abi.TEX_R32F and e[0] == 0.0 and np.isclose(e[1], 1.0)
+
+
+def test_errors_do_not_cross_the_boundary_as_exceptions(tmp_path):
+    with pytest.raises(HiprzError, match="Failed to open"):
+        scene_io.load_scene_file(str(tmp_path / "nothing.json"))
+    (tmp_path / "bad.json").write_text('{"Objects": [1, 2')
+    with pytest.raises(HiprzError, match="Failed to parse"):
+        scene_io.load_scene_file(str(tmp_path / "bad.json"))
+    (tmp_path / "scene.txt").write_text("{}")
+    with pytest.raises(HiprzError, match="Unsupported extension"):
+        scene_io.load_scene_file(str(tmp_path / "scene.txt"))
+    handle = C.c_void_p(1)
+    assert scene_io.host_lib().hiprz_scene_file_load(None, C.byref(handle)) != 0 and not handle.value
+
+
+# ---- headless runner ----
+HEADLESS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rayzath_amd", "csrc", "hiprz_headless")
+
+# the known answers of the reference's own unit test of this function (Tests/text_utils.cpp:18-51)
+SCIENTIFIC = [(0, "0.000"), (1, "1.000"), (9, "9.000"), (10, "10.00"), (11, "11.00"), (54, "54.00"), (99, "99.00"), (100, "100.0"),
+              (101, "101.0"), (102, "102.0"), (999, "999.0"), (1000, "1.000K"), (1001, "1.001K"), (1010, "1.010K"), (1100, "1.100K"),
+              (9999, "9.999K"), (10000, "10.00K"), (100000, "100.0K"), (1000000, "1.000M"), (10000000, "10.00M"), (100000000, "100.0M"),
+              (1000000000, "1.000G"), (10000000000, "10.00G"), (100000000000, "100.0G"), (1000000000000, "1.000T"),
+              (10000000000000, "10.00T"), (100000000000000, "100.0T"), (1000000000000000, "1.000P"), (10000000000000000, "10.00P"),
+              (100000000000000000, "100.0P"), (1000000000000000000, "1.000E"), (10000000000000000000, "10.00E"),
+              (18446744073709551615, "18.44E")]
+
+
+def test_scientific_with_prefix_matches_the_reference_test_vectors():
+    import subprocess
+    for value, text in SCIENTIFIC:
+        out = subprocess.run([HEADLESS, "--format", str(value)], capture_output=True, text=True, check=True).stdout.strip()
+        assert out == text, (value, out, text)
+
+
+def test_headless_task_file_errors(tmp_path):
+    import subprocess
+    (tmp_path / "t.json").write_text('{"tasks": [{"engine": "HIPGPU"}]}')
+    r = subprocess.run([HEADLESS, "--headless", str(tmp_path / "t.json"), "--quiet"], capture_output=True, text=True)
+    assert r.returncode == 1 and "scene path" in r.stderr
+    (tmp_path / "u.json").write_text('{"tasks": {"scene path": "x.json", "engine": "OPENGL"}}')
+    r = subprocess.run([HEADLESS, "--headless", str(tmp_path / "u.json"), "--quiet"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unknown engine type" in r.stderr
+    r = subprocess.run([HEADLESS], capture_output=True, text=True)
+    assert r.returncode == 2
