@@ -277,7 +277,12 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
         point = (ray.o + ray.d * ray.far_) + sf.normal * (0.0001f * ray.far_);
 
         const col4 direct = direct_illumination<SHADOW, COUNT>(s, cfg, lds_column, ray.d, ray_material, point, next_direction, sf, rng, cnt);
-        final_color = final_color + (direct * ray_color) * lerp(splat(1.0f), sf.color, sf.metalness);
+        if constexpr (SHADOW == RZ_SHADOW_DEFER) {  // rz_shadow_kernel adds (direct * a) * b once it knows the shadow masks
+            lds_column.defer_done = true;
+            lds_column.defer_a = ray_color, lds_column.defer_b = lerp(splat(1.0f), sf.color, sf.metalness);
+        } else {
+            final_color = final_color + (direct * ray_color) * lerp(splat(1.0f), sf.color, sf.metalness);
+        }
         ray_color = lerp(ray_color, ray_color * sf.color, sf.tint_factor);  // ColorF::Blend
     }
     path_continues = depth < cfg.max_depth;
@@ -306,15 +311,25 @@ RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& 
     const uint32_t ray_material = ps.material, depth = ps.depth;
 
     // ---- accumulate ----
-    col4 value;
-    if constexpr (FIRST) {
-        f.depth[p.local] = hit_distance;
-        value = col4{final_color.r, final_color.g, final_color.b, float(!path_continues)};
+    if constexpr (FIRST) f.depth[p.local] = hit_distance;
+    if constexpr (SHADOW == RZ_SHADOW_DEFER) {
+        // the radiance so far + what rz_shadow_kernel needs to finish it; it also does the accumulation
+        const uint32_t bits = (path_continues ? 1u : 0u) | (lds_column.defer_done ? 2u : 0u) | (lds_column.defer_mask << 2);
+        f.nee_base[p.local] = make_float4(final_color.r, final_color.g, final_color.b, __uint_as_float(bits));
+        if (lds_column.defer_done) {
+            f.nee_a[p.local] = make_float4(lds_column.defer_a.r, lds_column.defer_a.g, lds_column.defer_a.b, lds_column.defer_a.a);
+            f.nee_b[p.local] = make_float4(lds_column.defer_b.r, lds_column.defer_b.g, lds_column.defer_b.b, lds_column.defer_b.a);
+        }
     } else {
-        const float4 acc = f.accum[p.local];
-        value = col4{acc.x + final_color.r, acc.y + final_color.g, acc.z + final_color.b, acc.w + float(!path_continues)};
+        col4 value;
+        if constexpr (FIRST) {
+            value = col4{final_color.r, final_color.g, final_color.b, float(!path_continues)};
+        } else {
+            const float4 acc = f.accum[p.local];
+            value = col4{acc.x + final_color.r, acc.y + final_color.g, acc.z + final_color.b, acc.w + float(!path_continues)};
+        }
+        f.accum[p.local] = make_float4(value.r, value.g, value.b, value.a);
     }
-    f.accum[p.local] = make_float4(value.r, value.g, value.b, value.a);
 
     // ---- next segment ----
     f.st0[p.local] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
@@ -797,6 +812,11 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScen
     DScene s = scene_in;
     unsigned char* workspace = rz_lds + stage_scene<LDS_SCENE>(s, rz_lds);
     ShadowCtx shadow{stack_column<1>(workspace), TopCache{nullptr, nullptr, 0u}};
+    if constexpr (SHADOW == RZ_SHADOW_DEFER) {
+        shadow.lds_column = nullptr;
+        shadow.nee_point = f.nee_point, shadow.nee_dir = f.nee_dir, shadow.nee_term = f.nee_term;
+        shadow.nee_stride = f.n_local_tiles * 256u;
+    }
     if constexpr (SHADOW == 3) {
         float4* ln = reinterpret_cast<float4*>(workspace);
         uint32_t* ls = reinterpret_cast<uint32_t*>(workspace + top_n * 32u);
@@ -819,11 +839,67 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScen
         hit.bx = h0.y, hit.by = h0.z, hit.triangle = __float_as_uint(h0.w);
         hit.instance = found == 2 ? int32_t(h1 & 0x1FFFFFFFu) : -1;
         hit.external = (h1 & 0x80000000u) != 0u;
+        shadow.pixel = p.local;
         shade_and_store<FIRST, COUNT, SHADOW>(s, cam, cfg, f, p, ps, found, hit, shadow, cnt);
     } else if (f.sort_key && p.local < f.n_local_tiles * 256u) {
         f.sort_key[p.local] = 0x00FFFFFFu;  // slots outside the frame sort to the end
     }
     flush_counters<COUNT>(f, p.active ? 1u : 0u, cnt);
+}
+
+// The shadow rays of a pass, deferred by rz_shade_kernel<..., RZ_SHADOW_DEFER>: anyIntersection (cpu_engine_kernel.cpp:398-481)
+// for every sample slot that holds a ray, then the sums of directLightSampling / spotLightSampling (:742-743, :789-790),
+// `final += (direct * ray_color) * lerp(1, colour, metalness)` (:160-165) and the accumulation of renderFirstPass /
+// renderCumulativePass (:42-45, :82-86), all in the order the inline path has them.  One wave per workgroup, tree tops in
+// LDS, packed box test: the walk runs at the trace kernel's occupancy instead of the shading kernel's 128 VGPRs.
+template <bool FIRST, bool COUNT, int MINW>
+__global__ void __launch_bounds__(64, MINW) rz_shadow_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f, uint32_t top_n) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
+    float4* ln = reinterpret_cast<float4*>(rz_lds);
+    uint32_t* ls = reinterpret_cast<uint32_t*>(rz_lds + top_n * 32u);
+    for (uint32_t i = threadIdx.x; i < 2u * top_n; i += 64u) ln[i] = s.nodes[i];
+    for (uint32_t i = threadIdx.x; i < top_n; i += 64u) ls[i] = s.node_skip[i];
+    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+    const PixelId p = pixel_of_local(f, cam, f.perm ? f.perm[slot] : slot);
+    Counters cnt;
+    if (p.active) {
+        const ShadowCtx sc{nullptr, TopCache{ln, ls, top_n}};
+        const float4 base = f.nee_base[p.local];
+        const uint32_t bits = __float_as_uint(base.w);
+        const bool path_continues = (bits & 1u) != 0u;
+        col4 final_color{base.x, base.y, base.z, 0.0f};
+        if (bits & 2u) {
+            const uint32_t mask = bits >> 2, stride = f.n_local_tiles * 256u;
+            const float4 o = f.nee_point[p.local];
+            auto shadowed_sum = [&](uint32_t first, uint32_t count) {
+                col4 total = splat(0.0f);
+                for (uint32_t k = first; k < first + count; ++k) {
+                    if (!(mask & (1u << k))) continue;
+                    const float4 d = f.nee_dir[size_t(k) * stride + p.local], t = f.nee_term[size_t(k) * stride + p.local];
+                    Ray sr;
+                    sr.o = V3(o.x, o.y, o.z), sr.d = V3(d.x, d.y, d.z), sr.near_ = 0.0f, sr.far_ = d.w;
+                    const col4 V_PL = splat(any_hit<3, COUNT>(s, sc, sr, cnt));
+                    total = total + (col4{t.x, t.y, t.z, t.w} * V_PL) * V_PL.a;
+                }
+                return total;
+            };
+            col4 direct_total = splat(0.0f), spot_total = splat(0.0f);
+            if (s.n_direct_lights != 0u) direct_total = div_scalar(shadowed_sum(0u, cfg.direct_samples), float(cfg.direct_samples) / float(s.n_direct_lights));
+            if (s.n_spot_lights != 0u) spot_total = div_scalar(shadowed_sum(cfg.direct_samples, cfg.spot_samples), float(cfg.spot_samples) / float(s.n_spot_lights));
+            const col4 direct = direct_total + spot_total;
+            const float4 a = f.nee_a[p.local], b = f.nee_b[p.local];
+            final_color = final_color + (direct * col4{a.x, a.y, a.z, a.w}) * col4{b.x, b.y, b.z, b.w};
+        }
+        col4 value;
+        if constexpr (FIRST) {
+            value = col4{final_color.r, final_color.g, final_color.b, float(!path_continues)};
+        } else {
+            const float4 acc = f.accum[p.local];
+            value = col4{acc.x + final_color.r, acc.y + final_color.g, acc.z + final_color.b, acc.w + float(!path_continues)};
+        }
+        f.accum[p.local] = make_float4(value.r, value.g, value.b, value.a);
+    }
+    flush_counters<COUNT>(f, 0u, cnt);
 }
 
 // passUpdate / segmentUpdate (cuda_postprocess_kernel.cu:95-104, cuda_render_kernel.cu:122-129):
@@ -1086,6 +1162,9 @@ struct hiprz_ctx {
     DeviceArray<unsigned long long> wg_times;  // diagnostics: start / end clock of every trace-kernel workgroup of the last pass
     bool wg_timing = false;
     uint32_t pool_threshold = 32u;  // MODE 6: lanes that must be inside meshes for the mesh phase to go on while others could join
+    bool sorted_this_pass = false;  // the deferred shadow kernel wants the NEXT pass's ray order: the sort then runs before it
+    bool defer_shadow_rays = true;  // HIPRZ_DEFER_SHADOWS=0: walk them inside the shade kernel
+    DeviceArray<float4> nee_base, nee_a, nee_b, nee_point, nee_dir, nee_term;
     int shade_shadow_walk = 3;  // shade kernel of scenes not staged in LDS: 3 = skip links + staged tree tops, 1 = LDS stack (HIPRZ_SHADOW_WALK)
     int trace_wg = 64;    // MODE 3 trace kernel: 64 = one wave per workgroup (rz_trace_skip_kernel); HIPRZ_TRACE_WG=256: the 256-thread kernel
     int trace_waves = 0;  // 0 = by tree size; HIPRZ_TRACE_WAVES = 4 | 6 forces the register budget
@@ -1164,6 +1243,7 @@ void release_frame(hiprz_ctx* c) {
     c->st0.release(), c->st1.release(), c->st2.release(), c->accum.release(), c->depth.release(), c->rgba8.release();
     c->hit0.release(), c->hit1.release();
     for (int k = 0; k < 2; ++k) c->rq0[k].release(), c->rq1[k].release(), c->rq2[k].release();
+    c->nee_base.release(), c->nee_a.release(), c->nee_b.release(), c->nee_point.release(), c->nee_dir.release(), c->nee_term.release();
     c->sort_keys.release(), c->sort_keys_out.release(), c->sort_iota.release(), c->sort_perm.release(), c->sort_temp.release();
     c->image_f4.release(), c->state_md.release(), c->state_ray.release();
 }
@@ -1222,6 +1302,7 @@ int allocate_frame(hiprz_ctx* c) {
 
 int effective_mode(const hiprz_ctx* c);
 void resolve_pipeline(hiprz_ctx* c);
+bool defer_shadows(const hiprz_ctx* c);
 bool use_lds_scene(const hiprz_ctx* c);
 bool resident_active(const hiprz_ctx* c) { return c->pipeline == 2; }
 // rays are reordered where the walk is bound by scattered fetches: scenes not staged in LDS, split pipeline
@@ -1243,6 +1324,8 @@ DFrame make_frame(hiprz_ctx* c, bool counted) {
     f.tiles_x = c->tiles_x, f.rank = c->rank, f.world = c->world, f.n_local_tiles = c->n_local_tiles;
     f.xcd_swizzle = c->xcd_swizzle ? 1u : 0u;
     f.wg_times = c->wg_timing ? c->wg_times.ptr : nullptr;
+    f.nee_base = c->nee_base.ptr, f.nee_a = c->nee_a.ptr, f.nee_b = c->nee_b.ptr;
+    f.nee_point = c->nee_point.ptr, f.nee_dir = c->nee_dir.ptr, f.nee_term = c->nee_term.ptr;
     const bool sorting = sort_enabled(c);
     f.sort_key = sorting ? c->sort_keys.ptr : nullptr;
     f.perm = sorting ? c->sort_perm.ptr : nullptr;  // always a valid permutation (identity until the first sort)
@@ -1263,6 +1346,13 @@ int effective_mode(const hiprz_ctx* c) {
     // iteration pays for the instance-entry / exit / refill blocks.)
     if (!c->lds_scene && c->pipeline == 1) return 3;
     return c->dscene.mesh_stack_entries <= 2u ? 2 : 1;
+}
+
+// Shadow rays get their own kernel when the scene has lights, is not staged in LDS (split pipeline) and the sample slots of a
+// segment fit the 30-bit mask of the hand-over record.
+bool defer_shadows(const hiprz_ctx* c) {
+    return c->defer_shadow_rays && c->pipeline == 1 && !use_lds_scene(c) && c->dscene.n_spot_lights + c->dscene.n_direct_lights != 0u &&
+           c->config.spot_samples + c->config.direct_samples <= 30u;
 }
 
 void resolve_pipeline(hiprz_ctx* c) {
@@ -1286,8 +1376,10 @@ bool use_lds_scene(const hiprz_ctx* c) {
     return c->lds_scene;
 }
 
+void launch_sort(hiprz_ctx* c);
 template <bool FIRST, bool COUNT>
 void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_shade = nullptr) {
+    c->sorted_this_pass = false;
     // with the XCD swizzle the grid is padded to a multiple of 8 workgroups (the extra ones find no tile)
     const dim3 grid(c->xcd_swizzle ? ((c->n_local_tiles + 7u) / 8u) * 8u : c->n_local_tiles), block(256);
     const DConfig cfg = make_config(c);
@@ -1346,7 +1438,18 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
         const bool lights = c->dscene.n_spot_lights + c->dscene.n_direct_lights != 0u;
         const uint32_t shade_top = std::min<uint32_t>(c->dscene.top_count, kTopCacheNodes);
         if (lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, 1>), grid, block, blob + stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-        else if (lights && c->shade_shadow_walk == 3) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, 3>), grid, block, TopCache::bytes_host(shade_top), c->stream, c->dscene, c->dcamera, cfg, f, shade_top);
+        else if (lights && defer_shadows(c)) {
+            // shading without shadow walks, then every shadow ray of the pass in a lean single-wave kernel
+            hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+            // the shadow rays start where the next segment's rays start: walk them in the order the next trace kernel will use
+            // (origin cell + direction of the next ray), so that a wave's rays meet the same instances
+            launch_sort(c);
+            const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;
+            const uint32_t top_n = std::min<uint32_t>(c->dscene.top_count, big_trees ? 170u : 272u);
+            const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
+            if (big_trees) hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 6>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
+            else hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 4>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
+        } else if (lights && c->shade_shadow_walk == 3) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, 3>), grid, block, TopCache::bytes_host(shade_top), c->stream, c->dscene, c->dcamera, cfg, f, shade_top);
         else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, 1>), grid, block, stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
     } else {
         // the fused kernel's shadow rays use the stack walk: its columns must exist in every mode
@@ -1404,7 +1507,8 @@ void drop_graph(hiprz_ctx* c) {
 
 // radix sort of the keys the shade kernel just wrote -> permutation the next trace kernel follows
 void launch_sort(hiprz_ctx* c) {
-    if (!sort_enabled(c) || c->n_local_tiles == 0) return;
+    if (!sort_enabled(c) || c->n_local_tiles == 0 || c->sorted_this_pass) return;
+    c->sorted_this_pass = true;
     size_t bytes = c->sort_temp_bytes;
     (void)hipcub::DeviceRadixSort::SortPairs(c->sort_temp.ptr, bytes, c->sort_keys.ptr, c->sort_keys_out.ptr, c->sort_iota.ptr,
                                              c->sort_perm.ptr, int(c->n_local_tiles * 256u), 0, 24, c->stream);
@@ -1438,6 +1542,16 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     if (!c->have_scene || !c->have_camera) return fail(c, HIPRZ_ERR_STATE, "render before scene and camera upload");
     if (n_passes == 0 || c->n_local_tiles == 0) return HIPRZ_OK;
     StageTimer timer;
+    if (defer_shadows(c)) {  // hand-over buffers of the deferred shadow rays: (4 + 2 * samples) float4 per owned pixel
+        const size_t n = size_t(c->n_local_tiles) * 256u, k = c->config.spot_samples + c->config.direct_samples;
+        if (c->nee_dir.count < n * k || c->nee_base.count < n) c->graph_valid = false;
+        RZ_HIP(c, c->nee_base.resize(n));
+        RZ_HIP(c, c->nee_a.resize(n));
+        RZ_HIP(c, c->nee_b.resize(n));
+        RZ_HIP(c, c->nee_point.resize(n));
+        RZ_HIP(c, c->nee_dir.resize(n * k));
+        RZ_HIP(c, c->nee_term.resize(n * k));
+    }
     if (effective_mode(c) == 6) RZ_HIP(c, c->rq_counts.resize(32));
     if (effective_mode(c) == 5 && c->pipeline == 1 && !use_lds_scene(c)) {
         const size_t n = size_t(c->n_local_tiles) * 256u;
@@ -1772,6 +1886,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
         if (v == 64 || v == 256) c->trace_wg = v;
     }
     if (const char* w = std::getenv("HIPRZ_TRACE_WAVES")) c->trace_waves = std::atoi(w);
+    if (const char* w = std::getenv("HIPRZ_DEFER_SHADOWS")) c->defer_shadow_rays = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SHADOW_WALK")) c->shade_shadow_walk = std::atoi(w) == 1 ? 1 : 3;
     c->device = device_id;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);

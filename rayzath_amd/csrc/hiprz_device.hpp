@@ -158,6 +158,13 @@ struct DFrame {
     uint32_t* sort_key;    // shade kernel: sort key of the pixel's NEXT ray (nullptr = ray reordering off)
     const uint32_t* perm;  // trace kernel: thread i walks the ray of local pixel perm[i] (nullptr = identity)
     uint32_t xcd_swizzle;  // 1: workgroup b works on owned tile (b % 8) * ceil(n/8) + b / 8 (see pixel_of_thread)
+    // deferred shadow rays (rz_shade_kernel<..., RZ_SHADOW_DEFER> -> rz_shadow_kernel); null when shadow rays are walked inline
+    float4* nee_base;   // [pixel] radiance before next-event estimation, bits(path continues | NEE ran << 1 | sample mask << 2)
+    float4* nee_a;      // [pixel] final += (direct * a) * b
+    float4* nee_b;
+    float4* nee_point;  // [pixel] shadow-ray origin
+    float4* nee_dir;    // [sample][pixel] direction, far
+    float4* nee_term;   // [sample][pixel] unshadowed contribution
     unsigned long long* wg_times;  // diagnostics (hiprz_set_workgroup_timing): [2 * workgroup] = start, end of the trace kernel's workgroups (100 MHz clock)
 };
 
@@ -1290,9 +1297,20 @@ RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit
     else return closest_hit_stack<COUNT, RCP>(s, lds_column, ray, hit, cnt);  // MODE 2 calls closest_hit_binned directly
 }
 // what a shadow-ray walk needs besides the scene: the lane's LDS stack column (MODE 1) or the staged tree tops (MODE 3)
+// MODE 4 ("defer"): no walk here — the sample's shadow ray and its unshadowed radiance term are written out for
+// rz_shadow_kernel, which walks the rays of all pixels in a lean kernel of its own and finishes the sums in this order.
+#define RZ_SHADOW_DEFER 4
 struct ShadowCtx {
     uint32_t* lds_column;
     TopCache top;
+    // deferred shadow rays (split pipeline, scenes with lights that are not staged in LDS)
+    float4* nee_point = nullptr;  // [pixel]            shadow-ray origin (the offset hit point)
+    float4* nee_dir = nullptr;    // [sample][pixel]    direction.xyz, far
+    float4* nee_term = nullptr;   // [sample][pixel]    (light colour * brdf colour) * radiance
+    uint32_t nee_stride = 0u, pixel = 0u;
+    mutable uint32_t defer_mask = 0u;  // bit k: sample slot k holds a shadow ray
+    mutable bool defer_done = false;   // the segment went through directIllumination
+    mutable col4 defer_a{0.0f, 0.0f, 0.0f, 0.0f}, defer_b{0.0f, 0.0f, 0.0f, 0.0f};  // final += (direct * a) * b
 };
 #ifndef RZ_SHADE_SHARED_RCP   // packed shared-reciprocal box test in the shade kernel's shadow-ray walk (MODE 3)
 #define RZ_SHADE_SHARED_RCP 1
@@ -1568,7 +1586,18 @@ RZ_DEV v3 sample_direction(v3 ray_d, uint32_t& ray_material, Surface& sf, Rng& r
     return vO;
 }
 
+RZ_DEV void defer_sample(const ShadowCtx& sc, uint32_t slot, const Ray& sr, col4 term) {
+    const size_t at = size_t(slot) * sc.nee_stride + sc.pixel;
+    sc.nee_dir[at] = make_float4(sr.d.x, sr.d.y, sr.d.z, sr.far_);
+    sc.nee_term[at] = make_float4(term.r, term.g, term.b, term.a);
+    sc.nee_point[sc.pixel] = make_float4(sr.o.x, sr.o.y, sr.o.z, 0.0f);
+    sc.defer_mask |= 1u << slot;
+}
+
 // --- next-event estimation: cpu_engine_kernel.cpp:690-865 -------------------------------
+// The two halves of a sample's contribution — (light colour * brdf colour) * radiance, and the shadow mask it is multiplied
+// with twice (V_PL, then V_PL.alpha: the CPU kernel's mask is a colour) — are kept apart so that MODE RZ_SHADOW_DEFER can
+// hand the first half and the shadow ray to rz_shadow_kernel.
 template <int MODE, bool COUNT>
 RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const ShadowCtx& lds_column, v3 ray_d, uint32_t ray_material,
                                 v3 point, v3 next_dir, const Surface& sf, Rng& rng, Counters& cnt) {
@@ -1605,9 +1634,14 @@ RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const Shado
             if (radiance < 1.0e-4f) continue;
             Ray sr;
             sr.o = point, sr.d = normalized(vPL), sr.near_ = 0.0f, sr.far_ = RZ_FLT_MAX;
-            const float V = any_hit<MODE, COUNT>(s, lds_column, sr, cnt);
-            const col4 V_PL = splat(V);
-            direct_total = direct_total + (((from_u8(__float_as_uint(l1.x)) * bc) * radiance) * V_PL) * V_PL.a;
+            const col4 term = (from_u8(__float_as_uint(l1.x)) * bc) * radiance;
+            if constexpr (MODE == RZ_SHADOW_DEFER) {
+                defer_sample(lds_column, i, sr, term);
+            } else {
+                const float V = any_hit<MODE, COUNT>(s, lds_column, sr, cnt);
+                const col4 V_PL = splat(V);
+                direct_total = direct_total + (term * V_PL) * V_PL.a;
+            }
         }
         const float pdf = float(cfg.direct_samples) / float(s.n_direct_lights);
         direct_total = div_scalar(direct_total, pdf);
@@ -1657,9 +1691,14 @@ RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const Shado
             if (radiance < 1.0e-4f) continue;
             Ray sr;
             sr.o = point, sr.d = normalized(vPL), sr.near_ = 0.0f, sr.far_ = dPL;
-            const float V = any_hit<MODE, COUNT>(s, lds_column, sr, cnt);
-            const col4 V_PL = splat(V);
-            spot_total = spot_total + (((from_u8(__float_as_uint(l2.x)) * bc) * radiance) * V_PL) * V_PL.a;
+            const col4 term = (from_u8(__float_as_uint(l2.x)) * bc) * radiance;
+            if constexpr (MODE == RZ_SHADOW_DEFER) {
+                defer_sample(lds_column, cfg.direct_samples + i, sr, term);
+            } else {
+                const float V = any_hit<MODE, COUNT>(s, lds_column, sr, cnt);
+                const col4 V_PL = splat(V);
+                spot_total = spot_total + (term * V_PL) * V_PL.a;
+            }
         }
         const float pdf = float(cfg.spot_samples) / float(s.n_spot_lights);
         spot_total = div_scalar(spot_total, pdf);

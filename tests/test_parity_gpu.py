@@ -424,3 +424,26 @@ def test_headless_runner_end_to_end(built, tmp_path):
     assert data.startswith(b"P6\n128 96\n255\n") and len(data) == len(b"P6\n128 96\n255\n") + 128 * 96 * 3
     pixels = np.frombuffer(data[len(b"P6\n128 96\n255\n"):], dtype=np.uint8)
     assert pixels.max() > 100 and pixels.std() > 10   # an actual picture, not a blank frame
+
+
+def test_deferred_shadow_rays_equal_inline_walks(built, monkeypatch):
+    """rz_shade_kernel<..., DEFER> + rz_shadow_kernel (shadow rays of a pass walked in their own lean kernel, sums finished in
+    the reference's order) == shadow rays walked inside the shade kernel: accumulator, state and all ten work counters."""
+    for samples in ((1, 1), (3, 2)):
+        world = scenes.living_room(96, 64, 16)
+        flat, cam = flatten(world), camera_struct(world.camera)
+        cfg = RenderConfig(LightSampling(*samples), Tracing(5, 4)).struct()
+        out = []
+        for defer in ("0", "1"):
+            monkeypatch.setenv("HIPRZ_DEFER_SHADOWS", defer)
+            c = Context(0)
+            c.set_traversal_mode(3), c.set_lds_scene(0), c.set_ray_sort(0)
+            c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+            counters = [c.render_counted(1), c.render_counted(2)]
+            c.render(4), c.render(4)
+            out.append((c.read_accum(), c.read_depth(), c.read_state(), counters))
+        assert out[0][3] == out[1][3]
+        assert out[0][3][0]["shadow_rays"] > 0
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        for k in out[0][2]:
+            assert np.array_equal(out[0][2][k], out[1][2][k]), k
