@@ -1300,6 +1300,7 @@ int allocate_frame(hiprz_ctx* c) {
     return HIPRZ_OK;
 }
 
+constexpr uint32_t kLatencyBoundNodes = 32768u;  // trees beyond ~1 MiB of nodes: fetches come from L2 / HBM, occupancy hides them
 int effective_mode(const hiprz_ctx* c);
 void resolve_pipeline(hiprz_ctx* c);
 bool defer_shadows(const hiprz_ctx* c);
@@ -1309,9 +1310,11 @@ bool resident_active(const hiprz_ctx* c) { return c->pipeline == 2; }
 bool sort_enabled(const hiprz_ctx* c) {
     if (c->pipeline != 1 || c->sort_rays == 0) return false;
     if (c->sort_rays == 1) return true;
-    // measured (1920x1080+, MODE 3): many small instances (config E, 46) 33.9 -> 26.5 ms per pass with sorting; one big
-    // mesh (config D) 3.7 -> 4.6 ms, config C unchanged.  So: on when the world tree has many instances.
-    return !use_lds_scene(c) && effective_mode(c) >= 3 && c->dscene.n_instances >= 16u;
+    // measured (1920x1080+, MODE 3; the sort itself costs ~0.12 ms per pass at 1080p): many small instances (config E, 46) 33.9 ->
+    // 26.5 ms per pass; one mid-size mesh (config C, 12 k nodes) trace kernel 853 -> 645 us, step 7.70 -> 6.98 ms; one big mesh
+    // (config D, 600 k nodes) trace kernel 2 656 -> 2 586 us but step 22.5 -> 23.2 ms.  So: on for many instances, and for trees
+    // small enough that a coherent wave finds its nodes in LDS / L2.
+    return !use_lds_scene(c) && effective_mode(c) >= 3 && (c->dscene.n_instances >= 16u || c->n_nodes <= kLatencyBoundNodes);
 }
 
 DFrame make_frame(hiprz_ctx* c, bool counted) {
@@ -1365,7 +1368,6 @@ void resolve_pipeline(hiprz_ctx* c) {
     }
 }
 
-constexpr uint32_t kLatencyBoundNodes = 32768u;  // trees beyond ~1 MiB of nodes: fetches come from L2 / HBM, occupancy hides them
 constexpr uint32_t kTopCacheNodes = 682u;  // 682 x 36 B = 24 KiB per workgroup: ~9 levels of every tree, 5 workgroups per CU
 
 constexpr size_t kLdsSceneLimit = 52u * 1024u;  // per workgroup: 3 x 52 KiB < 160 KiB per CU
