@@ -628,6 +628,7 @@ RZ_DEV bool closest_in_mesh_stack(const DScene& s, LdsStack& w, uint32_t root, W
     while (n != RZ_END) {
         RZ_GUARD(guard);
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
+        RZ_PHASE(3);
         RZ_COUNT(box_tests);
         if (box_hit<RCP>(n0, n1, lr)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
@@ -639,6 +640,7 @@ RZ_DEV bool closest_in_mesh_stack(const DScene& s, LdsStack& w, uint32_t root, W
             for (uint32_t i = begin; i < end; ++i) {
                 const float4 a = s.tris[3 * i], b = s.tris[3 * i + 1], c = s.tris[3 * i + 2];
                 float t, b1, b2, det;
+                RZ_PHASE(4);
                 RZ_COUNT(tri_tests);
                 if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
                     lr.far_ = t;
@@ -850,6 +852,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
     uint32_t guard = 0u;
     while (round < (1u << 20)) {  // workgroup-uniform bound: a ray enters each instance at most once
         // A. advance this ray to its next candidate instance (traverseWorld, cpu_engine_kernel.cpp:254-277, 305)
+        RZ_PHASE(5);
         uint32_t cand = RZ_BIN_NONE;
         while (true) {
             RZ_GUARD(guard);
@@ -857,6 +860,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
                 const uint32_t inst = s.tlas_order[leaf_i++];
                 float4 ib0, ib1;
                 load_instance_box(s, inst, ib0, ib1);
+                RZ_PHASE(1);
                 RZ_COUNT(box_tests);
                 if (box_hit<RCP>(ib0, ib1, g)) {
                     cand = inst;
@@ -866,6 +870,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
             }
             if (n == RZ_END) break;
             const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
+            RZ_PHASE(0);
             RZ_COUNT(box_tests);
             if (box_hit<RCP>(n0, n1, g)) {
                 const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
@@ -911,6 +916,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
         //    SIMDs they live on — change from round to round instead of always being waves 0..1.
         const uint32_t slot = (tid - ((blockIdx.x + round) & 3u) * 64u) & 255u;
         if (slot < n_items) {
+            RZ_PHASE(2);
             const uint32_t item = lds.items[slot], inst = item >> 8, src = item & 255u;
             WalkRay w;
             w.o = V3(lds.ray[0 * 256 + src], lds.ray[1 * 256 + src], lds.ray[2 * 256 + src]);
