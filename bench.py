@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--requeue", type=str, default="", help="mode 5 schedule: comma-separated lane thresholds per bailing round")
     ap.add_argument("--pipeline", type=int, default=-1, help="0 fused pass kernel, 1 trace + shade kernels, 2 resident batch kernel (-1: chosen per scene)")
     ap.add_argument("--ray-sort", type=int, default=-1, help="-1 auto, 0 off, 1 on")
+    ap.add_argument("--walk-order", type=int, default=-1, help="mesh child order of the skip-link walk: 0 reference order, 1 front to back (-1: library default)")
     ap.add_argument("--no-xcd-swizzle", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-gather", action="store_true", help="check the gathered frame against an unsharded render (N > 1)")
@@ -118,6 +119,8 @@ def main():
     if args.pipeline >= 0:
         ctx.set_pipeline(args.pipeline)
     ctx.set_ray_sort(args.ray_sort)
+    if args.walk_order >= 0:
+        ctx.set_walk_order(args.walk_order)
     if args.no_xcd_swizzle:
         ctx.set_xcd_swizzle(False)
     ctx.set_shard(rank, world)

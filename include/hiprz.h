@@ -273,6 +273,15 @@ int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
  * is queued (48 B of walk state) and resumed by the next round's kernel in a dense wave.  All visit the same boxes
  * and triangles in the same per-ray order and give identical results. */
 int hiprz_set_traversal_mode(hiprz_ctx* ctx, int mode);
+/* Order in which the single-wave skip-link walk (mode 3) enters the two children of a MESH-tree node.  0 = the reference's
+ * fixed order, first child then second (cpu_engine_kernel.cpp:331-352): box / triangle test counters equal the CPU kernel's.
+ * 1 (default) = front to back: the child on the side the ray comes from first (decided by the sign of the ray direction along
+ * the node's split axis; per ray octant the order is fixed, so the walk stays stack-free on per-octant skip links).  The closest
+ * hit is the same triangle — among equal distances the one the reference meets first wins — while fewer boxes and triangles are
+ * tested (config D: -22 % / -30 %).  World trees and instance lists are always walked in the reference's order.
+ * hiprz_render_counted() walks in the reference's order under 0 and 1, so its counters are the work of the reference's
+ * algorithm (what the roofline's algorithmic bytes are made of); 2 = front to back there too: counters = tests executed. */
+int hiprz_set_walk_order(hiprz_ctx* ctx, int order);
 /* Mode 5 schedule: thresholds[r] (0..64) = lanes of a wave that must remain inside a mesh walk during round r for
  * it to go on; otherwise they are queued for round r+1.  After n_rounds (<= 30) rounds a final round finishes every ray. */
 int hiprz_set_requeue_schedule(hiprz_ctx* ctx, const uint32_t* thresholds, uint32_t n_rounds);

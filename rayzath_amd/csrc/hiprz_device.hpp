@@ -113,6 +113,10 @@ struct DScene {
     uint32_t top_count;            // MODE 3: the first top_count nodes (+ their links) are staged in LDS by every workgroup
     const uint32_t* node_skip;     // link to the node that follows a node's subtree (same numbering as `nodes`)
     uint32_t walk_k, walk_l;       // MODE 3 mesh walk: node steps / triangle tests per lane per round (0 = unbounded)
+    // front-to-back mesh walk (hiprz_set_walk_order): 64-B records = node (32 B) + its skip link under each of the 8
+    // ray-direction octants; the first top_count_ordered of them have links that fit the 16-bit LDS copy
+    const float4* nodes64;
+    uint32_t top_count_ordered;
 };
 
 // Re-point the blob sections at a staged copy (LDS).
@@ -973,8 +977,49 @@ struct TopCache {
     const float4* nodes;   // LDS: top_count x 2 float4
     const uint32_t* skip;  // LDS: top_count
     uint32_t count;
+    const uint16_t* skip8 = nullptr;  // LDS, front-to-back walk: [octant][top_count] links (0xFFFF = end)
     static __host__ uint32_t bytes_host(uint32_t top_count) { return top_count * 36u; }
+    static __host__ uint32_t bytes_host_ordered(uint32_t top_count) { return top_count * 48u; }
 };
+// Front-to-back mesh walk.  The reference visits a node's first child, then its second (cpu_engine_kernel.cpp:331-352);
+// its builder puts the centroids BELOW the split plane into the first child (bvh_tree_node.hpp:150-215), so that fixed order is
+// front-to-back only for rays that travel up the split axis.  Which child a ray should enter first depends on nothing but the
+// sign of its direction along the node's split axis, i.e. on the ray's octant: per octant the whole visiting order is fixed, and
+// so are the skip links.  The upload derives the links of all 8 octants (64-B records: node + 8 links); a lane picks its table
+// once per mesh and the walk stays stack-free.  The closest hit is the same: among equal distances the triangle the reference
+// would have met first (lower index — triangles are stored in the reference's visiting order) wins (tri_hit_ordered).
+// octant bit p = the direction component along the axis of partition type p is negative (X=2, Y=1, Z=0; type 3 = split by size:
+// never flipped).
+RZ_DEV uint32_t octant_of(v3 d) { return uint32_t(d.z < 0.0f) | (uint32_t(d.y < 0.0f) << 1) | (uint32_t(d.x < 0.0f) << 2); }
+RZ_DEV void fetch_node_ordered(const DScene& s, const TopCache& top, uint32_t n, uint32_t oct, float4& n0, float4& n1, uint32_t& link) {
+    if (n < top.count) {
+        n0 = top.nodes[2 * n], n1 = top.nodes[2 * n + 1];
+        const uint32_t l = top.skip8[oct * top.count + n];
+        link = l == 0xFFFFu ? RZ_END : l;
+    } else {
+        const float4* rec = s.nodes64 + 4 * size_t(n);
+        n0 = rec[0], n1 = rec[1];
+        link = reinterpret_cast<const uint32_t*>(rec + 2)[oct];
+    }
+}
+// Triangle::closestIntersection for a walk in another order than the reference's: a hit at exactly the current `far` replaces the
+// held one when the reference would have met it first (`tie_ok`: a hit of THIS mesh is held and this triangle's index is lower).
+RZ_DEV bool tri_hit_ordered(v3 v1, v3 edge1, v3 edge2, const WalkRay& r, bool tie_ok, float& t_out, float& b1_out, float& b2_out, float& det_out) {
+    const v3 pvec = cross(r.d, edge2);
+    float det = dot(edge1, pvec);
+    det += float(uint32_t(det > -1.0e-7f) & uint32_t(det < 1.0e-7f)) * 1.0e-7f;
+    const float inv_det = 1.0f / det;
+    const v3 tvec = r.o - v1;
+    const float b1 = dot(tvec, pvec) * inv_det;
+    if (b1 < 0.0f || b1 > 1.0f) return false;
+    const v3 qvec = cross(tvec, edge1);
+    const float b2 = dot(r.d, qvec) * inv_det;
+    if (b2 < 0.0f || b1 + b2 > 1.0f) return false;
+    const float t = dot(edge2, qvec) * inv_det;
+    if (t <= r.near_ || t > r.far_ || (t == r.far_ && !tie_ok)) return false;
+    t_out = t, b1_out = b1, b2_out = b2, det_out = det;
+    return true;
+}
 RZ_DEV void fetch_node(const DScene& s, const TopCache& top, uint32_t n, float4& n0, float4& n1, uint32_t& link) {
     if (n < top.count) {
         n0 = top.nodes[2 * n], n1 = top.nodes[2 * n + 1], link = top.skip[n];
@@ -982,7 +1027,7 @@ RZ_DEV void fetch_node(const DScene& s, const TopCache& top, uint32_t n, float4&
         n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1], link = s.node_skip[n];
     }
 }
-template <bool COUNT, bool RCP>
+template <bool COUNT, bool RCP, bool ORDERED = false>
 RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit& hit, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
     WalkRay g;
@@ -993,7 +1038,8 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
         RZ_GUARD(guard);
         float4 n0, n1;
         uint32_t link;
-        fetch_node(s, top, n, n0, n1, link);
+        if constexpr (ORDERED) fetch_node_ordered(s, top, n, 0u, n0, n1, link);  // the world tree keeps the reference's order
+        else fetch_node(s, top, n, n0, n1, link);
         RZ_PHASE(0);
         RZ_COUNT(box_tests);
         if (box_hit<RCP>(n0, n1, g)) {
@@ -1016,6 +1062,7 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                 const float len = to_local<RCP>(x, g, lr, scene_fast);
                 bool found = false;
                 uint32_t m = x.blas_root;
+                const uint32_t oct = ORDERED ? octant_of(lr.d) : 0u;
                 // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352, as a "while-while" walk in bounded
                 // rounds: lanes without a leaf step through nodes until they HOLD one (at most walk_k steps per round), then the
                 // lanes that hold a leaf test its triangles (at most walk_l per round), together.  With the leaf loop nested in
@@ -1032,13 +1079,15 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                         k += 1u;
                         float4 m0, m1;
                         uint32_t mlink;
-                        fetch_node(s, top, m, m0, m1, mlink);
+                        if constexpr (ORDERED) fetch_node_ordered(s, top, m, oct, m0, m1, mlink);
+                        else fetch_node(s, top, m, m0, m1, mlink);
                         RZ_PHASE(3);
                         RZ_COUNT(box_tests);
                         if (box_hit<RCP>(m0, m1, lr)) {
                             const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                             if (!(mmeta & HIPRZ_NODE_LEAF)) {
                                 m = mbegin;
+                                if constexpr (ORDERED) m += (oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u;  // enter the nearer child first
                                 continue;
                             }
                             tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
@@ -1052,7 +1101,10 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                         float t, b1, b2, det;
                         RZ_PHASE(4);
                         RZ_COUNT(tri_tests);
-                        if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
+                        bool is_hit;
+                        if constexpr (ORDERED) is_hit = tri_hit_ordered(xyz(a), xyz(b), xyz(c), lr, found && tj < hit.triangle, t, b1, b2, det);
+                        else is_hit = tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det);
+                        if (is_hit) {
                             lr.far_ = t;
                             hit.triangle = tj;
                             hit.external = det > 0.0f;
@@ -1078,7 +1130,7 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
 
 // anyIntersection (cpu_engine_kernel.cpp:398-481) on skip links, with the tree tops from LDS: the shadow-ray walk of the
 // kernels that have a TopCache.  Same tests in the same order as any_hit_stack; returns the mask's alpha (0 or 1).
-template <bool COUNT, bool RCP>
+template <bool COUNT, bool RCP, bool ORDERED = false>
 RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
     WalkRay g;
@@ -1089,7 +1141,8 @@ RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, 
         RZ_GUARD(guard);
         float4 n0, n1;
         uint32_t link;
-        fetch_node(s, top, n, n0, n1, link);
+        if constexpr (ORDERED) fetch_node_ordered(s, top, n, 0u, n0, n1, link);
+        else fetch_node(s, top, n, n0, n1, link);
         RZ_COUNT(box_tests);
         RZ_COUNT(shadow_box_tests);
         if (box_hit<RCP>(n0, n1, g)) {
@@ -1110,6 +1163,7 @@ RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, 
                 WalkRay lr;
                 to_local<RCP>(x, g, lr, scene_fast);
                 uint32_t m = x.blas_root;
+                const uint32_t oct = ORDERED ? octant_of(lr.d) : 0u;  // any order finds the same answer; occluders tend to be near
                 // anyIntersection(const Mesh&, ...) :450-481, in the bounded while-while rounds of closest_hit_skip
                 uint32_t tj = 0u, tj_end = 0u;
                 const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? s.walk_l : 0xFFFFFFFFu;
@@ -1120,13 +1174,15 @@ RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, 
                         k += 1u;
                         float4 m0, m1;
                         uint32_t mlink;
-                        fetch_node(s, top, m, m0, m1, mlink);
+                        if constexpr (ORDERED) fetch_node_ordered(s, top, m, oct, m0, m1, mlink);
+                        else fetch_node(s, top, m, m0, m1, mlink);
                         RZ_COUNT(box_tests);
                         RZ_COUNT(shadow_box_tests);
                         if (box_hit<RCP>(m0, m1, lr)) {
                             const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                             if (!(mmeta & HIPRZ_NODE_LEAF)) {
                                 m = mbegin;
+                                if constexpr (ORDERED) m += (oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u;
                                 continue;
                             }
                             tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
@@ -1329,6 +1385,8 @@ RZ_DEV float any_hit(const DScene& s, const ShadowCtx& sc, const Ray& ray, Count
     if (s.n_instances == 0) return 0.0f;
     if constexpr (MODE == 3) {
         return any_hit_skip<COUNT, RZ_SHADE_SHARED_RCP != 0>(s, sc.top, ray, cnt);
+    } else if constexpr (MODE == 7) {  // MODE 3 with front-to-back mesh walks
+        return any_hit_skip<COUNT, RZ_SHADE_SHARED_RCP != 0, true>(s, sc.top, ray, cnt);
     } else if constexpr (MODE == 0) {
         Ray r = ray;
         Hit unused;

@@ -79,6 +79,10 @@ class Context:
     def set_traversal_mode(self, mode):
         self._check(self.lib.hiprz_set_traversal_mode(self._ctx, mode))
 
+    def set_walk_order(self, order):
+        """0 = mesh children in the reference's order (counters equal the CPU kernel's), 1 = front to back (default)."""
+        self._check(self.lib.hiprz_set_walk_order(self._ctx, order))
+
     def set_pipeline(self, pipeline):
         self._check(self.lib.hiprz_set_pipeline(self._ctx, pipeline))
 

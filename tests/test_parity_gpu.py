@@ -447,3 +447,32 @@ def test_deferred_shadow_rays_equal_inline_walks(built, monkeypatch):
         assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
         for k in out[0][2]:
             assert np.array_equal(out[0][2][k], out[1][2][k]), k
+
+
+def test_front_to_back_walk_equals_reference_order(built):
+    """hiprz_set_walk_order: meshes walked front to back on per-octant skip links (trace kernel and deferred shadow kernel) give
+    the accumulator, depth buffer and path state of the walk in the reference's child order, bit for bit, while testing fewer
+    boxes and triangles; counted renders keep the reference's order (and so the CPU kernel's counters) unless order 2 is set."""
+    cases = ((scenes.cornell_sphere(160, 96, resolution=40), (1, 1)),
+             (scenes.textured_sphere_scene(160, 96, resolution=60, map_size=64), (1, 1)),
+             (scenes.living_room(128, 80, 16), (2, 2)))
+    for world, samples in cases:
+        flat, cam = flatten(world), camera_struct(world.camera)
+        cfg = RenderConfig(LightSampling(*samples), Tracing(6, 4)).struct()
+        out = []
+        for order in (0, 1, 2):
+            c = Context(0)
+            c.set_traversal_mode(3), c.set_lds_scene(0), c.set_walk_order(order)
+            c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+            counters = c.render_counted(2)
+            c.render(6), c.render(4)
+            out.append((c.read_accum(), c.read_depth(), c.read_state(), counters))
+        assert out[0][3] == out[1][3]                      # order 1 counts in the reference's order
+        for k in ("segments", "hits", "finished", "light_samples", "shadow_rays", "texel_fetches"):
+            assert out[2][3][k] == out[0][3][k], k          # same paths, same hits ...
+        assert out[2][3]["box_tests"] < out[0][3]["box_tests"]  # ... found with fewer tests
+        assert out[2][3]["tri_tests"] < out[0][3]["tri_tests"]
+        for other in (1, 2):
+            assert np.array_equal(out[0][0], out[other][0]) and np.array_equal(out[0][1], out[other][1])
+            for k in out[0][2]:
+                assert np.array_equal(out[0][2][k], out[other][2][k]), k
