@@ -2129,6 +2129,11 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     c->n_nodes = sc->n_nodes;
     // mesh walk rounds of at most 4 node steps and 8 triangles per lane (measured: D 3 163 -> 2 891 us, C 935 -> 892 us)
     d.walk_k = 4u, d.walk_l = 8u;
+    // ray reordering key: without lights only the closest-hit walk follows the sorted order and the interleaved origin/direction
+    // code groups best (config C: trace kernel 583 -> 503 us); with lights the deferred shadow rays follow it too and they fan out
+    // from the origin cell, so the origin leads (config E: 86.5 ms per step against 92.6)
+    d.sort_variant = (sc->n_spot_lights + sc->n_direct_lights) ? 0u : 2u;
+    if (const char* v = std::getenv("HIPRZ_SORT_KEY")) d.sort_variant = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_K")) d.walk_k = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_L")) d.walk_l = uint32_t(std::atoi(v));
     d.wtop_count = std::min<uint32_t>(uint32_t(wnodes.size()), kTopCacheNodes);

@@ -117,6 +117,7 @@ struct DScene {
     // ray-direction octants; the first top_count_ordered of them have links that fit the 16-bit LDS copy
     const float4* nodes64;
     uint32_t top_count_ordered;
+    uint32_t sort_variant;  // ray_sort_key layout (HIPRZ_SORT_KEY): 0 origin cell then direction, 1 direction then cell, 2 interleaved
 };
 
 // Re-point the blob sections at a staged copy (LDS).
@@ -1876,6 +1877,16 @@ RZ_DEV uint32_t ray_sort_key(const DScene& s, v3 o, v3 d) {
     const uint32_t qx = uint32_t(fminf(fmaxf(d.x * inv * 3.99f + 4.0f, 0.0f), 7.0f));
     const uint32_t qy = uint32_t(fminf(fmaxf(d.y * inv * 3.99f + 4.0f, 0.0f), 7.0f));
     const uint32_t qz = uint32_t(fminf(fmaxf(d.z * inv * 3.99f + 4.0f, 0.0f), 7.0f));
+    if (s.sort_variant == 1u) return (((qx << 6) | (qy << 3) | qz) << 15) | morton;  // direction-major
+    if (s.sort_variant == 2u) {  // 6-D Morton code: 4 bits of each origin cell coordinate and of each direction component, interleaved
+        const uint32_t px = uint32_t(cx) >> 1, py = uint32_t(cy) >> 1, pz = uint32_t(cz) >> 1;
+        const uint32_t dx = uint32_t(fminf(fmaxf(d.x * inv * 7.99f + 8.0f, 0.0f), 15.0f)), dy = uint32_t(fminf(fmaxf(d.y * inv * 7.99f + 8.0f, 0.0f), 15.0f)),
+                       dz = uint32_t(fminf(fmaxf(d.z * inv * 7.99f + 8.0f, 0.0f), 15.0f));
+        uint32_t key = 0u;
+        for (int b = 3; b >= 0; --b)
+            key = (key << 6) | (((dx >> b) & 1u) << 5) | (((dy >> b) & 1u) << 4) | (((dz >> b) & 1u) << 3) | (((px >> b) & 1u) << 2) | (((py >> b) & 1u) << 1) | ((pz >> b) & 1u);
+        return key;
+    }
     return (morton << 9) | (qx << 6) | (qy << 3) | qz;
 }
 
