@@ -10,6 +10,8 @@
 #ifndef HIPRZ_IO_H
 #define HIPRZ_IO_H
 
+#include <stddef.h>
+
 #include "hiprz.h"
 
 #ifdef __cplusplus
@@ -32,6 +34,16 @@ uint32_t hiprz_scene_file_error_count(const hiprz_scene_file* file);
 uint32_t hiprz_scene_file_warning_count(const hiprz_scene_file* file);
 /* Write the loaded world back: `kind` 0 = .json with inline meshes, 1 = .obj + .mtl next to it. */
 int hiprz_scene_file_save(const hiprz_scene_file* file, const char* path, int kind);
+
+/* Image files of maps and saved frames (rayzath_amd/csrc/image_io.hpp; the reference: stbi_load / stbi_write_png, loader.cpp:36-98,
+ * saver.cpp:16-60).  Decodes PNG (every colour type / bit depth, palette, tRNS, Adam7), BMP, TGA and binary PPM / PGM to 8 bits
+ * per channel, rows top to bottom.  `channels` = 0 keeps the file's channel count (reported in *channels_out: 1 grey, 2 grey +
+ * alpha, 3 RGB, 4 RGBA), 1..4 converts like stb_image does (grey = (77 r + 150 g + 29 b) >> 8, missing alpha = 255).
+ * Call with pixels = NULL to learn the size; otherwise capacity must be >= width * height * channels. */
+int hiprz_image_read(const char* path, uint32_t channels, uint32_t* width_out, uint32_t* height_out, uint32_t* channels_out,
+                     uint8_t* pixels, size_t capacity);
+/* 8-bit PNG from `channels` (1..4) interleaved channels, rows top to bottom. */
+int hiprz_image_write_png(const char* path, const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels);
 const char* hiprz_io_last_error(void);
 
 #ifdef __cplusplus

@@ -1,6 +1,8 @@
 // headless.cpp — see headless.hpp.  Host-only C++17 above hip_engine.hpp / scene_io.hpp.
 #include "headless.hpp"
 
+#include "image_io.hpp"
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -157,10 +159,10 @@ std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& r
         result.duration = seconds_since(start);
         if (!quiet) std::printf("\nRendered in: %ss\n\n", fixed3(result.duration).c_str());
         if (save_images) {
-            const std::string name = report_dir + file_name(task.scene_path) + "_camera_" + scientificWithPrefix(result.total_traced_rays) + "_" + engine_name + ".ppm";
-            std::ofstream img(name, std::ios::binary);
-            img << "P6\n" << world.camera.width << ' ' << world.camera.height << "\n255\n";
-            for (size_t i = 0; i < size_t(world.camera.width) * world.camera.height; ++i) img.write(reinterpret_cast<const char*>(&world.camera.image_buffer[4 * i]), 3);
+            // saveMap<Texture> (headless.cpp:255-275, saver.cpp:16-37): the camera's RGBA8 frame as a PNG
+            const std::string name = report_dir + file_name(task.scene_path) + "_camera_" + scientificWithPrefix(result.total_traced_rays) + "_" + engine_name + ".png";
+            std::string why;
+            if (!IO::writePNG(name, world.camera.image_buffer.data(), world.camera.width, world.camera.height, 4, why)) throw Exception(HIPRZ_ERR_INVALID, why);
             if (!quiet) std::printf("Saved %s\n", name.c_str());
         }
         if (!quiet) std::printf("%s\n", engine.timingsString().c_str());

@@ -3,6 +3,9 @@
 
 #include <string>
 
+#include <cstring>
+
+#include "image_io.hpp"
 #include "scene_io.hpp"
 
 using namespace RayZath::Hip;
@@ -58,6 +61,31 @@ int hiprz_scene_file_save(const hiprz_scene_file* f, const char* path, int kind)
         g_error = e.what();
         return HIPRZ_ERR_INVALID;
     }
+    return HIPRZ_OK;
+}
+int hiprz_image_read(const char* path, uint32_t channels, uint32_t* width_out, uint32_t* height_out, uint32_t* channels_out, uint8_t* pixels,
+                     size_t capacity) {
+    if (!path || channels > 4) return g_error = "hiprz_image_read: bad arguments", HIPRZ_ERR_INVALID;
+    IO::Image img;
+    std::string why;
+    if (!IO::readImage(path, img, why)) return g_error = why, HIPRZ_ERR_INVALID;
+    const uint32_t c = channels ? channels : img.channels;
+    if (width_out) *width_out = img.width;
+    if (height_out) *height_out = img.height;
+    if (channels_out) *channels_out = c;
+    if (!pixels) return HIPRZ_OK;
+    const size_t bytes = size_t(img.width) * img.height * c;
+    if (capacity < bytes) return g_error = "hiprz_image_read: destination too small", HIPRZ_ERR_INVALID;
+    if (c == img.channels) std::memcpy(pixels, img.data.data(), bytes);
+    else {
+        const std::vector<uint8_t> converted = IO::convertChannels(img, c);
+        std::memcpy(pixels, converted.data(), bytes);
+    }
+    return HIPRZ_OK;
+}
+int hiprz_image_write_png(const char* path, const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels) {
+    std::string why;
+    if (!path || !IO::writePNG(path, pixels, width, height, channels, why)) return g_error = path ? why : "null path", HIPRZ_ERR_INVALID;
     return HIPRZ_OK;
 }
 const char* hiprz_io_last_error(void) { return g_error.c_str(); }

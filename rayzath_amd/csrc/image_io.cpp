@@ -1,0 +1,404 @@
+// image_io.cpp — see image_io.hpp.  Host-only C++17; inflate / deflate / crc32 come from zlib.
+#include "image_io.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+
+namespace RayZath::Hip::IO {
+namespace {
+
+constexpr uint32_t kMaxSide = 32768u;
+
+uint32_t be32(const uint8_t* p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
+uint32_t le32(const uint8_t* p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8) | (uint32_t(p[2]) << 16) | (uint32_t(p[3]) << 24); }
+uint32_t le16(const uint8_t* p) { return uint32_t(p[0]) | (uint32_t(p[1]) << 8); }
+void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back(uint8_t(x >> 24)), v.push_back(uint8_t(x >> 16)), v.push_back(uint8_t(x >> 8)), v.push_back(uint8_t(x));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PNG (ISO/IEC 15948)
+// ---------------------------------------------------------------------------------------------------------------------
+const uint8_t kPngSignature[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+
+int paeth(int a, int b, int c) {
+    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// reverses the row filters of one (sub-)image in place; rows are `stride` bytes after their filter-type byte
+bool unfilter(uint8_t* data, uint32_t rows, size_t stride, uint32_t bytes_per_pixel) {
+    std::vector<uint8_t> zero(stride, 0);
+    const uint8_t* prev = zero.data();
+    for (uint32_t y = 0; y < rows; ++y) {
+        uint8_t* line = data + size_t(y) * (stride + 1);
+        const uint8_t type = line[0];
+        uint8_t* cur = line + 1;
+        if (type > 4) return false;
+        for (size_t i = 0; i < stride; ++i) {
+            const int a = i >= bytes_per_pixel ? cur[i - bytes_per_pixel] : 0, b = prev[i], c = i >= bytes_per_pixel ? prev[i - bytes_per_pixel] : 0;
+            int add = 0;
+            if (type == 1) add = a;
+            else if (type == 2) add = b;
+            else if (type == 3) add = (a + b) >> 1;
+            else if (type == 4) add = paeth(a, b, c);
+            cur[i] = uint8_t(cur[i] + add);
+        }
+        prev = cur;
+    }
+    return true;
+}
+
+struct PngHeader {
+    uint32_t width = 0, height = 0;
+    uint8_t depth = 0, color_type = 0, interlace = 0;
+    uint32_t samples() const { return color_type == 0 ? 1u : color_type == 2 ? 3u : color_type == 3 ? 1u : color_type == 4 ? 2u : 4u; }
+    uint32_t bits_per_pixel() const { return samples() * depth; }
+};
+
+bool decode_png(const uint8_t* bytes, size_t size, const std::string& name, Image& out, std::string& why) {
+    auto bad = [&](const std::string& m) { return why = name + ": " + m, false; };
+    size_t pos = 8;
+    PngHeader h;
+    bool have_header = false, have_end = false;
+    std::vector<uint8_t> idat, palette, trns;
+    while (!have_end) {
+        if (pos + 12 > size) return bad("truncated PNG (chunk header)");
+        const uint32_t len = be32(bytes + pos);
+        const uint8_t* type = bytes + pos + 4;
+        if (len > 0x7FFFFFFFu || pos + 12 + size_t(len) > size) return bad("truncated PNG (chunk data)");
+        const uint8_t* data = bytes + pos + 8;
+        if (uint32_t(crc32(crc32(0L, Z_NULL, 0), type, uInt(len + 4))) != be32(data + len)) return bad("PNG chunk CRC mismatch");
+        const std::string t(reinterpret_cast<const char*>(type), 4);
+        if (!have_header && t != "IHDR") return bad("PNG does not start with IHDR");
+        if (t == "IHDR") {
+            if (len != 13 || have_header) return bad("bad IHDR");
+            h.width = be32(data), h.height = be32(data + 4), h.depth = data[8], h.color_type = data[9], h.interlace = data[12];
+            if (data[10] != 0 || data[11] != 0 || h.interlace > 1) return bad("unknown PNG compression / filter / interlace method");
+            if (h.width == 0 || h.height == 0 || h.width > kMaxSide || h.height > kMaxSide) return bad("PNG dimensions out of range");
+            const uint8_t d = h.depth;
+            const bool ok = (h.color_type == 0 && (d == 1 || d == 2 || d == 4 || d == 8 || d == 16)) || (h.color_type == 3 && (d == 1 || d == 2 || d == 4 || d == 8)) ||
+                            ((h.color_type == 2 || h.color_type == 4 || h.color_type == 6) && (d == 8 || d == 16));
+            if (!ok) return bad("invalid PNG colour type / bit depth");
+            have_header = true;
+        } else if (t == "PLTE") {
+            if (len == 0 || len % 3 != 0 || len > 768) return bad("bad PLTE");
+            palette.assign(data, data + len);
+        } else if (t == "tRNS") {
+            trns.assign(data, data + len);
+        } else if (t == "IDAT") {
+            idat.insert(idat.end(), data, data + len);
+        } else if (t == "IEND") {
+            have_end = true;
+        } else if (!(type[0] & 0x20)) {
+            return bad("unknown critical PNG chunk " + t);
+        }
+        pos += 12 + size_t(len);
+    }
+    if (idat.empty()) return bad("PNG without image data");
+    if (h.color_type == 3 && palette.empty()) return bad("paletted PNG without PLTE");
+
+    // sub-images: the whole picture, or the seven Adam7 passes
+    struct Pass { uint32_t x0, y0, dx, dy, w, h; size_t offset; };
+    static const uint32_t ax0[7] = {0, 4, 0, 2, 0, 1, 0}, ay0[7] = {0, 0, 4, 0, 2, 0, 1}, adx[7] = {8, 8, 4, 4, 2, 2, 1}, ady[7] = {8, 8, 8, 4, 4, 2, 2};
+    std::vector<Pass> passes;
+    const uint32_t bpp = h.bits_per_pixel();
+    size_t raw_size = 0;
+    auto add_pass = [&](uint32_t x0, uint32_t y0, uint32_t dx, uint32_t dy) {
+        if (x0 >= h.width || y0 >= h.height) return;
+        Pass p{x0, y0, dx, dy, (h.width - x0 + dx - 1) / dx, (h.height - y0 + dy - 1) / dy, raw_size};
+        raw_size += size_t(p.h) * (1 + (size_t(p.w) * bpp + 7) / 8);
+        passes.push_back(p);
+    };
+    if (h.interlace) for (int i = 0; i < 7; ++i) add_pass(ax0[i], ay0[i], adx[i], ady[i]);
+    else add_pass(0, 0, 1, 1);
+
+    std::vector<uint8_t> raw(raw_size);
+    uLongf got = uLongf(raw_size);
+    const int zr = uncompress(raw.data(), &got, idat.data(), uLong(idat.size()));
+    if (zr != Z_OK || size_t(got) != raw_size) return bad("PNG image data does not inflate to the size its header announces");
+
+    const bool key = !trns.empty() && (h.color_type == 0 || h.color_type == 2);
+    if (key && trns.size() < (h.color_type == 0 ? 2u : 6u)) return bad("bad tRNS");
+    const bool palette_alpha = h.color_type == 3 && !trns.empty();
+    out.width = h.width, out.height = h.height;
+    out.channels = h.color_type == 0 ? (key ? 2u : 1u) : h.color_type == 2 ? (key ? 4u : 3u) : h.color_type == 3 ? (palette_alpha ? 4u : 3u) : h.color_type == 4 ? 2u : 4u;
+    out.data.assign(size_t(h.width) * h.height * out.channels, 0);
+    const uint32_t n_samples = h.samples(), filter_bpp = std::max(1u, bpp / 8u);
+    static const uint32_t grey_scale[5] = {0, 0xFF, 0x55, 0, 0x11};
+    const uint32_t key16[3] = {key ? (uint32_t(trns[0]) << 8) | trns[1] : 0u, key && h.color_type == 2 ? (uint32_t(trns[2]) << 8) | trns[3] : 0u,
+                               key && h.color_type == 2 ? (uint32_t(trns[4]) << 8) | trns[5] : 0u};
+    for (const Pass& p : passes) {
+        const size_t stride = (size_t(p.w) * bpp + 7) / 8;
+        if (!unfilter(raw.data() + p.offset, p.h, stride, filter_bpp)) return bad("unknown PNG row filter");
+        for (uint32_t y = 0; y < p.h; ++y) {
+            const uint8_t* row = raw.data() + p.offset + size_t(y) * (stride + 1) + 1;
+            for (uint32_t x = 0; x < p.w; ++x) {
+                uint32_t sample[4] = {0, 0, 0, 0};  // at the file's bit depth
+                for (uint32_t s = 0; s < n_samples; ++s) {
+                    const size_t idx = size_t(x) * n_samples + s;
+                    if (h.depth == 16) sample[s] = (uint32_t(row[2 * idx]) << 8) | row[2 * idx + 1];
+                    else if (h.depth == 8) sample[s] = row[idx];
+                    else {
+                        const size_t bit = idx * h.depth;
+                        sample[s] = (row[bit >> 3] >> (8 - h.depth - (bit & 7))) & ((1u << h.depth) - 1u);
+                    }
+                }
+                uint8_t* o = &out.data[(size_t(p.y0 + y * p.dy) * h.width + (p.x0 + x * p.dx)) * out.channels];
+                auto to8 = [&](uint32_t v) { return uint8_t(h.depth == 16 ? v >> 8 : h.depth == 8 ? v : v * grey_scale[h.depth]); };
+                if (h.color_type == 3) {
+                    if (3 * sample[0] + 2 >= palette.size()) return bad("PNG palette index out of range");
+                    o[0] = palette[3 * sample[0]], o[1] = palette[3 * sample[0] + 1], o[2] = palette[3 * sample[0] + 2];
+                    if (palette_alpha) o[3] = sample[0] < trns.size() ? trns[sample[0]] : 255;
+                } else if (h.color_type == 0) {
+                    o[0] = to8(sample[0]);
+                    if (key) o[1] = sample[0] == key16[0] ? 0 : 255;
+                } else if (h.color_type == 2) {
+                    o[0] = to8(sample[0]), o[1] = to8(sample[1]), o[2] = to8(sample[2]);
+                    if (key) o[3] = (sample[0] == key16[0] && sample[1] == key16[1] && sample[2] == key16[2]) ? 0 : 255;
+                } else {
+                    for (uint32_t s = 0; s < n_samples; ++s) o[s] = to8(sample[s]);
+                }
+            }
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BMP
+// ---------------------------------------------------------------------------------------------------------------------
+bool decode_bmp(const uint8_t* b, size_t size, const std::string& name, Image& out, std::string& why) {
+    auto bad = [&](const std::string& m) { return why = name + ": " + m, false; };
+    if (size < 54) return bad("truncated BMP header");
+    const uint32_t data_offset = le32(b + 10), dib = le32(b + 14);
+    if (dib < 40) return bad("BMP with an OS/2 header is not decoded");
+    const int32_t w = int32_t(le32(b + 18)), hs = int32_t(le32(b + 22));
+    const uint32_t bpp = le16(b + 28), compression = le32(b + 30);
+    uint32_t colors = le32(b + 46);
+    const bool top_down = hs < 0;
+    const uint32_t h = uint32_t(top_down ? -int64_t(hs) : hs);
+    if (w <= 0 || h == 0 || uint32_t(w) > kMaxSide || h > kMaxSide) return bad("BMP dimensions out of range");
+    if (!(bpp == 8 || bpp == 24 || bpp == 32)) return bad("only 8, 24 and 32 bits per pixel BMP files are decoded");
+    uint32_t shift[4] = {16, 8, 0, 24};  // B G R A byte order of BI_RGB
+    bool has_alpha = bpp == 32;
+    if (compression == 3 && bpp == 32) {
+        const size_t m = dib >= 52 ? 54 : 14 + size_t(dib);  // masks: inside a V2+ header or right behind BITMAPINFOHEADER
+        if (m + 12 > size) return bad("truncated BMP bit masks");
+        const uint32_t mask[4] = {le32(b + m), le32(b + m + 4), le32(b + m + 8), dib >= 56 && m + 16 <= size ? le32(b + m + 12) : 0u};
+        for (int c = 0; c < 4; ++c) {
+            if (mask[c] == 0xFFu) shift[c] = 0;
+            else if (mask[c] == 0xFF00u) shift[c] = 8;
+            else if (mask[c] == 0xFF0000u) shift[c] = 16;
+            else if (mask[c] == 0xFF000000u) shift[c] = 24;
+            else if (c == 3 && mask[c] == 0) has_alpha = false;
+            else return bad("BMP bit masks that are not whole bytes are not decoded");
+        }
+    } else if (compression != 0) {
+        return bad("compressed BMP files are not decoded");
+    }
+    const size_t stride = ((size_t(w) * bpp + 31) / 32) * 4;
+    if (size_t(data_offset) + stride * h > size) return bad("truncated BMP pixel data");
+    const uint8_t* pal = b + 14 + dib;
+    if (bpp == 8) {
+        if (colors == 0 || colors > 256) colors = 256;
+        if (14 + size_t(dib) + 4 * size_t(colors) > size) return bad("truncated BMP palette");
+    }
+    out.width = uint32_t(w), out.height = h, out.channels = has_alpha ? 4u : 3u;
+    out.data.assign(size_t(w) * h * out.channels, 255);
+    bool any_alpha = false;
+    for (uint32_t y = 0; y < h; ++y) {
+        const uint8_t* row = b + data_offset + stride * (top_down ? y : h - 1 - y);
+        for (uint32_t x = 0; x < uint32_t(w); ++x) {
+            uint8_t* o = &out.data[(size_t(y) * w + x) * out.channels];
+            if (bpp == 8) {
+                const uint32_t i = row[x];
+                if (i >= colors) return bad("BMP palette index out of range");
+                o[0] = pal[4 * i + 2], o[1] = pal[4 * i + 1], o[2] = pal[4 * i];
+            } else if (bpp == 24) {
+                o[0] = row[3 * x + 2], o[1] = row[3 * x + 1], o[2] = row[3 * x];
+            } else {
+                const uint32_t v = le32(row + 4 * x);
+                o[0] = uint8_t(v >> shift[0]), o[1] = uint8_t(v >> shift[1]), o[2] = uint8_t(v >> shift[2]);
+                if (has_alpha) o[3] = uint8_t(v >> shift[3]), any_alpha = any_alpha || o[3] != 0;
+            }
+        }
+    }
+    if (has_alpha && !any_alpha)  // an all-zero alpha channel is an unused one (stb_image does the same)
+        for (size_t i = 3; i < out.data.size(); i += 4) out.data[i] = 255;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// TGA
+// ---------------------------------------------------------------------------------------------------------------------
+bool decode_tga(const uint8_t* b, size_t size, const std::string& name, Image& out, std::string& why) {
+    auto bad = [&](const std::string& m) { return why = name + ": " + m, false; };
+    if (size < 18) return bad("truncated TGA header");
+    const uint32_t id_len = b[0], cmap_type = b[1], type = b[2], w = le16(b + 12), h = le16(b + 14), bpp = b[16], desc = b[17];
+    if (cmap_type != 0 || !(type == 2 || type == 3 || type == 10 || type == 11)) return bad("only true-colour and grey TGA files (types 2, 3, 10, 11) are decoded");
+    const bool grey = type == 3 || type == 11, rle = type >= 10;
+    if ((grey && bpp != 8) || (!grey && bpp != 24 && bpp != 32)) return bad("only 8-bit grey and 24 / 32-bit colour TGA files are decoded");
+    if (w == 0 || h == 0) return bad("TGA dimensions out of range");
+    const uint32_t bytes = bpp / 8;
+    out.width = w, out.height = h, out.channels = grey ? 1u : bytes;
+    out.data.assign(size_t(w) * h * out.channels, 0);
+    size_t pos = 18 + size_t(id_len);
+    const size_t n = size_t(w) * h;
+    uint8_t px[4] = {0, 0, 0, 255};
+    size_t i = 0;
+    auto store = [&](size_t idx, const uint8_t* p) {
+        size_t y = idx / w, x = idx % w;
+        if (!(desc & 0x20)) y = h - 1 - y;  // bottom-up unless bit 5 is set
+        if (desc & 0x10) x = w - 1 - x;
+        uint8_t* o = &out.data[(y * w + x) * out.channels];
+        if (grey) o[0] = p[0];
+        else {
+            o[0] = p[2], o[1] = p[1], o[2] = p[0];
+            if (bytes == 4) o[3] = p[3];
+        }
+    };
+    while (i < n) {
+        if (!rle) {
+            if (pos + bytes > size) return bad("truncated TGA pixel data");
+            store(i++, b + pos), pos += bytes;
+            continue;
+        }
+        if (pos + 1 > size) return bad("truncated TGA packet");
+        const uint32_t head = b[pos++], count = (head & 127u) + 1u;
+        if (i + count > n) return bad("TGA packet runs past the image");
+        if (head & 128u) {
+            if (pos + bytes > size) return bad("truncated TGA packet");
+            std::memcpy(px, b + pos, bytes), pos += bytes;
+            for (uint32_t k = 0; k < count; ++k) store(i++, px);
+        } else {
+            if (pos + size_t(bytes) * count > size) return bad("truncated TGA packet");
+            for (uint32_t k = 0; k < count; ++k) store(i++, b + pos), pos += bytes;
+        }
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// binary PNM (P5 / P6)
+// ---------------------------------------------------------------------------------------------------------------------
+bool decode_pnm(const uint8_t* b, size_t size, const std::string& name, Image& out, std::string& why) {
+    auto bad = [&](const std::string& m) { return why = name + ": " + m, false; };
+    size_t pos = 0;
+    auto token = [&]() {
+        std::string t;
+        while (pos < size) {
+            if (b[pos] == '#') while (pos < size && b[pos] != '\n') ++pos;
+            else if (std::isspace(b[pos])) ++pos;
+            else break;
+        }
+        while (pos < size && !std::isspace(b[pos])) t.push_back(char(b[pos++]));
+        return t;
+    };
+    const std::string magic = token();
+    const long w = std::atol(token().c_str()), h = std::atol(token().c_str()), maxv = std::atol(token().c_str());
+    if (w <= 0 || h <= 0 || w > long(kMaxSide) || h > long(kMaxSide) || maxv != 255) return bad("unsupported PNM header");
+    ++pos;  // the single whitespace after maxval
+    out.width = uint32_t(w), out.height = uint32_t(h), out.channels = magic == "P6" ? 3u : 1u;
+    const size_t n = size_t(w) * size_t(h) * out.channels;
+    if (pos + n > size) return bad("truncated image");
+    out.data.assign(b + pos, b + pos + n);
+    return true;
+}
+
+std::string lower_extension(const std::string& path) {
+    const size_t p = path.find_last_of('.');
+    std::string e = p == std::string::npos ? std::string() : path.substr(p);
+    for (auto& c : e) c = char(std::tolower(static_cast<unsigned char>(c)));
+    return e;
+}
+
+}  // namespace
+
+bool decodeImage(const uint8_t* bytes, size_t size, const std::string& name, Image& out, std::string& why) {
+    out = Image{};
+    if (size >= 8 && std::memcmp(bytes, kPngSignature, 8) == 0) return decode_png(bytes, size, name, out, why);
+    if (size >= 2 && bytes[0] == 'B' && bytes[1] == 'M') return decode_bmp(bytes, size, name, out, why);
+    if (size >= 2 && bytes[0] == 'P' && (bytes[1] == '5' || bytes[1] == '6')) return decode_pnm(bytes, size, name, out, why);
+    if (size >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) return why = name + ": JPEG images are not decoded here (PNG, BMP, TGA, binary PPM / PGM are)", false;
+    if (lower_extension(name) == ".tga") return decode_tga(bytes, size, name, out, why);
+    return why = name + ": not an image format decoded here (PNG, BMP, TGA, binary PPM / PGM; the reference uses stb_image)", false;
+}
+
+bool readImage(const std::string& path, Image& out, std::string& why) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return why = "failed to open " + path, false;
+    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    return decodeImage(bytes.data(), bytes.size(), path, out, why);
+}
+
+std::vector<uint8_t> convertChannels(const Image& img, uint32_t channels) {
+    const size_t n = size_t(img.width) * img.height;
+    std::vector<uint8_t> out(n * channels);
+    const uint32_t src = img.channels;
+    for (size_t i = 0; i < n; ++i) {
+        const uint8_t* p = &img.data[i * src];
+        const uint8_t r = p[0], g = src >= 3 ? p[1] : p[0], b = src >= 3 ? p[2] : p[0], a = src == 2 ? p[1] : src == 4 ? p[3] : 255;
+        const uint8_t y = src >= 3 ? uint8_t((r * 77 + g * 150 + b * 29) >> 8) : p[0];
+        uint8_t* o = &out[i * channels];
+        if (channels == 1) o[0] = y;
+        else if (channels == 2) o[0] = y, o[1] = a;
+        else if (channels == 3) o[0] = r, o[1] = g, o[2] = b;
+        else o[0] = r, o[1] = g, o[2] = b, o[3] = a;
+    }
+    return out;
+}
+
+bool writePNG(const std::string& path, const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels, std::string& why) {
+    if (!pixels || width == 0 || height == 0 || width > kMaxSide || height > kMaxSide || channels < 1 || channels > 4) return why = "writePNG: bad arguments", false;
+    const size_t stride = size_t(width) * channels;
+    std::vector<uint8_t> raw(size_t(height) * (stride + 1)), best(stride), trial(stride);
+    const std::vector<uint8_t> zero(stride, 0);
+    for (uint32_t y = 0; y < height; ++y) {
+        const uint8_t* cur = pixels + size_t(y) * stride;
+        const uint8_t* prev = y ? pixels + size_t(y - 1) * stride : zero.data();
+        uint64_t best_cost = ~0ull;
+        uint8_t best_type = 0;
+        for (uint8_t type = 0; type < 5; ++type) {
+            uint64_t cost = 0;
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= channels ? cur[i - channels] : 0, b = prev[i], c = i >= channels ? prev[i - channels] : 0;
+                const int pred = type == 0 ? 0 : type == 1 ? a : type == 2 ? b : type == 3 ? (a + b) >> 1 : paeth(a, b, c);
+                trial[i] = uint8_t(cur[i] - pred);
+                cost += uint64_t(std::abs(int(int8_t(trial[i]))));
+            }
+            if (cost < best_cost) best_cost = cost, best_type = type, best.swap(trial);
+        }
+        raw[size_t(y) * (stride + 1)] = best_type;
+        std::memcpy(&raw[size_t(y) * (stride + 1) + 1], best.data(), stride);
+    }
+    uLongf packed_size = compressBound(uLong(raw.size()));
+    std::vector<uint8_t> packed(packed_size);
+    if (compress2(packed.data(), &packed_size, raw.data(), uLong(raw.size()), 6) != Z_OK) return why = "writePNG: deflate failed", false;
+
+    std::vector<uint8_t> file(kPngSignature, kPngSignature + 8);
+    auto chunk = [&file](const char* type, const uint8_t* data, size_t len) {
+        put_be32(file, uint32_t(len));
+        const size_t start = file.size();
+        file.insert(file.end(), type, type + 4);
+        if (len) file.insert(file.end(), data, data + len);
+        put_be32(file, uint32_t(crc32(crc32(0L, Z_NULL, 0), file.data() + start, uInt(len + 4))));
+    };
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, width), put_be32(ihdr, height);
+    static const uint8_t color_type[5] = {0, 0, 4, 2, 6};
+    ihdr.push_back(8), ihdr.push_back(color_type[channels]), ihdr.push_back(0), ihdr.push_back(0), ihdr.push_back(0);
+    chunk("IHDR", ihdr.data(), ihdr.size());
+    chunk("IDAT", packed.data(), size_t(packed_size));
+    chunk("IEND", nullptr, 0);
+    std::ofstream f(path, std::ios::binary);
+    if (!f.is_open()) return why = "failed to open " + path + " for writing", false;
+    f.write(reinterpret_cast<const char*>(file.data()), std::streamsize(file.size()));
+    return f.good() ? true : (why = "failed to write " + path, false);
+}
+
+}  // namespace RayZath::Hip::IO

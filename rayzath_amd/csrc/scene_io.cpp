@@ -1,6 +1,8 @@
 // scene_io.cpp — see scene_io.hpp.  Host-only C++17.
 #include "scene_io.hpp"
 
+#include "image_io.hpp"
+
 #include "mini_json.hpp"
 
 #include <algorithm>
@@ -47,49 +49,13 @@ bool is_absolute(const std::string& p) { return !p.empty() && (p[0] == '/' || (p
 std::string make_load_path(const std::string& p, const std::string& base_dir) { return is_absolute(p) ? p : base_dir + p; }
 float clampf(float v, float lo, float hi) { return v < lo ? lo : v > hi ? hi : v; }
 
-// ---- images: binary PPM / PGM only (see the header) ----
-struct Image {
-    uint32_t width = 0, height = 0, channels = 0;
-    std::vector<uint8_t> data;
-};
-bool read_pnm(const std::string& path, Image& img, std::string& why) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f.is_open()) return why = "failed to open " + path, false;
-    auto token = [&f]() {
-        std::string t;
-        int c;
-        while ((c = f.peek()) != EOF) {
-            if (c == '#') {
-                std::string skip;
-                std::getline(f, skip);
-            } else if (std::isspace(c)) {
-                f.get();
-            } else {
-                break;
-            }
-        }
-        while ((c = f.peek()) != EOF && !std::isspace(c)) t.push_back(char(f.get()));
-        return t;
-    };
-    const std::string magic = token();
-    if (magic != "P6" && magic != "P5")
-        return why = path + ": only binary PPM (P6) / PGM (P5) images are decoded here (the reference uses stb_image)", false;
-    const long w = std::atol(token().c_str()), h = std::atol(token().c_str()), maxv = std::atol(token().c_str());
-    if (w <= 0 || h <= 0 || w > 32768 || h > 32768 || maxv != 255) return why = path + ": unsupported PNM header", false;
-    f.get();  // the single whitespace after maxval
-    img.width = uint32_t(w), img.height = uint32_t(h), img.channels = magic == "P6" ? 3u : 1u;
-    img.data.resize(size_t(w) * size_t(h) * img.channels);
-    f.read(reinterpret_cast<char*>(img.data.data()), std::streamsize(img.data.size()));
-    if (size_t(f.gcount()) != img.data.size()) return why = path + ": truncated image", false;
-    return true;
-}
-uint8_t luma(const uint8_t* p) { return uint8_t((p[0] * 77 + p[1] * 150 + p[2] * 29) >> 8); }  // stb_image's RGB -> grey
-
-// BitmapLoader::loadMap<...> (loader.cpp:36-98): RGBA8 / RGBA8 with green negated / R8 / R8 / R32F (gamma 2.2 like stbi_loadf)
+// ---- images (image_io.hpp: PNG, BMP, TGA, binary PPM / PGM) ----
+// BitmapLoader::loadMap<...> (loader.cpp:36-98): RGBA8 (stbi_load(.., 4)) / RGBA8 with green negated / R8 (stbi_load(.., 1)) /
+// R8 / R32F (stbi_loadf(.., 1): stb_image turns 8-bit data into floats with gamma 2.2 and scale 1)
 std::shared_ptr<TextureBuffer> load_map(const std::string& path, uint32_t kind, bool normal_map, LoadLog& log) {
     Image img;
     std::string why;
-    if (!read_pnm(path, img, why)) {
+    if (!readImage(path, img, why)) {
         log.error(why);
         return nullptr;
     }
@@ -97,21 +63,16 @@ std::shared_ptr<TextureBuffer> load_map(const std::string& path, uint32_t kind, 
     t->kind = kind, t->width = img.width, t->height = img.height;
     const size_t n = size_t(img.width) * img.height;
     if (kind == HIPRZ_TEX_RGBA8) {
-        t->bitmap.resize(n * 4);
-        for (size_t i = 0; i < n; ++i) {
-            const uint8_t* p = &img.data[i * img.channels];
-            uint8_t* o = &t->bitmap[i * 4];
-            o[0] = p[0], o[1] = img.channels == 3 ? p[1] : p[0], o[2] = img.channels == 3 ? p[2] : p[0], o[3] = 255;
-            if (normal_map) o[1] = uint8_t(-o[1]);  // loader.cpp:54-66
-        }
+        t->bitmap = convertChannels(img, 4);
+        if (normal_map)
+            for (size_t i = 0; i < n; ++i) t->bitmap[i * 4 + 1] = uint8_t(-t->bitmap[i * 4 + 1]);  // loader.cpp:54-66
     } else if (kind == HIPRZ_TEX_R8) {
-        t->bitmap.resize(n);
-        for (size_t i = 0; i < n; ++i) t->bitmap[i] = img.channels == 3 ? luma(&img.data[i * 3]) : img.data[i];
+        t->bitmap = convertChannels(img, 1);
     } else {
+        const std::vector<uint8_t> grey = convertChannels(img, 1);
         t->bitmap.resize(n * 4);
         for (size_t i = 0; i < n; ++i) {
-            const uint8_t g = img.channels == 3 ? luma(&img.data[i * 3]) : img.data[i];
-            const float v = float(std::pow(g / 255.0f, 2.2f));
+            const float v = float(std::pow(grey[i] / 255.0f, 2.2f));
             std::memcpy(&t->bitmap[i * 4], &v, 4);
         }
     }

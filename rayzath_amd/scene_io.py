@@ -36,13 +36,39 @@ def host_lib():
         lib.hiprz_scene_file_warning_count.restype, lib.hiprz_scene_file_warning_count.argtypes = C.c_uint32, [P]
         lib.hiprz_scene_file_save.restype, lib.hiprz_scene_file_save.argtypes = C.c_int, [P, C.c_char_p, C.c_int]
         lib.hiprz_io_last_error.restype, lib.hiprz_io_last_error.argtypes = C.c_char_p, []
+        U32P = C.POINTER(C.c_uint32)
+        lib.hiprz_image_read.restype, lib.hiprz_image_read.argtypes = C.c_int, [C.c_char_p, C.c_uint32, U32P, U32P, U32P, P, C.c_size_t]
+        lib.hiprz_image_write_png.restype, lib.hiprz_image_write_png.argtypes = C.c_int, [C.c_char_p, P, C.c_uint32, C.c_uint32, C.c_uint32]
         _HOST = lib
     return _HOST
 
 
 IO_ENTRY_POINTS = ("hiprz_scene_file_load", "hiprz_scene_file_free", "hiprz_scene_file_scene", "hiprz_scene_file_camera",
                    "hiprz_scene_file_log", "hiprz_scene_file_error_count", "hiprz_scene_file_warning_count",
-                   "hiprz_scene_file_save", "hiprz_io_last_error")
+                   "hiprz_scene_file_save", "hiprz_io_last_error", "hiprz_image_read", "hiprz_image_write_png")
+
+
+def read_image(path, channels=0):
+    """Decode a PNG / BMP / TGA / binary PNM file with the C++ host library -> uint8 array (height, width, channels).
+    `channels` = 0 keeps the file's own channel count, 1..4 converts the way stb_image does (include/hiprz_io.h)."""
+    lib = host_lib()
+    w, h, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    if lib.hiprz_image_read(os.fsencode(path), channels, C.byref(w), C.byref(h), C.byref(c), None, 0) != 0:
+        raise _lib.HiprzError(-2, lib.hiprz_io_last_error().decode())
+    out = np.zeros((h.value, w.value, c.value), dtype=np.uint8)
+    if lib.hiprz_image_read(os.fsencode(path), channels, None, None, None, out.ctypes.data_as(C.c_void_p), out.nbytes) != 0:
+        raise _lib.HiprzError(-2, lib.hiprz_io_last_error().decode())
+    return out
+
+
+def write_png(path, pixels):
+    """uint8 array (height, width[, channels 1..4]) -> 8-bit PNG, written by the C++ host library."""
+    lib = host_lib()
+    a = np.ascontiguousarray(pixels, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[..., None]
+    if lib.hiprz_image_write_png(os.fsencode(path), a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0], a.shape[2]) != 0:
+        raise _lib.HiprzError(-2, lib.hiprz_io_last_error().decode())
 
 
 def _copy(ptr, count, dtype):

@@ -1,0 +1,301 @@
+"""Image files of maps and saved frames (rayzath_amd/csrc/image_io.cpp behind include/hiprz_io.h) — CPU only.
+
+The decoder is checked against files encoded HERE, independently, in pure Python (struct + zlib): every PNG colour type and bit
+depth, every row filter, palette + tRNS, colour keys, Adam7 interlacing; BMP (8 / 24 / 32 bits, both row orders, bit masks); TGA
+(raw and run-length encoded, grey / RGB / RGBA, both row orders); and the writer is checked by decoding what it wrote, with this
+file's own PNG decoder as the second opinion.  Conventions follow stb_image (what the reference links, loader.cpp:36-98)."""
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+from rayzath_amd import scene_io
+from rayzath_amd._lib import HiprzError
+
+SAMPLES = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}
+ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))
+
+
+def _chunk(kind, data):
+    return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data) & 0xFFFFFFFF)
+
+
+def _pack_rows(samples, depth):
+    """samples: (h, w, n) integers at the file's bit depth -> list of packed row byte strings."""
+    h, w, n = samples.shape
+    rows = []
+    for y in range(h):
+        flat = samples[y].reshape(-1)
+        if depth == 16:
+            rows.append(b"".join(struct.pack(">H", int(v)) for v in flat))
+        elif depth == 8:
+            rows.append(bytes(int(v) for v in flat))
+        else:
+            bits = "".join(format(int(v), f"0{depth}b") for v in flat)
+            bits += "0" * (-len(bits) % 8)
+            rows.append(bytes(int(bits[i:i + 8], 2) for i in range(0, len(bits), 8)))
+    return rows
+
+
+def _paeth(a, b, c):
+    p = a + b - c
+    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+    return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+
+def _filter_rows(rows, bpp, filters):
+    out, prev = b"", bytes(len(rows[0])) if rows else b""
+    for y, row in enumerate(rows):
+        t = filters[y % len(filters)]
+        line = bytearray()
+        for i, v in enumerate(row):
+            a = row[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            pred = (0, a, b, (a + b) >> 1, _paeth(a, b, c))[t]
+            line.append((v - pred) & 0xFF)
+        out += bytes([t]) + bytes(line)
+        prev = row
+    return out
+
+
+def encode_png(samples, color_type, depth, filters=(0, 1, 2, 3, 4), interlace=False, palette=None, trns=None, idat_split=1):
+    h, w, n = samples.shape
+    assert n == SAMPLES[color_type]
+    bpp = max(1, n * depth // 8)
+    raw = b""
+    if interlace:
+        for x0, y0, dx, dy in ADAM7:
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += _filter_rows(_pack_rows(sub, depth), bpp, filters)
+    else:
+        raw = _filter_rows(_pack_rows(samples, depth), bpp, filters)
+    packed = zlib.compress(raw, 6)
+    out = b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color_type, 0, 0, int(interlace)))
+    out += _chunk(b"tEXt", b"Comment\0ancillary chunks are skipped")
+    if palette is not None:
+        out += _chunk(b"PLTE", bytes(np.asarray(palette, dtype=np.uint8).reshape(-1)))
+    if trns is not None:
+        out += _chunk(b"tRNS", trns)
+    step = (len(packed) + idat_split - 1) // idat_split
+    for i in range(0, len(packed), step):
+        out += _chunk(b"IDAT", packed[i:i + step])
+    return out + _chunk(b"IEND", b"")
+
+
+def decode_png_8bit(data):
+    """Second opinion for the writer: a minimal decoder for 8-bit, non-interlaced PNG files (pure Python)."""
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, hdr = 8, b"", None
+    while pos < len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(kind + body) & 0xFFFFFFFF
+        if kind == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif kind == b"IDAT":
+            idat += body
+        pos += 12 + n
+    w, h, depth, ct, _, _, il = hdr
+    assert depth == 8 and il == 0
+    n = SAMPLES[ct]
+    raw, stride = zlib.decompress(idat), w * n
+    out, prev = np.zeros((h, stride), dtype=np.uint8), bytes(stride)
+    for y in range(h):
+        t, line = raw[y * (stride + 1)], bytearray(raw[y * (stride + 1) + 1:(y + 1) * (stride + 1)])
+        for i in range(stride):
+            a = line[i - n] if i >= n else 0
+            b = prev[i]
+            c = prev[i - n] if i >= n else 0
+            line[i] = (line[i] + (0, a, b, (a + b) >> 1, _paeth(a, b, c))[t]) & 0xFF
+        out[y], prev = np.frombuffer(bytes(line), dtype=np.uint8), bytes(line)
+    return out.reshape(h, w, n)
+
+
+def _to8(samples, depth, grey=False):
+    if depth == 16:
+        return (samples >> 8).astype(np.uint8)
+    if depth == 8:
+        return samples.astype(np.uint8)
+    return (samples * {1: 0xFF, 2: 0x55, 4: 0x11}[depth]).astype(np.uint8)
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+@pytest.mark.parametrize("color_type,depth", [(0, 1), (0, 2), (0, 4), (0, 8), (0, 16), (2, 8), (2, 16), (4, 8), (4, 16), (6, 8), (6, 16)])
+def test_png_colour_types_bit_depths_filters_and_interlacing(tmp_path, color_type, depth, interlace):
+    rng = np.random.default_rng(100 * color_type + depth)
+    for w, h in ((1, 1), (5, 3), (13, 11), (32, 9)):
+        samples = rng.integers(0, 1 << depth, size=(h, w, SAMPLES[color_type]))
+        path = tmp_path / f"t_{w}x{h}.png"
+        path.write_bytes(encode_png(samples, color_type, depth, interlace=interlace, idat_split=3))
+        got = scene_io.read_image(str(path))
+        assert got.shape == (h, w, SAMPLES[color_type])
+        assert np.array_equal(got, _to8(samples, depth))
+
+
+def test_png_palette_transparency_and_colour_keys(tmp_path):
+    rng = np.random.default_rng(7)
+    palette = rng.integers(0, 256, size=(6, 3))
+    for depth in (1, 2, 4, 8):
+        idx = rng.integers(0, min(6, 1 << depth), size=(7, 9, 1))
+        (tmp_path / "p.png").write_bytes(encode_png(idx, 3, depth, palette=palette))
+        assert np.array_equal(scene_io.read_image(str(tmp_path / "p.png")), palette[idx[..., 0]].astype(np.uint8))
+        (tmp_path / "pa.png").write_bytes(encode_png(idx, 3, depth, palette=palette, trns=bytes([0, 128, 255])))  # entries 3.. stay opaque
+        alpha = np.array([0, 128, 255, 255, 255, 255], dtype=np.uint8)
+        got = scene_io.read_image(str(tmp_path / "pa.png"))
+        assert got.shape[2] == 4 and np.array_equal(got[..., :3], palette[idx[..., 0]]) and np.array_equal(got[..., 3], alpha[idx[..., 0]])
+    grey = rng.integers(0, 16, size=(6, 6, 1))
+    (tmp_path / "gk.png").write_bytes(encode_png(grey, 0, 4, trns=struct.pack(">H", 5)))
+    got = scene_io.read_image(str(tmp_path / "gk.png"))
+    assert np.array_equal(got[..., 0], grey[..., 0] * 0x11) and np.array_equal(got[..., 1], np.where(grey[..., 0] == 5, 0, 255))
+    rgb = rng.integers(0, 4, size=(8, 8, 3)) * 60
+    (tmp_path / "ck.png").write_bytes(encode_png(rgb, 2, 8, trns=struct.pack(">HHH", 60, 120, 0)))
+    got = scene_io.read_image(str(tmp_path / "ck.png"))
+    key = (rgb[..., 0] == 60) & (rgb[..., 1] == 120) & (rgb[..., 2] == 0)
+    assert np.array_equal(got[..., :3], rgb) and np.array_equal(got[..., 3], np.where(key, 0, 255))
+
+
+def test_channel_conversion_follows_stb_image(tmp_path):
+    rng = np.random.default_rng(3)
+    rgba = rng.integers(0, 256, size=(5, 4, 4))
+    (tmp_path / "c.png").write_bytes(encode_png(rgba, 6, 8))
+    luma = ((rgba[..., 0] * 77 + rgba[..., 1] * 150 + rgba[..., 2] * 29) >> 8).astype(np.uint8)
+    assert np.array_equal(scene_io.read_image(str(tmp_path / "c.png"), 1)[..., 0], luma)
+    two = scene_io.read_image(str(tmp_path / "c.png"), 2)
+    assert np.array_equal(two[..., 0], luma) and np.array_equal(two[..., 1], rgba[..., 3])
+    assert np.array_equal(scene_io.read_image(str(tmp_path / "c.png"), 3), rgba[..., :3])
+    grey = rng.integers(0, 256, size=(3, 3, 1))
+    (tmp_path / "g.png").write_bytes(encode_png(grey, 0, 8))
+    four = scene_io.read_image(str(tmp_path / "g.png"), 4)
+    assert np.array_equal(four[..., :3], np.repeat(grey, 3, axis=2)) and (four[..., 3] == 255).all()
+
+
+def test_damaged_png_files_are_refused(tmp_path):
+    good = encode_png(np.arange(12).reshape(2, 2, 3), 2, 8)
+    cases = {"crc": good[:40] + bytes([good[40] ^ 1]) + good[41:], "cut": good[:-20], "size": good.replace(struct.pack(">II", 2, 2), struct.pack(">II", 2, 3), 1)}
+    for name, data in cases.items():
+        (tmp_path / f"{name}.png").write_bytes(data)
+        with pytest.raises(HiprzError):
+            scene_io.read_image(str(tmp_path / f"{name}.png"))
+    (tmp_path / "x.jpg").write_bytes(b"\xff\xd8\xff\xe0" + bytes(32))
+    with pytest.raises(HiprzError, match="JPEG"):
+        scene_io.read_image(str(tmp_path / "x.jpg"))
+    with pytest.raises(HiprzError, match="failed to open"):
+        scene_io.read_image(str(tmp_path / "nothing.png"))
+
+
+def _bmp(pixels, bpp, top_down=False, masks=None, palette=None):
+    h, w = pixels.shape[:2]
+    stride = ((w * bpp + 31) // 32) * 4
+    rows = []
+    for y in (range(h) if top_down else range(h - 1, -1, -1)):
+        if bpp == 8:
+            row = bytes(int(v) for v in pixels[y, :, 0])
+        elif bpp == 24:
+            row = b"".join(bytes([int(p[2]), int(p[1]), int(p[0])]) for p in pixels[y])
+        elif masks:
+            row = b"".join(struct.pack("<I", (int(p[0]) << 24) | (int(p[1]) << 16) | (int(p[2]) << 8) | int(p[3])) for p in pixels[y])   # R G B A from the top byte down
+        else:
+            row = b"".join(bytes([int(p[2]), int(p[1]), int(p[0]), int(p[3])]) for p in pixels[y])
+        rows.append(row + bytes(stride - len(row)))
+    pal = b"".join(bytes([int(c[2]), int(c[1]), int(c[0]), 0]) for c in palette) if palette is not None else b""
+    extra = struct.pack("<IIII", 0xFF000000, 0x00FF0000, 0x0000FF00, 0x000000FF) if masks else b""
+    dib = struct.pack("<IiiHHIIiiII", 40 + (16 if masks else 0), w, -h if top_down else h, 1, bpp, 3 if masks else 0, stride * h, 2835, 2835, len(palette) if palette is not None else 0, 0) + extra
+    offset = 14 + len(dib) + len(pal)
+    return b"BM" + struct.pack("<IHHI", offset + stride * h, 0, 0, offset) + dib + pal + b"".join(rows)
+
+
+def test_bmp_files(tmp_path):
+    rng = np.random.default_rng(11)
+    rgb = rng.integers(0, 256, size=(5, 7, 3))
+    for top_down in (False, True):
+        (tmp_path / "a.bmp").write_bytes(_bmp(rgb, 24, top_down))
+        assert np.array_equal(scene_io.read_image(str(tmp_path / "a.bmp")), rgb)
+    rgba = rng.integers(1, 256, size=(4, 3, 4))
+    (tmp_path / "b.bmp").write_bytes(_bmp(rgba, 32))
+    assert np.array_equal(scene_io.read_image(str(tmp_path / "b.bmp")), rgba)
+    (tmp_path / "m.bmp").write_bytes(_bmp(rgba, 32, masks=True))
+    assert np.array_equal(scene_io.read_image(str(tmp_path / "m.bmp")), rgba)
+    unused_alpha = rgba.copy()
+    unused_alpha[..., 3] = 0                                         # an all-zero alpha channel means "no alpha": opaque
+    (tmp_path / "z.bmp").write_bytes(_bmp(unused_alpha, 32))
+    got = scene_io.read_image(str(tmp_path / "z.bmp"))
+    assert np.array_equal(got[..., :3], rgba[..., :3]) and (got[..., 3] == 255).all()
+    palette = rng.integers(0, 256, size=(5, 3))
+    idx = rng.integers(0, 5, size=(6, 5, 1))
+    (tmp_path / "p.bmp").write_bytes(_bmp(idx, 8, palette=palette))
+    assert np.array_equal(scene_io.read_image(str(tmp_path / "p.bmp")), palette[idx[..., 0]])
+
+
+def _tga(pixels, rle, top_down):
+    h, w, n = pixels.shape
+    order = range(h) if top_down else range(h - 1, -1, -1)
+    px = [bytes([int(p[0])]) if n == 1 else bytes([int(p[2]), int(p[1]), int(p[0])] + ([int(p[3])] if n == 4 else [])) for y in order for p in pixels[y]]
+    body = b""
+    if not rle:
+        body = b"".join(px)
+    else:
+        i = 0
+        while i < len(px):
+            run = 1
+            while i + run < len(px) and run < 128 and px[i + run] == px[i]:
+                run += 1
+            if run > 1:
+                body += bytes([0x80 | (run - 1)]) + px[i]
+                i += run
+            else:
+                lit = 1
+                while i + lit < len(px) and lit < 128 and (i + lit + 1 >= len(px) or px[i + lit] != px[i + lit + 1]):
+                    lit += 1
+                body += bytes([lit - 1]) + b"".join(px[i:i + lit])
+                i += lit
+    kind = (3 if n == 1 else 2) + (8 if rle else 0)
+    header = struct.pack("<BBBHHBHHHHBB", 4, 0, kind, 0, 0, 0, 0, 0, w, h, 8 * n, (0x20 if top_down else 0) | (8 if n == 4 else 0))
+    return header + b"id! " + body
+
+
+def test_tga_files(tmp_path):
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 4):
+        pixels = rng.integers(0, 3, size=(6, 10, n)) * 100    # few distinct values: the run-length encoder finds runs
+        for rle in (False, True):
+            for top_down in (False, True):
+                (tmp_path / "t.tga").write_bytes(_tga(pixels, rle, top_down))
+                assert np.array_equal(scene_io.read_image(str(tmp_path / "t.tga")), pixels), (n, rle, top_down)
+
+
+def test_png_writer_round_trip(tmp_path):
+    rng = np.random.default_rng(21)
+    for n in (1, 2, 3, 4):
+        for shape in ((1, 1), (7, 5), (64, 33)):
+            smooth = np.add.outer(np.arange(shape[0]) * 3, np.arange(shape[1]) * 2)[..., None] + rng.integers(0, 8, size=shape + (n,))
+            pixels = (smooth % 256).astype(np.uint8)
+            path = tmp_path / "w.png"
+            scene_io.write_png(str(path), pixels)
+            assert np.array_equal(decode_png_8bit(path.read_bytes()), pixels)     # this file's decoder
+            assert np.array_equal(scene_io.read_image(str(path)), pixels)         # and the library's own
+
+
+def test_png_maps_reach_the_flattened_scene(tmp_path):
+    """map_Kd with an alpha channel, a 16-bit normal map and a paletted roughness map, all PNG, through the .mtl loader."""
+    rng = np.random.default_rng(2)
+    rgba = rng.integers(0, 256, size=(2, 2, 4))
+    (tmp_path / "kd.png").write_bytes(encode_png(rgba, 6, 8, interlace=True))
+    nrm16 = rng.integers(0, 65536, size=(2, 2, 3))
+    (tmp_path / "n.png").write_bytes(encode_png(nrm16, 2, 16))
+    (tmp_path / "r.png").write_bytes(encode_png(np.array([[[0], [1]]]), 3, 1, palette=[(10, 10, 10), (200, 200, 200)]))
+    (tmp_path / "m.mtl").write_text("newmtl a\nmap_Kd kd.png\nnorm n.png\nmap_Pr r.png\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\no x\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl a\nf 1 2 3\n")
+    s = scene_io.load_scene_file(str(tmp_path / "m.obj"))
+    assert s.errors == 0, s.log
+    f = s.flat
+    mat = f.materials[2]
+    tex, nrm, rough = f.textures[mat["texture"]], f.textures[mat["normal_map"]], f.textures[mat["roughness_map"]]
+    assert np.array_equal(f.texels[tex["offset"]:tex["offset"] + 16].reshape(2, 2, 4), rgba)
+    n8 = (nrm16 >> 8).astype(np.uint8)
+    want = np.concatenate([n8, np.full((2, 2, 1), 255, dtype=np.uint8)], axis=2)
+    want[..., 1] = (-want[..., 1].astype(np.int32)) & 0xFF                     # green negated (loader.cpp:54-66)
+    assert np.array_equal(f.texels[nrm["offset"]:nrm["offset"] + 16].reshape(2, 2, 4), want)
+    assert list(f.texels[rough["offset"]:rough["offset"] + 2]) == [10, 200]   # grey of (10,10,10) / (200,200,200): (77+150+29) * v >> 8 = v

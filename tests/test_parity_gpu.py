@@ -418,11 +418,11 @@ def test_headless_runner_end_to_end(built, tmp_path):
     m = re.fullmatch(r"Scene: cornell\.json\n\tengine: HIPGPU \| max depth: 4\n\tduration: \d+\.\d{3}s \| traced (\S+) rays \((\S+) rps\)\n", report)
     assert m, report
     assert m.group(1) == "503.8K"   # 41 * 128 * 96 rays: 40 pipelined passes + the final synchronous one
-    images = [f for f in os.listdir(tmp_path) if f.endswith("_HIPGPU.ppm")]
+    images = [f for f in os.listdir(tmp_path) if f.endswith("_HIPGPU.png")]
     assert len(images) == 1
-    data = (tmp_path / images[0]).read_bytes()
-    assert data.startswith(b"P6\n128 96\n255\n") and len(data) == len(b"P6\n128 96\n255\n") + 128 * 96 * 3
-    pixels = np.frombuffer(data[len(b"P6\n128 96\n255\n"):], dtype=np.uint8)
+    frame = scene_io.read_image(str(tmp_path / images[0]))
+    assert frame.shape == (96, 128, 4) and (frame[..., 3] == 255).all()
+    pixels = frame[..., :3]
     assert pixels.max() > 100 and pixels.std() > 10   # an actual picture, not a blank frame
 
 
