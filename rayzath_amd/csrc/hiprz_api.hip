@@ -335,7 +335,15 @@ RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& 
     f.st0[p.local] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
     f.st1[p.local] = make_float4(ray.d.y, ray.d.z, ray_color.r, ray_color.g);
     f.st2[p.local] = make_float2(ray_color.b, __uint_as_float((ray_material & 0xFFFFu) | (depth << 16)));
-    if (f.sort_key) f.sort_key[p.local] = ray_sort_key(s, ray.o, ray.d);
+    if (f.sort_key) f.sort_key[p.local] = ray_sort_key(s, ray.o, ray.d, s.sort_variant);
+    if constexpr (SHADOW == RZ_SHADOW_DEFER) {
+        // the shadow rays of this pixel start at the hit point and point at the light the (last) sample chose: rays from one cell to
+        // one light walk the same instances.  Pixels without a sample have nothing to walk and sort to the end.
+        if (f.shadow_key)
+            f.shadow_key[p.local] = lds_column.defer_mask ? ray_sort_key(s, V3(lds_column.key_o[0], lds_column.key_o[1], lds_column.key_o[2]),
+                                                                         V3(lds_column.key_dir[0], lds_column.key_dir[1], lds_column.key_dir[2]), 0u)
+                                                          : 0x00FFFFFEu;
+    }
 }
 
 template <bool COUNT>
@@ -855,6 +863,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScen
         shade_and_store<FIRST, COUNT, SHADOW>(s, cam, cfg, f, p, ps, found, hit, shadow, cnt);
     } else if (f.sort_key && p.local < f.n_local_tiles * 256u) {
         f.sort_key[p.local] = 0x00FFFFFFu;  // slots outside the frame sort to the end
+        if (f.shadow_key) f.shadow_key[p.local] = 0x00FFFFFFu;
     }
     flush_counters<COUNT>(f, p.active ? 1u : 0u, cnt);
 }
@@ -874,7 +883,8 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_kernel(const DScene s, con
     else
         for (uint32_t i = threadIdx.x; i < top_n; i += 64u) ls[i] = s.node_skip[i];
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
-    const PixelId p = pixel_of_local(f, cam, f.perm ? f.perm[slot] : slot);
+    const uint32_t* order = f.shadow_perm ? f.shadow_perm : f.perm;
+    const PixelId p = pixel_of_local(f, cam, order ? order[slot] : slot);
     Counters cnt;
     if (p.active) {
         const ShadowCtx sc{nullptr, TopCache{ln, ls, top_n, reinterpret_cast<const uint16_t*>(ls)}};
@@ -1172,6 +1182,8 @@ struct hiprz_ctx {
     bool graph_valid = false;
     // ray reordering between passes (split pipeline): keys from the shade kernel -> radix sort -> permutation
     DeviceArray<uint32_t> sort_keys, sort_keys_out, sort_iota, sort_perm;
+    DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
+    int shadow_sort = 1;  // HIPRZ_SHADOW_SORT=0: the shadow kernel follows the next pass's ray order instead
     DeviceArray<uint8_t> sort_temp;
     size_t sort_temp_bytes = 0;
     int sort_rays = -1;  // -1 auto (on for scenes walked with MODE 3), 0 off, 1 on
@@ -1260,7 +1272,7 @@ void release_frame(hiprz_ctx* c) {
     c->hit0.release(), c->hit1.release();
     for (int k = 0; k < 2; ++k) c->rq0[k].release(), c->rq1[k].release(), c->rq2[k].release();
     c->nee_base.release(), c->nee_a.release(), c->nee_b.release(), c->nee_point.release(), c->nee_dir.release(), c->nee_term.release();
-    c->sort_keys.release(), c->sort_keys_out.release(), c->sort_iota.release(), c->sort_perm.release(), c->sort_temp.release();
+    c->sort_keys.release(), c->sort_keys_out.release(), c->sort_iota.release(), c->sort_perm.release(), c->sort_temp.release(), c->shadow_keys.release(), c->shadow_perm.release();
     c->image_f4.release(), c->state_md.release(), c->state_ray.release();
 }
 
@@ -1289,12 +1301,16 @@ int allocate_frame(hiprz_ctx* c) {
     RZ_HIP(c, c->sort_keys_out.resize(n));
     RZ_HIP(c, c->sort_perm.resize(n));
     RZ_HIP(c, c->sort_iota.resize(n));
+    RZ_HIP(c, c->shadow_keys.resize(n));
+    RZ_HIP(c, c->shadow_perm.resize(n));
     if (n) {
         std::vector<uint32_t> iota(n);
         for (size_t i = 0; i < n; ++i) iota[i] = uint32_t(i);
         RZ_HIP(c, hipMemcpyAsync(c->sort_iota.ptr, iota.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         RZ_HIP(c, hipMemcpyAsync(c->sort_perm.ptr, iota.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));  // identity until the first sort
+        RZ_HIP(c, hipMemcpyAsync(c->shadow_perm.ptr, iota.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         RZ_HIP(c, hipMemsetAsync(c->sort_keys.ptr, 0, n * sizeof(uint32_t), c->stream));
+        RZ_HIP(c, hipMemsetAsync(c->shadow_keys.ptr, 0, n * sizeof(uint32_t), c->stream));
         RZ_HIP(c, hipStreamSynchronize(c->stream));
         size_t bytes = 0;
         RZ_HIP(c, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, c->sort_keys.ptr, c->sort_keys_out.ptr, c->sort_iota.ptr,
@@ -1348,6 +1364,9 @@ DFrame make_frame(hiprz_ctx* c, bool counted) {
     const bool sorting = sort_enabled(c);
     f.sort_key = sorting ? c->sort_keys.ptr : nullptr;
     f.perm = sorting ? c->sort_perm.ptr : nullptr;  // always a valid permutation (identity until the first sort)
+    const bool shadow_sorting = sorting && c->shadow_sort != 0 && c->pipeline == 1 && defer_shadows(c);
+    f.shadow_key = shadow_sorting ? c->shadow_keys.ptr : nullptr;
+    f.shadow_perm = shadow_sorting ? c->shadow_perm.ptr : nullptr;
     return f;
 }
 
@@ -1395,6 +1414,7 @@ bool use_lds_scene(const hiprz_ctx* c) {
 }
 
 void launch_sort(hiprz_ctx* c);
+void launch_shadow_sort(hiprz_ctx* c);
 template <bool FIRST, bool COUNT>
 void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_shade = nullptr) {
     c->sorted_this_pass = false;
@@ -1468,6 +1488,7 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
             // the shadow rays start where the next segment's rays start: walk them in the order the next trace kernel will use
             // (origin cell + direction of the next ray), so that a wave's rays meet the same instances
             launch_sort(c);
+            if (f.shadow_key) launch_shadow_sort(c);
             const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;
             const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
             if (COUNT ? c->walk_order == 2 : c->walk_order != 0) {
@@ -1542,6 +1563,14 @@ void launch_sort(hiprz_ctx* c) {
     size_t bytes = c->sort_temp_bytes;
     (void)hipcub::DeviceRadixSort::SortPairs(c->sort_temp.ptr, bytes, c->sort_keys.ptr, c->sort_keys_out.ptr, c->sort_iota.ptr,
                                              c->sort_perm.ptr, int(c->n_local_tiles * 256u), 0, 24, c->stream);
+}
+
+// the same for the keys of the pass's shadow rays -> the order rz_shadow_kernel follows
+void launch_shadow_sort(hiprz_ctx* c) {
+    if (c->n_local_tiles == 0) return;
+    size_t bytes = c->sort_temp_bytes;
+    (void)hipcub::DeviceRadixSort::SortPairs(c->sort_temp.ptr, bytes, c->shadow_keys.ptr, c->sort_keys_out.ptr, c->sort_iota.ptr,
+                                             c->shadow_perm.ptr, int(c->n_local_tiles * 256u), 0, 24, c->stream);
 }
 
 // [cumulative pass, sort, pass update] x n on the stream — eagerly, or into a capture
@@ -1960,6 +1989,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     }
     if (const char* w = std::getenv("HIPRZ_TRACE_WAVES")) c->trace_waves = std::atoi(w);
     if (const char* w = std::getenv("HIPRZ_DEFER_SHADOWS")) c->defer_shadow_rays = std::atoi(w) != 0;
+    if (const char* w = std::getenv("HIPRZ_SHADOW_SORT")) c->shadow_sort = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SHADOW_WALK")) c->shade_shadow_walk = std::atoi(w) == 1 ? 1 : 3;
     c->device = device_id;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -2132,7 +2162,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     // ray reordering key: without lights only the closest-hit walk follows the sorted order and the interleaved origin/direction
     // code groups best (config C: trace kernel 583 -> 503 us); with lights the deferred shadow rays follow it too and they fan out
     // from the origin cell, so the origin leads (config E: 86.5 ms per step against 92.6)
-    d.sort_variant = (sc->n_spot_lights + sc->n_direct_lights) ? 0u : 2u;
+    d.sort_variant = (sc->n_spot_lights + sc->n_direct_lights) && c->shadow_sort == 0 ? 0u : 2u;
     if (const char* v = std::getenv("HIPRZ_SORT_KEY")) d.sort_variant = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_K")) d.walk_k = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_L")) d.walk_l = uint32_t(std::atoi(v));

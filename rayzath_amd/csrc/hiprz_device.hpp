@@ -170,6 +170,8 @@ struct DFrame {
     float4* nee_point;  // [pixel] shadow-ray origin
     float4* nee_dir;    // [sample][pixel] direction, far
     float4* nee_term;   // [sample][pixel] unshadowed contribution
+    uint32_t* shadow_key;         // deferred shadow rays: sort key of the pixel's shadow rays (origin cell + direction towards the light)
+    const uint32_t* shadow_perm;  // rz_shadow_kernel: thread i finishes local pixel shadow_perm[i] (nullptr: follow `perm`)
     unsigned long long* wg_times;  // diagnostics (hiprz_set_workgroup_timing): [2 * workgroup] = start, end of the trace kernel's workgroups (100 MHz clock)
 };
 
@@ -1372,6 +1374,8 @@ struct ShadowCtx {
     float4* nee_term = nullptr;   // [sample][pixel]    (light colour * brdf colour) * radiance
     uint32_t nee_stride = 0u, pixel = 0u;
     mutable uint32_t defer_mask = 0u;  // bit k: sample slot k holds a shadow ray
+    mutable float key_dir[3] = {0.0f, 0.0f, 0.0f};  // direction of the shadow ray in the highest slot (spot samples come last) and the
+    mutable float key_o[3] = {0.0f, 0.0f, 0.0f};    // rays' common origin: what the pixel's shadow sort key is made of
     mutable bool defer_done = false;   // the segment went through directIllumination
     mutable col4 defer_a{0.0f, 0.0f, 0.0f, 0.0f}, defer_b{0.0f, 0.0f, 0.0f, 0.0f};  // final += (direct * a) * b
 };
@@ -1656,6 +1660,10 @@ RZ_DEV void defer_sample(const ShadowCtx& sc, uint32_t slot, const Ray& sr, col4
     sc.nee_dir[at] = make_float4(sr.d.x, sr.d.y, sr.d.z, sr.far_);
     sc.nee_term[at] = make_float4(term.r, term.g, term.b, term.a);
     sc.nee_point[sc.pixel] = make_float4(sr.o.x, sr.o.y, sr.o.z, 0.0f);
+    if ((1u << slot) > sc.defer_mask) {
+        sc.key_dir[0] = sr.d.x, sc.key_dir[1] = sr.d.y, sc.key_dir[2] = sr.d.z;
+        sc.key_o[0] = sr.o.x, sc.key_o[1] = sr.o.y, sc.key_o[2] = sr.o.z;
+    }
     sc.defer_mask |= 1u << slot;
 }
 
@@ -1868,7 +1876,7 @@ RZ_DEV uint32_t spread3(uint32_t v) {  // 5 bits -> every third bit
     v = (v | (v << 2)) & 0x00249249u;
     return v;
 }
-RZ_DEV uint32_t ray_sort_key(const DScene& s, v3 o, v3 d) {
+RZ_DEV uint32_t ray_sort_key(const DScene& s, v3 o, v3 d, uint32_t variant) {
     const float cx = fminf(fmaxf((o.x - s.bounds_min[0]) * s.bounds_scale[0], 0.0f), 31.0f);
     const float cy = fminf(fmaxf((o.y - s.bounds_min[1]) * s.bounds_scale[1], 0.0f), 31.0f);
     const float cz = fminf(fmaxf((o.z - s.bounds_min[2]) * s.bounds_scale[2], 0.0f), 31.0f);
@@ -1877,8 +1885,8 @@ RZ_DEV uint32_t ray_sort_key(const DScene& s, v3 o, v3 d) {
     const uint32_t qx = uint32_t(fminf(fmaxf(d.x * inv * 3.99f + 4.0f, 0.0f), 7.0f));
     const uint32_t qy = uint32_t(fminf(fmaxf(d.y * inv * 3.99f + 4.0f, 0.0f), 7.0f));
     const uint32_t qz = uint32_t(fminf(fmaxf(d.z * inv * 3.99f + 4.0f, 0.0f), 7.0f));
-    if (s.sort_variant == 1u) return (((qx << 6) | (qy << 3) | qz) << 15) | morton;  // direction-major
-    if (s.sort_variant == 2u) {  // 6-D Morton code: 4 bits of each origin cell coordinate and of each direction component, interleaved
+    if (variant == 1u) return (((qx << 6) | (qy << 3) | qz) << 15) | morton;  // direction-major
+    if (variant == 2u) {  // 6-D Morton code: 4 bits of each origin cell coordinate and of each direction component, interleaved
         const uint32_t px = uint32_t(cx) >> 1, py = uint32_t(cy) >> 1, pz = uint32_t(cz) >> 1;
         const uint32_t dx = uint32_t(fminf(fmaxf(d.x * inv * 7.99f + 8.0f, 0.0f), 15.0f)), dy = uint32_t(fminf(fmaxf(d.y * inv * 7.99f + 8.0f, 0.0f), 15.0f)),
                        dz = uint32_t(fminf(fmaxf(d.z * inv * 7.99f + 8.0f, 0.0f), 15.0f));
