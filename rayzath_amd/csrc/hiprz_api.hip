@@ -341,7 +341,7 @@ RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& 
         // one light walk the same instances.  Pixels without a sample have nothing to walk and sort to the end.
         if (f.shadow_key)
             f.shadow_key[p.local] = lds_column.defer_mask ? ray_sort_key(s, V3(lds_column.key_o[0], lds_column.key_o[1], lds_column.key_o[2]),
-                                                                         V3(lds_column.key_dir[0], lds_column.key_dir[1], lds_column.key_dir[2]), 0u)
+                                                                         V3(lds_column.key_dir[0], lds_column.key_dir[1], lds_column.key_dir[2]), s.shadow_variant)
                                                           : 0x00FFFFFEu;
     }
 }
@@ -2163,6 +2163,8 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     // code groups best (config C: trace kernel 583 -> 503 us); with lights the deferred shadow rays follow it too and they fan out
     // from the origin cell, so the origin leads (config E: 86.5 ms per step against 92.6)
     d.sort_variant = (sc->n_spot_lights + sc->n_direct_lights) && c->shadow_sort == 0 ? 0u : 2u;
+    d.shadow_variant = 0u;
+    if (const char* v = std::getenv("HIPRZ_SHADOW_KEY")) d.shadow_variant = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_SORT_KEY")) d.sort_variant = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_K")) d.walk_k = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_L")) d.walk_l = uint32_t(std::atoi(v));

@@ -117,6 +117,7 @@ struct DScene {
     // ray-direction octants; the first top_count_ordered of them have links that fit the 16-bit LDS copy
     const float4* nodes64;
     uint32_t top_count_ordered;
+    uint32_t shadow_variant;  // the same for the shadow rays' key (HIPRZ_SHADOW_KEY)
     uint32_t sort_variant;  // ray_sort_key layout (HIPRZ_SORT_KEY): 0 origin cell then direction, 1 direction then cell, 2 interleaved
 };
 

@@ -211,6 +211,112 @@ std::shared_ptr<Mesh> generateSphere(uint32_t r, bool normals, bool texcrds) {
     return m;
 }
 
+// Math::vec3 rotations as the reference's CUDA restatement spells them (cuda_render_parts.cuh:116-139; hiprz_host.cpp uses the same)
+struct V3f {
+    float x, y, z;
+};
+inline V3f rot_x(V3f v, float a) {
+    const float s = std::sin(a), c = std::cos(a);
+    return {v.x, v.y * c + v.z * s, v.y * -s + v.z * c};
+}
+inline V3f rot_y(V3f v, float a) {
+    const float s = std::sin(a), c = std::cos(a);
+    return {v.x * c - v.z * s, v.y, v.x * s + v.z * c};
+}
+inline V3f rot_z(V3f v, float a) {
+    const float s = std::sin(a), c = std::cos(a);
+    return {v.x * c + v.y * s, v.x * -s + v.y * c, v.z};
+}
+inline void push_normal(Mesh& m, V3f n) { m.normals.push_back(n.x), m.normals.push_back(n.y), m.normals.push_back(n.z); }
+
+// World::generateMesh<CommonMesh::Cone> (world.cpp:342-397): unit base circle in y = 0, apex (0, 1, 0), two normals per side face
+std::shared_ptr<Mesh> generateCone(uint32_t side_faces, bool normals) {
+    if (side_faces < 3) fail("cone should have at least 3 side faces");
+    auto m = std::make_shared<Mesh>();
+    const float pi = 3.14159265358979323846f;
+    const float delta_phi = pi * 2.0f / float(side_faces), offset_phi = delta_phi * 0.5f;
+    for (uint32_t i = 0; i < side_faces; ++i) {
+        const float angle = delta_phi * float(i) + offset_phi;
+        m->createVertex(std::cos(angle), 0.0f, std::sin(angle));
+    }
+    const uint32_t apex = m->createVertex(0.0f, 1.0f, 0.0f);
+    for (uint32_t i = 0; i < side_faces; ++i) {
+        const float angle = delta_phi * float(i) + offset_phi;
+        push_normal(*m, rot_y(rot_x(V3f{0.0f, 1.0f, 0.0f}, 0.25f * pi), angle + 0.5f * pi));
+        push_normal(*m, rot_y(rot_x(V3f{0.0f, 1.0f, 0.0f}, 0.25f * pi), angle + 0.5f * pi + 0.5f * delta_phi));
+    }
+    const std::array<uint32_t, 3> unused{Mesh::ids_unused, Mesh::ids_unused, Mesh::ids_unused};
+    for (uint32_t i = 0; i < side_faces; ++i)
+        m->createTriangle({apex, (i + 1) % side_faces, i}, unused,
+                          normals ? std::array<uint32_t, 3>{(i * 2 + 1) % (side_faces * 2), ((i + 1) * 2) % (side_faces * 2), i * 2} : unused);
+    for (uint32_t i = 0; i + 2 < side_faces; ++i) m->createTriangle({0, i + 1, (i + 2) % side_faces});
+    return m;
+}
+
+// World::generateMesh<CommonMesh::Cylinder> (world.cpp:399-479): radius 1, y in [-1, 1], one texcrd, one normal per side edge
+std::shared_ptr<Mesh> generateCylinder(uint32_t faces, bool normals) {
+    if (faces < 3) fail("cylinder should have at least 3 faces");
+    auto m = std::make_shared<Mesh>();
+    const float pi = 3.14159265358979323846f;
+    const uint32_t n_vertices = faces * 2;
+    m->createTexcrd(0.5f, 0.5f);
+    const float delta_theta = pi * 2.0f / float(faces), offset_theta = delta_theta * 0.5f;
+    for (uint32_t i = 0; i < faces; ++i) {
+        const float angle = delta_theta * float(i) + offset_theta;
+        m->createVertex(std::cos(angle), -1.0f, std::sin(angle));
+        m->createVertex(std::cos(angle), +1.0f, std::sin(angle));
+        if (normals) push_normal(*m, rot_y(V3f{1.0f, 0.0f, 0.0f}, angle));
+    }
+    auto v = [n_vertices](uint32_t idx) { return idx % n_vertices; };
+    for (uint32_t i = 0; i + 2 < faces; ++i) {
+        m->createTriangle({0, v((i + 1) * 2), v((i + 2) * 2)});              // bottom
+        m->createTriangle({1, v((i + 2) * 2 + 1), v((i + 1) * 2 + 1)});      // top
+    }
+    for (uint32_t i = 0; i < faces; ++i) {                                    // side
+        if (normals) {
+            m->createTriangle({v(i * 2), v(i * 2 + 1), v((i + 1) * 2 + 1)}, {0, 0, 0}, {i, i, (i + 1) % faces});
+            m->createTriangle({v(i * 2), v((i + 1) * 2 + 1), v((i + 1) * 2)}, {0, 0, 0}, {i, (i + 1) % faces, (i + 1) % faces});
+        } else {
+            m->createTriangle({v(i * 2), v(i * 2 + 1), v((i + 1) * 2 + 1)});
+            m->createTriangle({v(i * 2), v((i + 1) * 2 + 1), v((i + 1) * 2)});
+        }
+    }
+    return m;
+}
+
+// World::generateMesh<CommonMesh::Torus> (world.cpp:481-560): ring of radius `major_radius` in the xz plane, tube of `minor_radius`
+std::shared_ptr<Mesh> generateTorus(uint32_t minor_resolution, uint32_t major_resolution, float minor_radius, float major_radius, bool normals, bool texcrds) {
+    if (minor_resolution < 3 || major_resolution < 3) fail("resolution should be at least 3");
+    auto m = std::make_shared<Mesh>();
+    const float pi = 3.14159265358979323846f;
+    const float d_phi = pi * 2.0f / float(major_resolution), offset_phi = d_phi * 0.5f, d_theta = pi * 2.0f / float(minor_resolution);
+    for (uint32_t M = 0; M < major_resolution; ++M) {
+        const float a_phi = d_phi * float(M) + offset_phi;
+        for (uint32_t k = 0; k < minor_resolution; ++k) {
+            const float a_theta = d_theta * float(k);
+            const V3f center = rot_y(V3f{1.0f, 0.0f, 0.0f}, a_phi), normal = rot_y(rot_z(V3f{1.0f, 0.0f, 0.0f}, -a_theta), a_phi);
+            m->createVertex(center.x * major_radius + normal.x * minor_radius, center.y * major_radius + normal.y * minor_radius,
+                            center.z * major_radius + normal.z * minor_radius);
+            if (normals) push_normal(*m, normal);
+        }
+    }
+    if (texcrds)
+        for (uint32_t M = 0; M <= major_resolution; ++M)
+            for (uint32_t k = 0; k <= minor_resolution; ++k) m->createTexcrd(float(M) / float(major_resolution), float(k) / float(minor_resolution));
+    const std::array<uint32_t, 3> unused{Mesh::ids_unused, Mesh::ids_unused, Mesh::ids_unused};
+    const uint32_t r = minor_resolution, R = major_resolution;
+    for (uint32_t M = 0; M < R; ++M)
+        for (uint32_t k = 0; k < r; ++k) {
+            const std::array<uint32_t, 3> v1{M * r + k, M * r + (k + 1) % r, ((M + 1) % R) * r + (k + 1) % r};
+            const std::array<uint32_t, 3> t1{M * (r + 1) + k, M * (r + 1) + k + 1, (M + 1) * (r + 1) + k + 1};
+            m->createTriangle(v1, texcrds ? t1 : unused, normals ? v1 : unused);
+            const std::array<uint32_t, 3> v2{M * r + k, ((M + 1) % R) * r + (k + 1) % r, ((M + 1) % R) * r + k};
+            const std::array<uint32_t, 3> t2{M * (r + 1) + k, (M + 1) * (r + 1) + k + 1, (M + 1) * (r + 1) + k};
+            m->createTriangle(v2, texcrds ? t2 : unused, normals ? v2 : unused);
+        }
+    return m;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // .mtl
 // ---------------------------------------------------------------------------------------------------------
@@ -679,8 +785,36 @@ struct SceneLoader {
             }
             return generateSphere(std::max(res, 4u), normals, texcrds);
         }
-        log.error(std::string("\"") + which + "\" is not available in this host library (cube, plane and sphere are).");
-        return nullptr;
+        if (!std::strcmp(which, "generate cone")) {
+            uint32_t faces = 16;
+            bool normals = true;  // CommonMeshParameters<Cone> (world.hpp); "texcrds" is parsed by the reference and has no effect
+            for (const auto& [key, value] : g.members) {
+                if (key == "resolution" && value.is_number()) faces = resolution(value);
+                if (key == "normals" && value.is_bool()) normals = value.b;
+            }
+            return generateCone(faces, normals);
+        }
+        if (!std::strcmp(which, "generate cylinder")) {
+            uint32_t faces = 16;
+            bool normals = true;
+            for (const auto& [key, value] : g.members) {
+                if (key == "resolution" && value.is_number()) faces = resolution(value);
+                if (key == "normals" && value.is_bool()) normals = value.b;
+            }
+            return generateCylinder(faces, normals);
+        }
+        uint32_t minor_res = 16, major_res = 32;  // "generate torus": CommonMeshParameters<Torus>
+        float minor_radius = 0.25f, major_radius = 1.0f;
+        bool normals = true, texcrds = true;
+        for (const auto& [key, value] : g.members) {
+            if (key == "minor resolution" && value.is_number()) minor_res = resolution(value);
+            if (key == "major resolution" && value.is_number()) major_res = resolution(value);
+            if (key == "minor radious" && value.is_number()) minor_radius = std::max(as_float(value), 0.0f);
+            if (key == "major radious" && value.is_number()) major_radius = std::max(as_float(value), 0.0f);
+            if (key == "normals" && value.is_bool()) normals = value.b;
+            if (key == "texcrds" && value.is_bool()) texcrds = value.b;
+        }
+        return generateTorus(minor_res, major_res, minor_radius, major_radius, normals, texcrds);
     }
     std::shared_ptr<Mesh> load_mesh(const Json& j) {  // json_loader.cpp:538-662
         if (j.is_string()) {

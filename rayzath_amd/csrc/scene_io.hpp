@@ -55,8 +55,12 @@ void loadScene(const std::string& json_path, World& world, LoadLog& log);
 void saveScene(const std::string& json_path, const World& world);
 void saveOBJ(const std::string& obj_path, const World& world);
 
-// procedural meshes of world.cpp reachable from scene files ("generate cube|plane|sphere")
+// procedural meshes of world.cpp reachable from scene files ("generate cube|plane|sphere|cone|cylinder|torus")
 std::shared_ptr<Mesh> generatePlane(uint32_t sides, float width, float height);             // world.cpp:168-200
 std::shared_ptr<Mesh> generateSphere(uint32_t resolution, bool normals, bool texcrds);     // world.cpp:202-341 (UV sphere)
+std::shared_ptr<Mesh> generateCone(uint32_t side_faces, bool normals);                     // world.cpp:342-397
+std::shared_ptr<Mesh> generateCylinder(uint32_t faces, bool normals);                      // world.cpp:399-479
+std::shared_ptr<Mesh> generateTorus(uint32_t minor_resolution, uint32_t major_resolution, float minor_radius, float major_radius, bool normals,
+                                    bool texcrds);                                         // world.cpp:481-560
 
 }  // namespace RayZath::Hip::IO

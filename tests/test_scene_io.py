@@ -270,3 +270,58 @@ def test_headless_task_file_errors(tmp_path):
     assert r.returncode == 1 and "Unknown engine type" in r.stderr
     r = subprocess.run([HEADLESS], capture_output=True, text=True)
     assert r.returncode == 2
+
+
+def test_generated_cone_cylinder_torus(tmp_path):
+    """"generate cone | cylinder | torus" (json_loader.cpp:471-533 -> world.cpp:342-560): triangle and vertex counts, the surfaces
+    the vertices lie on, outward unit normals, winding consistent with them."""
+    doc = """{ "Objects": {
+      "Mesh": [ {"name": "cone", "generate cone": {"resolution": 7}},
+                {"name": "cyl", "generate cylinder": {"resolution": 9, "normals": true}},
+                {"name": "flatcyl", "generate cylinder": {"resolution": 5, "normals": false}},
+                {"name": "torus", "generate torus": {"minor resolution": 6, "major resolution": 10, "minor radious": 0.5, "major radious": 2.0}} ],
+      "Camera": [ {"name": "c", "resolution": [8, 8]} ],
+      "Instance": [ {"name": "a", "Mesh": "cone"}, {"name": "b", "Mesh": "cyl"}, {"name": "c", "Mesh": "flatcyl"}, {"name": "d", "Mesh": "torus"} ] } }"""
+    (tmp_path / "g.json").write_text(doc)
+    s = scene_io.load_scene_file(str(tmp_path / "g.json"))
+    assert s.errors == 0, s.log
+    f = s.flat
+    counts = [7 + 5, 2 * 7 + 2 * 9, 2 * 3 + 2 * 5, 2 * 6 * 10]
+    assert len(f.tris) == sum(counts)
+    # triangles are stored per mesh in tree-leaf order: recover each mesh's triangles through its instance's tree
+    def mesh_tris(inst):
+        out, stack = [], [int(f.instances[inst]["blas_root"])]
+        while stack:
+            n = f.nodes[stack.pop()]
+            if n["meta"] & 0x80000000:
+                out += list(range(int(n["begin"]), int(n["begin"]) + int(n["meta"] & 0x1FFFFFFF)))
+            else:
+                stack += [int(n["begin"]), int(n["begin"]) + 1]
+        return np.array(sorted(out))
+    per_mesh = [mesh_tris(i) for i in range(4)]
+    assert [len(t) for t in per_mesh] == counts
+    def verts(ids):
+        return np.concatenate([f.tris[k][ids] for k in ("v1", "v2", "v3")])
+    cone = verts(per_mesh[0])
+    on_base = np.isclose(cone[:, 1], 0.0, atol=1e-6)
+    assert np.allclose(np.hypot(cone[on_base, 0], cone[on_base, 2]), 1.0, atol=1e-5) and np.allclose(cone[~on_base], [0, 1, 0], atol=1e-6)
+    for ids in per_mesh[1:3]:
+        cyl = verts(ids)
+        assert np.allclose(np.hypot(cyl[:, 0], cyl[:, 2]), 1.0, atol=1e-5) and np.allclose(np.abs(cyl[:, 1]), 1.0)
+    torus = verts(per_mesh[3])
+    ring = np.hypot(torus[:, 0], torus[:, 2]) - 2.0
+    assert np.allclose(np.hypot(ring, torus[:, 1]), 0.5, atol=1e-5)
+    # smooth normals: unit length and pointing away from the axis / the ring
+    attrs = f.tri_attrs[per_mesh[3]]
+    for vk, nk in (("v1", "n1"), ("v2", "n2"), ("v3", "n3")):
+        p, n = f.tris[vk][per_mesh[3]], attrs[nk]
+        centre = np.stack([p[:, 0], np.zeros(len(p)), p[:, 2]], axis=1)
+        centre *= (2.0 / np.hypot(p[:, 0], p[:, 2]))[:, None]
+        assert np.allclose(np.linalg.norm(n, axis=1), 1.0, atol=1e-5)
+        assert np.allclose(n, (p - centre) / 0.5, atol=1e-4)
+    # the side triangles of the smooth cylinder carry normals that point away from the axis
+    attrs = f.tri_attrs[per_mesh[1]]
+    side = np.abs(attrs["n1"][:, 1]) < 0.5
+    side &= ~np.isclose(f.tris["v1"][per_mesh[1]][:, 1], f.tris["v3"][per_mesh[1]][:, 1]) | ~np.isclose(f.tris["v1"][per_mesh[1]][:, 1], f.tris["v2"][per_mesh[1]][:, 1])
+    p, n = f.tris["v1"][per_mesh[1]][side], attrs["n1"][side]
+    assert side.sum() == 18 and (np.einsum("ij,ij->i", p * [1, 0, 1], n) > 0.9).all()
