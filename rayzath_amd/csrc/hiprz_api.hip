@@ -496,32 +496,25 @@ __global__ void __launch_bounds__(256, RZ_TRACE_MIN_WAVES) rz_trace_kernel(const
     }
 }
 
-// LDS copy of the 8 per-octant link tables of the first top_n nodes (front-to-back mesh walk), 16 bits per link: the upload
-// guarantees that these links are RZ_END or below 0xFFFF (DScene::top_count_ordered).
-RZ_DEV void stage_skip8(const DScene& s, uint16_t* l16, uint32_t top_n, uint32_t wg) {
-    for (uint32_t o = 0; o < 8u; ++o)
-        for (uint32_t n = threadIdx.x; n < top_n; n += wg) {
-            const uint32_t v = reinterpret_cast<const uint32_t*>(s.nodes64 + 4 * size_t(n) + 2)[o];
-            l16[o * top_n + n] = uint16_t(v == RZ_END ? 0xFFFFu : v);
-        }
-}
-
 // MODE 3 trace kernel, one wave per workgroup.  A workgroup's registers and LDS stay allocated until its LAST wave ends and
 // a wave lasts as long as its slowest ray, so with heavy-tailed ray costs single-wave workgroups give their slots back sooner
 // (config D 3 378 -> 3 093 us, C 974 -> 910 us against 256 threads); the price is a smaller share of LDS for the tree-top cache
 // (top_n nodes per workgroup).  MINW = waves per SIMD the register budget is cut for: big trees are bound by the latency of
 // their node fetches and want occupancy (D: 6 waves 2 959 us, 4 waves 3 370 us), trees that live in L2 / LDS want registers
 // (C: 4 waves 879 us, 6 waves 984 us).
+#ifndef RZ_TRACE_PARK
+#define RZ_TRACE_PARK 1
+#endif
 template <bool FIRST, bool COUNT, int MINW, bool ORDERED>
 __global__ void __launch_bounds__(64, MINW) rz_trace_skip_kernel(const DScene s, const DCamera cam, const DFrame f, uint32_t top_n) {
     constexpr int WG = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
     float4* ln = reinterpret_cast<float4*>(rz_lds);
     uint32_t* ls = reinterpret_cast<uint32_t*>(rz_lds + top_n * 32u);
-    for (uint32_t i = threadIdx.x; i < 2u * top_n; i += uint32_t(WG)) ln[i] = s.nodes[i];
-    if constexpr (ORDERED) stage_skip8(s, reinterpret_cast<uint16_t*>(ls), top_n, uint32_t(WG));
-    else
+    if constexpr (!ORDERED) {  // the front-to-back walk reads its 64-B records straight from L1 / L2 (top_n = 0): LDS only parks state
+        for (uint32_t i = threadIdx.x; i < 2u * top_n; i += uint32_t(WG)) ln[i] = s.nodes[i];
         for (uint32_t i = threadIdx.x; i < top_n; i += uint32_t(WG)) ls[i] = s.node_skip[i];
+    }
     if constexpr (WG > 64) __syncthreads();
     const uint32_t slot = blockIdx.x * uint32_t(WG) + threadIdx.x;
     const PixelId p = pixel_of_local(f, cam, (!FIRST && f.perm) ? f.perm[slot] : slot);
@@ -536,8 +529,10 @@ __global__ void __launch_bounds__(64, MINW) rz_trace_skip_kernel(const DScene s,
     hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
     int found = 0;
     if (p.active && s.n_instances != 0u) {
-        const TopCache top{ln, ls, top_n, reinterpret_cast<const uint16_t*>(ls)};
-        found = closest_hit_skip<COUNT, RZ_TRACE_SHARED_RCP != 0, ORDERED>(s, top, ray, hit, cnt);
+        // MINW 6 (80 VGPRs): the world-space ray waits in LDS while a mesh is walked (closest_hit_skip<.., PARK>)
+        constexpr bool PARK = ORDERED && MINW >= 6 && RZ_TRACE_PARK != 0;
+        const TopCache top{ln, ls, top_n, reinterpret_cast<float*>(rz_lds)};
+        found = closest_hit_skip<COUNT, RZ_TRACE_SHARED_RCP != 0, ORDERED, PARK>(s, top, ray, hit, cnt);
     }
     if (p.active) {
         f.hit0[p.local] = make_float4(ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
@@ -878,16 +873,16 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_kernel(const DScene s, con
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
     float4* ln = reinterpret_cast<float4*>(rz_lds);
     uint32_t* ls = reinterpret_cast<uint32_t*>(rz_lds + top_n * 32u);
-    for (uint32_t i = threadIdx.x; i < 2u * top_n; i += 64u) ln[i] = s.nodes[i];
-    if constexpr (ORDERED) stage_skip8(s, reinterpret_cast<uint16_t*>(ls), top_n, 64u);
-    else
+    if constexpr (!ORDERED)
+        for (uint32_t i = threadIdx.x; i < 2u * top_n; i += 64u) ln[i] = s.nodes[i];
+    if constexpr (!ORDERED)
         for (uint32_t i = threadIdx.x; i < top_n; i += 64u) ls[i] = s.node_skip[i];
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
     const uint32_t* order = f.shadow_perm ? f.shadow_perm : f.perm;
     const PixelId p = pixel_of_local(f, cam, order ? order[slot] : slot);
     Counters cnt;
     if (p.active) {
-        const ShadowCtx sc{nullptr, TopCache{ln, ls, top_n, reinterpret_cast<const uint16_t*>(ls)}};
+        const ShadowCtx sc{nullptr, TopCache{ln, ls, top_n}};
         const float4 base = f.nee_base[p.local];
         const uint32_t bits = __float_as_uint(base.w);
         const bool path_continues = (bits & 1u) != 0u;
@@ -1465,9 +1460,9 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
             const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;
             // tree-top cache: 160 KiB of LDS over 24 (6 waves per SIMD) or 16 (4) single-wave workgroups per CU
             if (COUNT ? c->walk_order == 2 : c->walk_order != 0) {  // front-to-back mesh walks: 48 B of LDS per cached node instead of 36
-                const uint32_t top_n = std::min<uint32_t>(c->dscene.top_count_ordered, big_trees ? 128u : 204u);
-                if (big_trees) hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 6, true>), dim3(n_wg), dim3(64), TopCache::bytes_host_ordered(top_n), c->stream, c->dscene, c->dcamera, f, top_n);
-                else hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 4, true>), dim3(n_wg), dim3(64), TopCache::bytes_host_ordered(top_n), c->stream, c->dscene, c->dcamera, f, top_n);
+                const size_t park = TopCache::park_bytes_host();  // no tree-top cache: see fetch_node_ordered
+                if (big_trees) hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 6, true>), dim3(n_wg), dim3(64), park, c->stream, c->dscene, c->dcamera, f, 0u);
+                else hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 4, true>), dim3(n_wg), dim3(64), park, c->stream, c->dscene, c->dcamera, f, 0u);
             } else {
                 const uint32_t top_n = std::min<uint32_t>(c->dscene.top_count, big_trees ? 170u : 272u);
                 if (big_trees) hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 6, false>), dim3(n_wg), dim3(64), TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, f, top_n);
@@ -1492,9 +1487,8 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
             const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;
             const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
             if (COUNT ? c->walk_order == 2 : c->walk_order != 0) {
-                const uint32_t top_n = std::min<uint32_t>(c->dscene.top_count_ordered, big_trees ? 128u : 204u);
-                if (big_trees) hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 6, true>), sgrid, sblock, TopCache::bytes_host_ordered(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
-                else hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 4, true>), sgrid, sblock, TopCache::bytes_host_ordered(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
+                if (big_trees) hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 6, true>), sgrid, sblock, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+                else hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 4, true>), sgrid, sblock, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
             } else {
                 const uint32_t top_n = std::min<uint32_t>(c->dscene.top_count, big_trees ? 170u : 272u);
                 if (big_trees) hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 6, false>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
@@ -2150,12 +2144,6 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     }
     d.top_count = std::min<uint32_t>(sc->n_nodes, kTopCacheNodes);
     d.nodes64 = reinterpret_cast<const float4*>(c->nodes64.ptr);
-    d.top_count_ordered = d.top_count;  // the LDS copy of the octant links is 16 bits wide
-    for (uint32_t n = 0; n < d.top_count_ordered; ++n)
-        for (uint32_t o = 0; o < 8u; ++o) {
-            const uint32_t l = derived.dskip8[size_t(n) * 8u + o];
-            if (l != RZ_END && l >= 0xFFFFu) d.top_count_ordered = n;
-        }
     c->n_nodes = sc->n_nodes;
     // mesh walk rounds of at most 4 node steps and 8 triangles per lane (measured: D 3 163 -> 2 891 us, C 935 -> 892 us)
     d.walk_k = 4u, d.walk_l = 8u;

@@ -114,9 +114,8 @@ struct DScene {
     const uint32_t* node_skip;     // link to the node that follows a node's subtree (same numbering as `nodes`)
     uint32_t walk_k, walk_l;       // MODE 3 mesh walk: node steps / triangle tests per lane per round (0 = unbounded)
     // front-to-back mesh walk (hiprz_set_walk_order): 64-B records = node (32 B) + its skip link under each of the 8
-    // ray-direction octants; the first top_count_ordered of them have links that fit the 16-bit LDS copy
+    // ray-direction octants
     const float4* nodes64;
-    uint32_t top_count_ordered;
     uint32_t shadow_variant;  // the same for the shadow rays' key (HIPRZ_SHADOW_KEY)
     uint32_t sort_variant;  // ray_sort_key layout (HIPRZ_SORT_KEY): 0 origin cell then direction, 1 direction then cell, 2 interleaved
 };
@@ -977,34 +976,32 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
 // (hiprz_api.hip: relayout), so the levels nearest the roots — the ones every ray visits — form a prefix;
 // each workgroup stages that prefix (nodes + links) into LDS.  Following skip links instead of popping a
 // stack means the walk needs no LDS stack at all, which is what frees the space for the cache.
+#define RZ_PARK_WORDS 6u
 struct TopCache {
     const float4* nodes;   // LDS: top_count x 2 float4
     const uint32_t* skip;  // LDS: top_count
     uint32_t count;
-    const uint16_t* skip8 = nullptr;  // LDS, front-to-back walk: [octant][top_count] links (0xFFFF = end)
+    float* park = nullptr;            // LDS, RZ_PARK_WORDS x 64 floats: per-lane world-level state while a lane is inside a mesh (closest_hit_skip<.., PARK>)
+    static __host__ uint32_t park_bytes_host() { return RZ_PARK_WORDS * 64u * 4u; }
     static __host__ uint32_t bytes_host(uint32_t top_count) { return top_count * 36u; }
-    static __host__ uint32_t bytes_host_ordered(uint32_t top_count) { return top_count * 48u; }
 };
 // Front-to-back mesh walk.  The reference visits a node's first child, then its second (cpu_engine_kernel.cpp:331-352);
 // its builder puts the centroids BELOW the split plane into the first child (bvh_tree_node.hpp:150-215), so that fixed order is
 // front-to-back only for rays that travel up the split axis.  Which child a ray should enter first depends on nothing but the
 // sign of its direction along the node's split axis, i.e. on the ray's octant: per octant the whole visiting order is fixed, and
 // so are the skip links.  The upload derives the links of all 8 octants (64-B records: node + 8 links); a lane picks its table
-// once per mesh and the walk stays stack-free.  The closest hit is the same: among equal distances the triangle the reference
+// once per mesh and the walk stays stack-free (and LDS-free).  The closest hit is the same: among equal distances the triangle the reference
 // would have met first (lower index — triangles are stored in the reference's visiting order) wins (tri_hit_ordered).
 // octant bit p = the direction component along the axis of partition type p is negative (X=2, Y=1, Z=0; type 3 = split by size:
 // never flipped).
 RZ_DEV uint32_t octant_of(v3 d) { return uint32_t(d.z < 0.0f) | (uint32_t(d.y < 0.0f) << 1) | (uint32_t(d.x < 0.0f) << 2); }
-RZ_DEV void fetch_node_ordered(const DScene& s, const TopCache& top, uint32_t n, uint32_t oct, float4& n0, float4& n1, uint32_t& link) {
-    if (n < top.count) {
-        n0 = top.nodes[2 * n], n1 = top.nodes[2 * n + 1];
-        const uint32_t l = top.skip8[oct * top.count + n];
-        link = l == 0xFFFFu ? RZ_END : l;
-    } else {
-        const float4* rec = s.nodes64 + 4 * size_t(n);
-        n0 = rec[0], n1 = rec[1];
-        link = reinterpret_cast<const uint32_t*>(rec + 2)[oct];
-    }
+RZ_DEV void fetch_node_ordered(const DScene& s, uint32_t n, uint32_t oct, float4& n0, float4& n1, uint32_t& link) {
+    // straight from the 64-B records: with rays in sorted order and every lane entering the nearer child first the top levels stay
+    // in L1, and an LDS copy of them costs more than it saves (staging 48 B per node per 64-ray workgroup + a branch per fetch:
+    // config C trace kernel 504 -> 430 us, D 1 454 -> 1 434 us without it)
+    const float4* rec = s.nodes64 + 4 * size_t(n);
+    n0 = rec[0], n1 = rec[1];
+    link = reinterpret_cast<const uint32_t*>(rec + 2)[oct];
 }
 // Triangle::closestIntersection for a walk in another order than the reference's: a hit at exactly the current `far` replaces the
 // held one when the reference would have met it first (`tie_ok`: a hit of THIS mesh is held and this triangle's index is lower).
@@ -1031,18 +1028,27 @@ RZ_DEV void fetch_node(const DScene& s, const TopCache& top, uint32_t n, float4&
         n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1], link = s.node_skip[n];
     }
 }
-template <bool COUNT, bool RCP, bool ORDERED = false>
+// PARK: under a tight register budget (6 waves per SIMD = 80 VGPRs) the compiler keeps the world-space ray alive through the mesh
+// walk and spills the MESH-space ray instead — every box test of the hot loop then reloads 14 dwords from scratch.  With PARK the
+// world-space origin and direction are written to LDS once and read back (and the reciprocals recomputed, the same instructions)
+// after every mesh walk, so they are dead while a mesh is walked.
+template <bool COUNT, bool RCP, bool ORDERED = false, bool PARK = false>
 RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit& hit, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
     prepare<RCP>(g, scene_fast);
+    volatile float* park = top.park + (threadIdx.x & 63u);
+    if constexpr (PARK) {
+        park[0] = g.o.x, park[64] = g.o.y, park[128] = g.o.z;
+        park[192] = g.d.x, park[256] = g.d.y, park[320] = g.d.z;
+    }
     uint32_t n = s.tlas_root, guard = 0u;
     while (n != RZ_END) {
         RZ_GUARD(guard);
         float4 n0, n1;
         uint32_t link;
-        if constexpr (ORDERED) fetch_node_ordered(s, top, n, 0u, n0, n1, link);  // the world tree keeps the reference's order
+        if constexpr (ORDERED) fetch_node_ordered(s, n, 0u, n0, n1, link);  // the world tree keeps the reference's order
         else fetch_node(s, top, n, n0, n1, link);
         RZ_PHASE(0);
         RZ_COUNT(box_tests);
@@ -1083,7 +1089,7 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                         k += 1u;
                         float4 m0, m1;
                         uint32_t mlink;
-                        if constexpr (ORDERED) fetch_node_ordered(s, top, m, oct, m0, m1, mlink);
+                        if constexpr (ORDERED) fetch_node_ordered(s, m, oct, m0, m1, mlink);
                         else fetch_node(s, top, m, m0, m1, mlink);
                         RZ_PHASE(3);
                         RZ_COUNT(box_tests);
@@ -1122,6 +1128,11 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                     g.near_ = lr.near_ / len;
                     g.far_ = lr.far_ / len;
                 }
+                if constexpr (PARK) {
+                    g.o = v3{park[0], park[64], park[128]};
+                    g.d = v3{park[192], park[256], park[320]};
+                    prepare<RCP>(g, scene_fast);
+                }
             }
         } else if (n == s.tlas_root) {
             return 0;  // root box missed (cpu_engine_kernel.cpp:283)
@@ -1145,7 +1156,7 @@ RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, 
         RZ_GUARD(guard);
         float4 n0, n1;
         uint32_t link;
-        if constexpr (ORDERED) fetch_node_ordered(s, top, n, 0u, n0, n1, link);
+        if constexpr (ORDERED) fetch_node_ordered(s, n, 0u, n0, n1, link);
         else fetch_node(s, top, n, n0, n1, link);
         RZ_COUNT(box_tests);
         RZ_COUNT(shadow_box_tests);
@@ -1178,7 +1189,7 @@ RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, 
                         k += 1u;
                         float4 m0, m1;
                         uint32_t mlink;
-                        if constexpr (ORDERED) fetch_node_ordered(s, top, m, oct, m0, m1, mlink);
+                        if constexpr (ORDERED) fetch_node_ordered(s, m, oct, m0, m1, mlink);
                         else fetch_node(s, top, m, m0, m1, mlink);
                         RZ_COUNT(box_tests);
                         RZ_COUNT(shadow_box_tests);

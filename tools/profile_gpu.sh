@@ -15,3 +15,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch 
 echo fetch done
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/pmc_write.log 2>&1
 echo write done
+python3 $R/tools/hbm_traffic.py $TAG $OUT $OUT/hbm_pmc.txt $OUT/traffic.json > /dev/null
+python3 $R/tools/kstats.py $OUT/trace/trace_kernel_stats.csv 8
+cat $OUT/hbm_pmc.txt
