@@ -1038,7 +1038,8 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
     prepare<RCP>(g, scene_fast);
-    volatile float* park = top.park + (threadIdx.x & 63u);
+    // an LDS-qualified pointer: ds_read / ds_write instead of flat accesses
+    volatile __attribute__((address_space(3))) float* park = (volatile __attribute__((address_space(3))) float*)(top.park) + (threadIdx.x & 63u);
     if constexpr (PARK) {
         park[0] = g.o.x, park[64] = g.o.y, park[128] = g.o.z;
         park[192] = g.d.x, park[256] = g.d.y, park[320] = g.d.z;
