@@ -976,7 +976,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
 // (hiprz_api.hip: relayout), so the levels nearest the roots — the ones every ray visits — form a prefix;
 // each workgroup stages that prefix (nodes + links) into LDS.  Following skip links instead of popping a
 // stack means the walk needs no LDS stack at all, which is what frees the space for the cache.
-#define RZ_PARK_WORDS 6u
+#define RZ_PARK_WORDS 16u
 struct TopCache {
     const float4* nodes;   // LDS: top_count x 2 float4
     const uint32_t* skip;  // LDS: top_count
@@ -1059,9 +1059,9 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                 n = begin;
                 continue;
             }
-            const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
+            uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
             for (uint32_t i = begin; i < end; ++i) {
-                const uint32_t inst = s.tlas_order[i];
+                uint32_t inst = s.tlas_order[i];
                 float4 ib0, ib1;
                 load_instance_box(s, inst, ib0, ib1);
                 RZ_PHASE(1);
@@ -1070,9 +1070,13 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                 RZ_PHASE(2);
                 const InstanceXform x = load_instance_xform(s, inst);
                 WalkRay lr;
-                const float len = to_local<RCP>(x, g, lr, scene_fast);
+                float len = to_local<RCP>(x, g, lr, scene_fast);
                 bool found = false;
                 uint32_t m = x.blas_root;
+                if constexpr (PARK) {  // the world-level loop state waits in LDS as well
+                    park[384] = g.near_, park[448] = g.far_, park[512] = len;
+                    park[576] = __uint_as_float(i), park[640] = __uint_as_float(end), park[704] = __uint_as_float(link), park[768] = __uint_as_float(inst);
+                }
                 const uint32_t oct = ORDERED ? octant_of(lr.d) : 0u;
                 // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352, as a "while-while" walk in bounded
                 // rounds: lanes without a leaf step through nodes until they HOLD one (at most walk_k steps per round), then the
@@ -1118,11 +1122,19 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                         if (is_hit) {
                             lr.far_ = t;
                             hit.triangle = tj;
-                            hit.external = det > 0.0f;
-                            hit.bx = b1, hit.by = b2;
+                            if constexpr (PARK) {  // read back once, when the walk is over
+                                park[832] = b1, park[896] = b2, park[960] = det > 0.0f ? 1.0f : 0.0f;
+                            } else {
+                                hit.external = det > 0.0f;
+                                hit.bx = b1, hit.by = b2;
+                            }
                             found = true;
                         }
                     }
+                }
+                if constexpr (PARK) {
+                    g.near_ = park[384], g.far_ = park[448], len = park[512];
+                    i = __float_as_uint(park[576]), end = __float_as_uint(park[640]), link = __float_as_uint(park[704]), inst = __float_as_uint(park[768]);
                 }
                 if (found) {
                     hit.instance = int32_t(inst);
@@ -1141,6 +1153,9 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
         n = link;
     }
     ray.near_ = g.near_, ray.far_ = g.far_;
+    if constexpr (PARK) {
+        if (hit.instance >= 0) hit.bx = park[832], hit.by = park[896], hit.external = park[960] != 0.0f;
+    }
     return hit.instance >= 0 ? 2 : 1;
 }
 
