@@ -1159,6 +1159,166 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
     return hit.instance >= 0 ? 2 : 1;
 }
 
+// ---- the front-to-back walk with a COOPERATIVE triangle phase ----
+// After front to back the thin phase of the walk is the triangle test: a lane that holds a leaf tests its (up to 8) triangles one
+// after the other while the lanes without a leaf wait — config D: 133 wave-level triangle steps per wave at 7.9 active lanes.
+// Here every loop of the walk is wave-uniform (conditions are ballots, lanes carry predicates), so ALL 64 lanes reach the triangle
+// phase, and the (ray, triangle) pairs of the lanes that hold leaves are dealt out over the whole wave:
+//   counts -> wave prefix sum -> the holders write their lane id into the item list (LDS, one byte per item) -> every lane takes
+//   one item, fetches its holder's mesh-space ray with ds_bpermute (no memory), tests the triangle, and the closest hit of a holder
+//   is found with a 64-bit LDS atomic min on (bits(t) << 32 | triangle index) — t > near >= 0, so its bit pattern orders like the
+//   number, and the index in the low word is the reference's "first found wins" — the winning lane leaves the barycentrics in LDS.
+// A leaf's triangles tested against the range the lane held when it reached the leaf, then reduced by (t, index), give what testing
+// them one by one in index order gives (each accepted t is strictly smaller, or equal with a lower index than a hit of another
+// leaf): same boxes, same triangles, same hits as closest_hit_skip<.., ORDERED>.  The caller brings all 64 lanes (`active` = has a
+// ray).  LDS per wave: CoopLds::kBytes.
+#define RZ_LDS __attribute__((address_space(3)))
+struct CoopLds {  // LDS-qualified pointers: ds_read / ds_write / ds_min_u64, not flat accesses
+    RZ_LDS unsigned char* owner;       // [512] item -> holder lane
+    RZ_LDS unsigned long long* key;    // [64]  per holder: min over its items of bits(t) << 32 | triangle
+    RZ_LDS float* res;                 // [3][64] winner's b1, b2, external
+    static constexpr uint32_t kItems = 512u, kBytes = 512u + 512u + 768u;
+    RZ_DEV explicit CoopLds(unsigned char* base)
+        : owner((RZ_LDS unsigned char*)base), key((RZ_LDS unsigned long long*)(base + 512)), res((RZ_LDS float*)(base + 1024)) {}
+};
+RZ_DEV void lds_min_u64(RZ_LDS unsigned long long* p, unsigned long long v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+RZ_DEV float shfl_f(float v, uint32_t src) { return __shfl(v, int(src)); }
+template <bool COUNT, bool RCP>
+RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ray& ray, Hit& hit, Counters& cnt) {
+    const bool scene_fast = s.fast_div != 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    WalkRay g;
+    g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
+    prepare<RCP>(g, scene_fast);
+    const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? (s.walk_l < 8u ? s.walk_l : 8u) : 8u;
+    uint32_t n = active ? s.tlas_root : RZ_END, guard = 0u;
+    bool root_missed = false;
+    while (__any(n != RZ_END)) {
+        RZ_GUARD(guard);
+        uint32_t i = 0u, end = 0u, link = RZ_END;
+        bool descended = false;
+        if (n != RZ_END) {
+            float4 n0, n1;
+            fetch_node_ordered(s, n, 0u, n0, n1, link);  // the world tree keeps the reference's order
+            RZ_PHASE(0);
+            RZ_COUNT(box_tests);
+            if (box_hit<RCP>(n0, n1, g)) {
+                const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+                if (!(meta & HIPRZ_NODE_LEAF)) n = begin, descended = true;
+                else i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
+            } else if (n == s.tlas_root) {
+                root_missed = true, link = RZ_END;  // root box missed (cpu_engine_kernel.cpp:283): this lane's walk is over
+            }
+        }
+        while (__any(i < end)) {
+            bool enter = false;
+            uint32_t inst = 0u;
+            if (i < end) {
+                inst = s.tlas_order[i];
+                float4 ib0, ib1;
+                load_instance_box(s, inst, ib0, ib1);
+                RZ_PHASE(1);
+                RZ_COUNT(box_tests);
+                enter = box_hit<RCP>(ib0, ib1, g);
+                i += 1u;
+            }
+            if (!__any(enter)) continue;
+            WalkRay lr;
+            lr.o = lr.d = lr.y = V3(0.0f, 0.0f, 0.0f), lr.near_ = lr.far_ = 0.0f, lr.fast = true;
+            float len = 1.0f;
+            bool found = false;
+            uint32_t m = RZ_END, oct = 0u;
+            if (enter) {
+                RZ_PHASE(2);
+                const InstanceXform x = load_instance_xform(s, inst);
+                len = to_local<RCP>(x, g, lr, scene_fast);
+                m = x.blas_root;
+                oct = octant_of(lr.d);
+            }
+            uint32_t tj = 0u, tj_end = 0u;  // the held leaf's remaining triangles
+            while (__any(tj != tj_end || m != RZ_END)) {
+                RZ_PHASE(5);
+                // node phase: lanes without a leaf step (at most kmax steps per round), the others wait
+                for (uint32_t k = 0u; k < kmax && __any(tj == tj_end && m != RZ_END); ++k) {
+                    if (tj == tj_end && m != RZ_END) {
+                        RZ_GUARD(guard);
+                        float4 m0, m1;
+                        uint32_t mlink;
+                        fetch_node_ordered(s, m, oct, m0, m1, mlink);
+                        RZ_PHASE(3);
+                        RZ_COUNT(box_tests);
+                        if (box_hit<RCP>(m0, m1, lr)) {
+                            const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
+                            if (!(mmeta & HIPRZ_NODE_LEAF)) mlink = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);  // enter the nearer child first
+                            else tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
+                        }
+                        m = mlink;
+                    }
+                }
+                if (!__any(tj != tj_end)) continue;
+                // triangle phase, all 64 lanes
+                const uint32_t c = tj_end - tj < lmax ? tj_end - tj : lmax;
+                uint32_t incl = c;
+                for (uint32_t d = 1u; d < 64u; d <<= 1) {
+                    const uint32_t v = __shfl_up(incl, d);
+                    if (lane >= d) incl += v;
+                }
+                const uint32_t off = incl - c, total = __shfl(incl, 63);
+                for (uint32_t j = 0u; j < c; ++j) lds.owner[off + j] = (unsigned char)lane;
+                lds.key[lane] = ~0ull;
+                __syncthreads();
+                for (uint32_t base = 0u; base < total; base += 64u) {
+                    const uint32_t item = base + lane;
+                    const bool valid = item < total;
+                    const uint32_t h = valid ? uint32_t(lds.owner[item]) : lane;
+                    WalkRay hr;
+                    hr.o = V3(shfl_f(lr.o.x, h), shfl_f(lr.o.y, h), shfl_f(lr.o.z, h));
+                    hr.d = V3(shfl_f(lr.d.x, h), shfl_f(lr.d.y, h), shfl_f(lr.d.z, h));
+                    hr.near_ = shfl_f(lr.near_, h), hr.far_ = shfl_f(lr.far_, h);
+                    const uint32_t htj = __shfl(tj, int(h)), hoff = __shfl(off, int(h)), hbest = __shfl(hit.triangle, int(h));
+                    const bool hfound = __shfl(int(found), int(h)) != 0;
+                    unsigned long long mykey = ~0ull;
+                    float b1 = 0.0f, b2 = 0.0f, det = 0.0f;
+                    if (valid) {
+                        const uint32_t tri = htj + (item - hoff);
+                        const float4 a = s.tris[3 * tri], b = s.tris[3 * tri + 1], cc = s.tris[3 * tri + 2];
+                        float t;
+                        RZ_PHASE(4);
+                        RZ_COUNT(tri_tests);
+                        if (tri_hit_ordered(xyz(a), xyz(b), xyz(cc), hr, hfound && tri < hbest, t, b1, b2, det)) {
+                            mykey = ((unsigned long long)__float_as_uint(t) << 32) | tri;
+                            lds_min_u64(&lds.key[h], mykey);
+                        }
+                    }
+                    __syncthreads();
+                    if (mykey != ~0ull && lds.key[h] == mykey) lds.res[h] = b1, lds.res[64 + h] = b2, lds.res[128 + h] = det > 0.0f ? 1.0f : 0.0f;
+                }
+                __syncthreads();
+                if (c != 0u) {
+                    const unsigned long long best = lds.key[lane];
+                    if (best != ~0ull) {
+                        lr.far_ = __uint_as_float(uint32_t(best >> 32));
+                        hit.triangle = uint32_t(best);
+                        hit.bx = lds.res[lane], hit.by = lds.res[64 + lane], hit.external = lds.res[128 + lane] != 0.0f;
+                        found = true;
+                    }
+                    tj += c;
+                }
+                __syncthreads();  // the next round rewrites owner / key
+            }
+            if (found) {
+                hit.instance = int32_t(inst);
+                g.near_ = lr.near_ / len;
+                g.far_ = lr.far_ / len;
+            }
+        }
+        if (n != RZ_END && !descended) n = link;
+    }
+    ray.near_ = g.near_, ray.far_ = g.far_;
+    if (!active || root_missed) return 0;
+    return hit.instance >= 0 ? 2 : 1;
+}
+
 // anyIntersection (cpu_engine_kernel.cpp:398-481) on skip links, with the tree tops from LDS: the shadow-ray walk of the
 // kernels that have a TopCache.  Same tests in the same order as any_hit_stack; returns the mask's alpha (0 or 1).
 template <bool COUNT, bool RCP, bool ORDERED = false>

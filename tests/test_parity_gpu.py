@@ -476,3 +476,28 @@ def test_front_to_back_walk_equals_reference_order(built):
             assert np.array_equal(out[0][0], out[other][0]) and np.array_equal(out[0][1], out[other][1])
             for k in out[0][2]:
                 assert np.array_equal(out[0][2][k], out[other][2][k]), k
+
+
+def test_cooperative_triangle_phase_equals_the_per_lane_walk(built, monkeypatch):
+    """rz_trace_coop_kernel (all 64 lanes share the triangle tests of the lanes that hold a leaf: prefix sum, ds_bpermute ray fetch,
+    64-bit LDS atomic min on (t, triangle)) == rz_trace_skip_kernel walking front to back: frames, path state AND the executed work
+    counters, bit for bit — it tests the same boxes and triangles, only on other lanes."""
+    cases = ((scenes.cornell_sphere(160, 96, resolution=40), (1, 1)),
+             (scenes.textured_sphere_scene(200, 120, resolution=160, map_size=64), (1, 1)),
+             (scenes.living_room(128, 80, 16), (2, 2)))
+    for world, samples in cases:
+        flat, cam = flatten(world), camera_struct(world.camera)
+        cfg = RenderConfig(LightSampling(*samples), Tracing(6, 4)).struct()
+        out = []
+        for coop in ("0", "1"):
+            monkeypatch.setenv("HIPRZ_COOP", coop)
+            c = Context(0)
+            c.set_traversal_mode(3), c.set_lds_scene(0), c.set_walk_order(2)
+            c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+            counters = c.render_counted(2)
+            c.render(6), c.render(4)
+            out.append((c.read_accum(), c.read_depth(), c.read_state(), counters))
+        assert out[0][3] == out[1][3]
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        for k in out[0][2]:
+            assert np.array_equal(out[0][2][k], out[1][2][k]), k
