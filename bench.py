@@ -220,7 +220,8 @@ def main():
             # dominant kernel = the BVH-traversal kernel.  Its algorithmic bytes: the ray it reads (40 B of path state) and
             # the hit record it writes (20 B) per segment + 32 B per box test + 36 B per triangle test of the closest-hit
             # walk (shadow-ray tests run in the shade kernel and are not counted here).
-            kernel_name = {3: "rz_trace_skip_kernel", 5: "rz_trace_requeue_kernel", 6: "rz_trace_pool_kernel"}.get(ctx.traversal_mode(), "rz_trace_kernel") + " (closest-hit walk)"
+            mode3 = "rz_trace_coop_kernel" if (args.walk_order if args.walk_order >= 0 else 1) != 0 and os.environ.get("HIPRZ_COOP", "1") != "0" else "rz_trace_skip_kernel"
+            kernel_name = {3: mode3, 5: "rz_trace_requeue_kernel", 6: "rz_trace_pool_kernel"}.get(ctx.traversal_mode(), "rz_trace_kernel") + " (closest-hit walk)"
             kernel_s = breakdown[0] / 1e3 / breakdown[2]
             kernel_bytes = (60 * counters["segments"] + 32 * (counters["box_tests"] - counters["shadow_box_tests"])
                             + 36 * (counters["tri_tests"] - counters["shadow_tri_tests"])) / RPP
@@ -252,7 +253,7 @@ def main():
                        "triangles": int(len(flat.tris)), "instances": int(len(flat.instances)),
                        "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
                        "requeued_rays_per_round": requeue_counts,
-                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned", 3: "skip-links+lds-top-cache", 4: "persistent-lanes", 5: "skip-links+requeue-rounds", 6: "wave-pool"}[ctx.traversal_mode()],
+                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned", 3: "skip-links", 4: "persistent-lanes", 5: "skip-links+requeue-rounds", 6: "wave-pool"}[ctx.traversal_mode()],
                        "pipeline": {0: "fused (one kernel per pass)", 1: "trace+shade (two kernels per pass)", 2: "resident (one kernel per step)"}[pipeline]},
             "spp_per_s": spp_per_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
