@@ -946,6 +946,66 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_kernel(const DScene s, con
     flush_counters<COUNT>(f, 0u, cnt);
 }
 
+// rz_shadow_kernel with the cooperative any-hit walk (hiprz_device.hpp: any_hit_coop): the sample loop is wave-uniform, a lane
+// whose pixel has no shadow ray in slot k walks along as a helper.  Sums, order and accumulation are those of rz_shadow_kernel.
+template <bool FIRST, bool COUNT, int MINW>
+__global__ void __launch_bounds__(64, MINW) rz_shadow_coop_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
+    const CoopLds lds(rz_lds);
+    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t* order = f.shadow_perm ? f.shadow_perm : f.perm;
+    const PixelId p = pixel_of_local(f, cam, order ? order[slot] : slot);
+    Counters cnt;
+    float4 base = make_float4(0.0f, 0.0f, 0.0f, 0.0f), o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t bits = 0u;
+    if (p.active) {
+        base = f.nee_base[p.local];
+        bits = __float_as_uint(base.w);
+        if (bits & 2u) o = f.nee_point[p.local];
+    }
+    const uint32_t mask = (bits & 2u) ? bits >> 2 : 0u, stride = f.n_local_tiles * 256u;
+    col4 direct_total = splat(0.0f), spot_total = splat(0.0f);
+    const uint32_t n_samples = cfg.direct_samples + cfg.spot_samples;
+    for (uint32_t k = 0u; k < n_samples; ++k) {  // wave-uniform
+        const bool has = (mask & (1u << k)) != 0u;
+        if (!__any(has)) continue;
+        float4 d = make_float4(0.0f, 0.0f, 1.0f, 0.0f), t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (has) d = f.nee_dir[size_t(k) * stride + p.local], t = f.nee_term[size_t(k) * stride + p.local];
+        Ray sr;
+        sr.o = V3(o.x, o.y, o.z), sr.d = V3(d.x, d.y, d.z), sr.near_ = 0.0f, sr.far_ = d.w;
+        if (has) { RZ_COUNT(shadow_rays); }
+        float v = 0.0f;
+        if (s.n_instances != 0u) v = any_hit_coop<COUNT, RZ_SHADE_SHARED_RCP != 0>(s, lds, has, sr, cnt);
+        if (has) {
+            const col4 V_PL = splat(v);
+            const col4 term = (col4{t.x, t.y, t.z, t.w} * V_PL) * V_PL.a;
+            if (k < cfg.direct_samples) direct_total = direct_total + term;
+            else spot_total = spot_total + term;
+        }
+    }
+    if (p.active) {
+        const bool path_continues = (bits & 1u) != 0u;
+        col4 final_color{base.x, base.y, base.z, 0.0f};
+        if (bits & 2u) {
+            col4 dt = splat(0.0f), st = splat(0.0f);
+            if (s.n_direct_lights != 0u) dt = div_scalar(direct_total, float(cfg.direct_samples) / float(s.n_direct_lights));
+            if (s.n_spot_lights != 0u) st = div_scalar(spot_total, float(cfg.spot_samples) / float(s.n_spot_lights));
+            const col4 direct = dt + st;
+            const float4 a = f.nee_a[p.local], b = f.nee_b[p.local];
+            final_color = final_color + (direct * col4{a.x, a.y, a.z, a.w}) * col4{b.x, b.y, b.z, b.w};
+        }
+        col4 value;
+        if constexpr (FIRST) {
+            value = col4{final_color.r, final_color.g, final_color.b, float(!path_continues)};
+        } else {
+            const float4 acc = f.accum[p.local];
+            value = col4{acc.x + final_color.r, acc.y + final_color.g, acc.z + final_color.b, acc.w + float(!path_continues)};
+        }
+        f.accum[p.local] = make_float4(value.r, value.g, value.b, value.a);
+    }
+    flush_counters<COUNT>(f, 0u, cnt);
+}
+
 // passUpdate / segmentUpdate (cuda_postprocess_kernel.cu:95-104, cuda_render_kernel.cu:122-129):
 // the pass index lives on the device so a captured graph replays without new arguments.
 __global__ void rz_pass_update_kernel(uint32_t* pass) { *pass += 1u; }
@@ -1204,6 +1264,7 @@ struct hiprz_ctx {
     DeviceArray<uint32_t> sort_keys, sort_keys_out, sort_iota, sort_perm;
     DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
     int coop_walk = 1;    // front-to-back walk with the cooperative triangle phase (rz_trace_coop_kernel); HIPRZ_COOP=0: rz_trace_skip_kernel
+    int coop_shadow = 1;  // deferred shadow rays in rz_shadow_coop_kernel (HIPRZ_COOP_SHADOW=0: rz_shadow_kernel)
     int shadow_sort = 1;  // HIPRZ_SHADOW_SORT=0: the shadow kernel follows the next pass's ray order instead
     DeviceArray<uint8_t> sort_temp;
     size_t sort_temp_bytes = 0;
@@ -1518,7 +1579,9 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
             if (f.shadow_key) launch_shadow_sort(c);
             const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;
             const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
-            if (COUNT ? c->walk_order == 2 : c->walk_order != 0) {
+            if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) && c->coop_shadow) {
+                hipLaunchKernelGGL((rz_shadow_coop_kernel<FIRST, COUNT, 4>), sgrid, sblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
+            } else if (COUNT ? c->walk_order == 2 : c->walk_order != 0) {
                 if (big_trees) hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 6, true>), sgrid, sblock, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
                 else hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 4, true>), sgrid, sblock, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
             } else {
@@ -2016,6 +2079,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     if (const char* w = std::getenv("HIPRZ_TRACE_WAVES")) c->trace_waves = std::atoi(w);
     if (const char* w = std::getenv("HIPRZ_DEFER_SHADOWS")) c->defer_shadow_rays = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_COOP")) c->coop_walk = std::atoi(w) != 0;
+    if (const char* w = std::getenv("HIPRZ_COOP_SHADOW")) c->coop_shadow = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SHADOW_SORT")) c->shadow_sort = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SHADOW_WALK")) c->shade_shadow_walk = std::atoi(w) == 1 ? 1 : 3;
     c->device = device_id;

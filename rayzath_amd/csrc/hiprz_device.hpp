@@ -1414,6 +1414,121 @@ RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, 
     return 1.0f;
 }
 
+// anyIntersection with the cooperative triangle phase of closest_hit_coop: all 64 lanes walk together (`active` = has a shadow
+// ray), the triangles of the lanes that hold a leaf are dealt out over the wave, and a holder is occluded as soon as ANY of its items
+// hits (an LDS flag instead of the atomic min).  A shadow ray's range is fixed, so the answer does not depend on the order of the tests.
+template <bool COUNT, bool RCP>
+RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, const Ray& ray, Counters& cnt) {
+    const bool scene_fast = s.fast_div != 0u;
+    const uint32_t lane = threadIdx.x & 63u;
+    WalkRay g;
+    g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
+    prepare<RCP>(g, scene_fast);
+    const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? (s.walk_l < 8u ? s.walk_l : 8u) : 8u;
+    uint32_t n = active ? s.tlas_root : RZ_END, guard = 0u;
+    bool occluded = false;
+    while (__any(n != RZ_END)) {
+        RZ_GUARD(guard);
+        uint32_t i = 0u, end = 0u, link = RZ_END;
+        bool descended = false;
+        if (n != RZ_END) {
+            float4 n0, n1;
+            fetch_node_ordered(s, n, 0u, n0, n1, link);
+            RZ_COUNT(box_tests);
+            RZ_COUNT(shadow_box_tests);
+            if (box_hit<RCP>(n0, n1, g)) {
+                const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+                if (!(meta & HIPRZ_NODE_LEAF)) n = begin, descended = true;
+                else i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
+            } else if (n == s.tlas_root) {
+                link = RZ_END;  // root box missed (:402): clear
+            }
+        }
+        while (__any(i < end)) {
+            bool enter = false;
+            uint32_t inst = 0u;
+            if (i < end) {
+                inst = s.tlas_order[i];
+                float4 ib0, ib1;
+                load_instance_box(s, inst, ib0, ib1);
+                RZ_COUNT(box_tests);
+                RZ_COUNT(shadow_box_tests);
+                enter = box_hit<RCP>(ib0, ib1, g);
+                i += 1u;
+            }
+            if (!__any(enter)) continue;
+            WalkRay lr;
+            lr.o = lr.d = lr.y = V3(0.0f, 0.0f, 0.0f), lr.near_ = lr.far_ = 0.0f, lr.fast = true;
+            uint32_t m = RZ_END, oct = 0u;
+            if (enter) {
+                const InstanceXform x = load_instance_xform(s, inst);
+                to_local<RCP>(x, g, lr, scene_fast);
+                m = x.blas_root;
+                oct = octant_of(lr.d);
+            }
+            uint32_t tj = 0u, tj_end = 0u;
+            while (__any(tj != tj_end || m != RZ_END)) {
+                for (uint32_t k = 0u; k < kmax && __any(tj == tj_end && m != RZ_END); ++k) {
+                    if (tj == tj_end && m != RZ_END) {
+                        RZ_GUARD(guard);
+                        float4 m0, m1;
+                        uint32_t mlink;
+                        fetch_node_ordered(s, m, oct, m0, m1, mlink);
+                        RZ_COUNT(box_tests);
+                        RZ_COUNT(shadow_box_tests);
+                        if (box_hit<RCP>(m0, m1, lr)) {
+                            const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
+                            if (!(mmeta & HIPRZ_NODE_LEAF)) mlink = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);
+                            else tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
+                        }
+                        m = mlink;
+                    }
+                }
+                if (!__any(tj != tj_end)) continue;
+                const uint32_t c = tj_end - tj < lmax ? tj_end - tj : lmax;
+                uint32_t incl = c;
+                for (uint32_t d = 1u; d < 64u; d <<= 1) {
+                    const uint32_t v = __shfl_up(incl, d);
+                    if (lane >= d) incl += v;
+                }
+                const uint32_t off = incl - c, total = __shfl(incl, 63);
+                for (uint32_t j = 0u; j < c; ++j) lds.owner[off + j] = (unsigned char)lane;
+                lds.res[lane] = 0.0f;  // "one of my triangles was hit"
+                rz_wave_sync();
+                for (uint32_t base = 0u; base < total; base += 64u) {
+                    const uint32_t item = base + lane;
+                    const bool valid = item < total;
+                    const uint32_t h = valid ? uint32_t(lds.owner[item]) : lane;
+                    WalkRay hr;
+                    hr.o = V3(shfl_f(lr.o.x, h), shfl_f(lr.o.y, h), shfl_f(lr.o.z, h));
+                    hr.d = V3(shfl_f(lr.d.x, h), shfl_f(lr.d.y, h), shfl_f(lr.d.z, h));
+                    hr.near_ = shfl_f(lr.near_, h), hr.far_ = shfl_f(lr.far_, h);
+                    const uint32_t htj = __shfl(tj, int(h)), hoff = __shfl(off, int(h));
+                    if (valid) {
+                        const uint32_t tri = htj + (item - hoff);
+                        const float4 a = s.tris[3 * tri], b = s.tris[3 * tri + 1], cc = s.tris[3 * tri + 2];
+                        float t, b1, b2, det;
+                        RZ_COUNT(tri_tests);
+                        RZ_COUNT(shadow_tri_tests);
+                        if (tri_hit(xyz(a), xyz(b), xyz(cc), hr, t, b1, b2, det)) lds.res[h] = 1.0f;
+                    }
+                }
+                rz_wave_sync();
+                if (c != 0u) {
+                    tj += c;
+                    if (lds.res[lane] != 0.0f) {  // occluded: this lane's walk is over (:465 "TODO: texture fetch" -> mask 0)
+                        occluded = true;
+                        tj = tj_end = 0u, m = RZ_END, i = end = 0u, n = RZ_END, link = RZ_END, descended = false;
+                    }
+                }
+                rz_wave_sync();
+            }
+        }
+        if (n != RZ_END && !descended) n = link;
+    }
+    return occluded ? 0.0f : 1.0f;
+}
+
 // ---- MODE 5: the MODE 3 walk in ROUNDS, with ray requeueing ----
 // A wave lasts as long as its slowest ray and ray cost is heavy-tailed (config D: the slowest of 64 rays is ~12x the mean;
 // 13 % lane utilisation in MODE 3).  Here a lane that is inside a mesh walk with fewer than `threshold` companions left in

@@ -15,7 +15,7 @@ for world, samples in cases:
     cfg = RenderConfig(LightSampling(*samples), Tracing(6, 4)).struct()
     out = []
     for coop in ("0", "1"):
-        os.environ["HIPRZ_COOP"] = coop
+        os.environ[sys.argv[1] if len(sys.argv) > 1 else "HIPRZ_COOP"] = coop
         c = Context(0)
         c.set_traversal_mode(3), c.set_lds_scene(0), c.set_walk_order(2)
         c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
