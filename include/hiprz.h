@@ -267,8 +267,9 @@ int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
 /* Tree-walk variant of the pass kernel.  -1 (default) = chosen per scene; 1 = nested loops with a
  * per-lane stack in LDS; 2 = workgroup-binned (rays advance in rounds, the (ray, instance) visits of
  * a round are compacted and sorted by instance in LDS and processed by dense waves); 0 = threaded
- * (skip links + instance pseudo-nodes, no stack); 3 = nested walk on skip links with the tree tops cached in
- * LDS; 4 = persistent lanes (a workgroup owns a pool of rays, a lane that finishes its ray takes the next one)
+ * (skip links + instance pseudo-nodes, no stack); 3 = nested walk on skip links, one wave per workgroup (see
+ * hiprz_set_walk_order: front to back with a cooperative triangle phase by default; in the reference's child order with
+ * the tree tops cached in LDS); 4 = persistent lanes (a workgroup owns a pool of rays, a lane that finishes its ray takes the next one)
  * on the flat walk graph with postponed leaves; 5 = the walk of 3 in rounds: a ray whose wave has run thin stops,
  * is queued (48 B of walk state) and resumed by the next round's kernel in a dense wave.  All visit the same boxes
  * and triangles in the same per-ray order and give identical results. */
@@ -278,7 +279,8 @@ int hiprz_set_traversal_mode(hiprz_ctx* ctx, int mode);
  * 1 (default) = front to back: the child on the side the ray comes from first (decided by the sign of the ray direction along
  * the node's split axis; per ray octant the order is fixed, so the walk stays stack-free on per-octant skip links).  The closest
  * hit is the same triangle — among equal distances the one the reference meets first wins — while fewer boxes and triangles are
- * tested (config D: -22 % / -30 %).  World trees and instance lists are always walked in the reference's order.
+ * tested (config D: -22 % / -30 %).  World trees and instance lists are always walked in the reference's order.  In this
+ * order the leaf triangles of all lanes of a wave are tested cooperatively (rz_trace_coop_kernel) and shadow rays likewise.
  * hiprz_render_counted() walks in the reference's order under 0 and 1, so its counters are the work of the reference's
  * algorithm (what the roofline's algorithmic bytes are made of); 2 = front to back there too: counters = tests executed. */
 int hiprz_set_walk_order(hiprz_ctx* ctx, int order);
