@@ -36,7 +36,7 @@ uint32_t hiprz_scene_file_warning_count(const hiprz_scene_file* file);
 int hiprz_scene_file_save(const hiprz_scene_file* file, const char* path, int kind);
 
 /* Image files of maps and saved frames (rayzath_amd/csrc/image_io.hpp; the reference: stbi_load / stbi_write_png, loader.cpp:36-98,
- * saver.cpp:16-60).  Decodes PNG (every colour type / bit depth, palette, tRNS, Adam7), BMP, TGA and binary PPM / PGM to 8 bits
+ * saver.cpp:16-60).  Decodes PNG (every colour type / bit depth, palette, tRNS, Adam7), baseline JPEG, BMP, TGA and binary PPM / PGM to 8 bits
  * per channel, rows top to bottom.  `channels` = 0 keeps the file's channel count (reported in *channels_out: 1 grey, 2 grey +
  * alpha, 3 RGB, 4 RGBA), 1..4 converts like stb_image does (grey = (77 r + 150 g + 29 b) >> 8, missing alpha = 255).
  * Call with pixels = NULL to learn the size; otherwise capacity must be >= width * height * channels. */

@@ -4,6 +4,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -310,6 +311,288 @@ bool decode_pnm(const uint8_t* b, size_t size, const std::string& name, Image& o
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// JPEG (ITU-T T.81): baseline / extended sequential DCT, Huffman coded, 8-bit samples, 1 or 3 components, restart intervals.
+// Chroma is upsampled the way stb_image does it (3:1 triangle filter for factor 2, replication otherwise) and converted with its
+// 20-bit fixed-point YCbCr matrix; the inverse DCT is a separable double-precision one rounded to nearest, so a sample can differ
+// from stb_image's integer IDCT by one code value.  Progressive and arithmetic-coded files are refused.
+// ---------------------------------------------------------------------------------------------------------------------
+struct JpegHuffman {
+    uint8_t bits[17] = {0};
+    uint8_t values[256] = {0};
+    int32_t mincode[17], maxcode[18], valptr[17];
+    bool defined = false;
+    void build() {
+        int32_t code = 0, k = 0;
+        for (int len = 1; len <= 16; ++len) {
+            valptr[len] = k;
+            mincode[len] = code;
+            code += bits[len];
+            k += bits[len];
+            maxcode[len] = bits[len] ? code - 1 : -1;
+            code <<= 1;
+        }
+        maxcode[17] = 0x7FFFFFFF;
+        defined = true;
+    }
+};
+struct JpegBits {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint32_t acc = 0;
+    int count = 0;
+    bool hit_marker = false;
+    int bit() {
+        if (count == 0) {
+            uint8_t b = 0;
+            if (p < end && !hit_marker) {
+                b = *p++;
+                if (b == 0xFF) {
+                    if (p < end && *p == 0x00) ++p;          // stuffed zero
+                    else hit_marker = true, b = 0, --p;      // a marker: feed zeros, leave it for the caller
+                }
+            }
+            acc = b, count = 8;
+        }
+        --count;
+        return int((acc >> count) & 1u);
+    }
+    int receive(int n) {
+        int v = 0;
+        for (int i = 0; i < n; ++i) v = (v << 1) | bit();
+        return v;
+    }
+    void reset() { acc = 0, count = 0, hit_marker = false; }
+};
+int jpeg_decode_symbol(JpegBits& br, const JpegHuffman& h) {
+    int32_t code = 0;
+    for (int len = 1; len <= 16; ++len) {
+        code = (code << 1) | br.bit();
+        if (h.maxcode[len] >= 0 && code <= h.maxcode[len] && code >= h.mincode[len]) return h.values[h.valptr[len] + code - h.mincode[len]];
+    }
+    return -1;
+}
+int jpeg_extend(int v, int t) { return t && v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+const uint8_t kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+void jpeg_idct(const int* coef, uint8_t* out, size_t stride) {
+    static double basis[8][8];
+    static bool ready = false;
+    if (!ready) {
+        for (int x = 0; x < 8; ++x)
+            for (int u = 0; u < 8; ++u) basis[x][u] = (u == 0 ? std::sqrt(0.125) : 0.5) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0);
+        ready = true;
+    }
+    double tmp[64];
+    for (int y = 0; y < 8; ++y)       // rows: over u
+        for (int x = 0; x < 8; ++x) {
+            double a = 0.0;
+            for (int u = 0; u < 8; ++u) a += basis[x][u] * coef[y * 8 + u];
+            tmp[y * 8 + x] = a;
+        }
+    for (int x = 0; x < 8; ++x)       // columns: over v
+        for (int y = 0; y < 8; ++y) {
+            double a = 0.0;
+            for (int v = 0; v < 8; ++v) a += basis[y][v] * tmp[v * 8 + x];
+            const long r = std::lround(a + 128.0);
+            out[size_t(y) * stride + x] = uint8_t(r < 0 ? 0 : r > 255 ? 255 : r);
+        }
+}
+struct JpegComponent {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0;
+    uint32_t w = 0, hgt = 0;  // padded plane size
+    std::vector<uint8_t> plane;
+};
+// stb_image's chroma upsampling of one row pair: factor 2 horizontally and / or vertically with a 3:1 triangle filter
+void jpeg_upsample_row(const uint8_t* near_row, const uint8_t* far_row, uint32_t w, int hs, int vs, uint8_t* out) {
+    if (hs == 1 && vs == 1) {
+        std::memcpy(out, near_row, w);
+    } else if (hs == 1 && vs == 2) {
+        for (uint32_t i = 0; i < w; ++i) out[i] = uint8_t((3 * near_row[i] + far_row[i] + 2) >> 2);
+    } else if (hs == 2 && vs == 1) {
+        if (w == 1) { out[0] = out[1] = near_row[0]; return; }
+        out[0] = near_row[0];
+        out[1] = uint8_t((near_row[0] * 3 + near_row[1] + 2) >> 2);
+        uint32_t i = 1;
+        for (; i + 1 < w; ++i) {
+            const int n = 3 * near_row[i] + 2;
+            out[2 * i] = uint8_t((n + near_row[i - 1]) >> 2);
+            out[2 * i + 1] = uint8_t((n + near_row[i + 1]) >> 2);
+        }
+        out[2 * i] = uint8_t((near_row[w - 2] * 3 + near_row[w - 1] + 2) >> 2);
+        out[2 * i + 1] = near_row[w - 1];
+    } else if (hs == 2 && vs == 2) {
+        if (w == 1) { out[0] = out[1] = uint8_t((3 * near_row[0] + far_row[0] + 2) >> 2); return; }
+        int t1 = 3 * near_row[0] + far_row[0];
+        out[0] = uint8_t((t1 + 2) >> 2);
+        for (uint32_t i = 1; i < w; ++i) {
+            const int t0 = t1;
+            t1 = 3 * near_row[i] + far_row[i];
+            out[2 * i - 1] = uint8_t((3 * t0 + t1 + 8) >> 4);
+            out[2 * i] = uint8_t((3 * t1 + t0 + 8) >> 4);
+        }
+        out[2 * w - 1] = uint8_t((t1 + 2) >> 2);
+    } else {
+        for (uint32_t i = 0; i < w; ++i)
+            for (int j = 0; j < hs; ++j) out[i * hs + j] = near_row[i];
+    }
+}
+bool decode_jpeg(const uint8_t* b, size_t size, const std::string& name, Image& out, std::string& why) {
+    auto bad = [&](const std::string& m) { return why = name + ": " + m, false; };
+    uint16_t quant[4][64] = {};
+    JpegHuffman dc[4], ac[4];
+    JpegComponent comp[3];
+    int n_comp = 0, hmax = 1, vmax = 1;
+    uint32_t width = 0, height = 0, restart_interval = 0;
+    bool have_frame = false;
+    size_t pos = 2;
+    while (true) {
+        if (pos + 4 > size) return bad("truncated JPEG");
+        if (b[pos] != 0xFF) return bad("JPEG marker expected");
+        while (pos < size && b[pos] == 0xFF) ++pos;
+        const uint8_t marker = b[pos++];
+        if (marker == 0xD9) return bad("JPEG ends before its scan");
+        if (marker == 0x01 || (marker >= 0xD0 && marker <= 0xD7)) continue;
+        if (pos + 2 > size) return bad("truncated JPEG");
+        const size_t len = (size_t(b[pos]) << 8) | b[pos + 1];
+        if (len < 2 || pos + len > size) return bad("truncated JPEG segment");
+        const uint8_t* d = b + pos + 2;
+        const size_t n = len - 2;
+        if (marker == 0xDB) {  // DQT
+            size_t i = 0;
+            while (i < n) {
+                const int pq = d[i] >> 4, tq = d[i] & 15;
+                ++i;
+                if (tq > 3 || i + (pq ? 128 : 64) > n) return bad("bad DQT");
+                for (int k = 0; k < 64; ++k) quant[tq][kZigzag[k]] = pq ? uint16_t((d[i + 2 * k] << 8) | d[i + 2 * k + 1]) : d[i + k];
+                i += pq ? 128 : 64;
+            }
+        } else if (marker == 0xC4) {  // DHT
+            size_t i = 0;
+            while (i < n) {
+                if (i + 17 > n) return bad("bad DHT");
+                const int tc = d[i] >> 4, th = d[i] & 15;
+                if (tc > 1 || th > 3) return bad("bad DHT");
+                JpegHuffman& h = tc ? ac[th] : dc[th];
+                int total = 0;
+                for (int k = 1; k <= 16; ++k) h.bits[k] = d[i + k], total += d[i + k];
+                i += 17;
+                if (total > 256 || i + size_t(total) > n) return bad("bad DHT");
+                std::memcpy(h.values, d + i, size_t(total));
+                i += size_t(total);
+                h.build();
+            }
+        } else if (marker == 0xC0 || marker == 0xC1) {  // SOF0 / SOF1
+            if (n < 6 || d[0] != 8) return bad("only 8-bit JPEG files are decoded");
+            height = (uint32_t(d[1]) << 8) | d[2], width = (uint32_t(d[3]) << 8) | d[4];
+            n_comp = d[5];
+            if (width == 0 || height == 0) return bad("JPEG dimensions out of range");
+            if (!(n_comp == 1 || n_comp == 3) || n < size_t(6 + 3 * n_comp)) return bad("only grey and three-component JPEG files are decoded");
+            for (int c = 0; c < n_comp; ++c) {
+                comp[c].id = d[6 + 3 * c], comp[c].h = d[7 + 3 * c] >> 4, comp[c].v = d[7 + 3 * c] & 15, comp[c].tq = d[8 + 3 * c];
+                if (comp[c].h < 1 || comp[c].h > 4 || comp[c].v < 1 || comp[c].v > 4 || comp[c].tq > 3) return bad("bad JPEG frame header");
+                hmax = std::max(hmax, comp[c].h), vmax = std::max(vmax, comp[c].v);
+            }
+            have_frame = true;
+        } else if (marker == 0xC2 || (marker >= 0xC3 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC)) {
+            return bad(marker == 0xC2 ? "progressive JPEG files are not decoded (baseline ones are)" : "this JPEG coding process is not decoded (baseline is)");
+        } else if (marker == 0xDD) {
+            if (n < 2) return bad("bad DRI");
+            restart_interval = (uint32_t(d[0]) << 8) | d[1];
+        } else if (marker == 0xDA) {  // SOS: the one scan of a sequential file
+            if (!have_frame) return bad("JPEG scan before its frame header");
+            if (n < 1 || d[0] != n_comp || n < size_t(1 + 2 * n_comp + 3)) return bad("only single-scan (interleaved) JPEG files are decoded");
+            for (int k = 0; k < n_comp; ++k) {
+                int c = 0;
+                while (c < n_comp && comp[c].id != d[1 + 2 * k]) ++c;
+                if (c == n_comp) return bad("bad JPEG scan header");
+                comp[c].td = d[2 + 2 * k] >> 4, comp[c].ta = d[2 + 2 * k] & 15;
+                if (comp[c].td > 3 || comp[c].ta > 3 || !dc[comp[c].td].defined || !ac[comp[c].ta].defined) return bad("JPEG scan uses an undefined Huffman table");
+            }
+            pos += len;
+            break;
+        }
+        pos += len;
+    }
+    const uint32_t mcu_w = 8u * uint32_t(hmax), mcu_h = 8u * uint32_t(vmax);
+    const uint32_t mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;
+    if (n_comp == 1) comp[0].h = comp[0].v = 1;  // a single-component scan is not interleaved: one block per MCU
+    const uint32_t gx = n_comp == 1 ? (width + 7) / 8 : mcus_x, gy = n_comp == 1 ? (height + 7) / 8 : mcus_y;
+    for (int c = 0; c < n_comp; ++c) {
+        comp[c].w = gx * 8u * uint32_t(comp[c].h), comp[c].hgt = gy * 8u * uint32_t(comp[c].v);
+        comp[c].plane.assign(size_t(comp[c].w) * comp[c].hgt, 0);
+    }
+    JpegBits br{b + pos, b + size};
+    uint32_t until_restart = restart_interval;
+    int coef[64];
+    for (uint32_t my = 0; my < gy; ++my)
+        for (uint32_t mx = 0; mx < gx; ++mx) {
+            if (restart_interval && until_restart == 0) {  // RSTn: byte-align, skip the marker, reset the predictors
+                br.reset();
+                while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) ++br.p;
+                if (br.p + 1 >= br.end) return bad("JPEG restart marker missing");
+                br.p += 2;
+                for (int c = 0; c < n_comp; ++c) comp[c].pred = 0;
+                until_restart = restart_interval;
+            }
+            for (int c = 0; c < n_comp; ++c)
+                for (int by = 0; by < comp[c].v; ++by)
+                    for (int bx = 0; bx < comp[c].h; ++bx) {
+                        std::memset(coef, 0, sizeof coef);
+                        const int t = jpeg_decode_symbol(br, dc[comp[c].td]);
+                        if (t < 0 || t > 15) return bad("bad JPEG Huffman code");
+                        comp[c].pred += jpeg_extend(br.receive(t), t);
+                        coef[0] = comp[c].pred * quant[comp[c].tq][0];
+                        for (int k = 1; k < 64;) {
+                            const int rs = jpeg_decode_symbol(br, ac[comp[c].ta]);
+                            if (rs < 0) return bad("bad JPEG Huffman code");
+                            const int r = rs >> 4, sz = rs & 15;
+                            if (sz == 0) {
+                                if (r != 15) break;  // end of block
+                                k += 16;
+                                continue;
+                            }
+                            k += r;
+                            if (k > 63) return bad("JPEG block overruns");
+                            coef[kZigzag[k]] = jpeg_extend(br.receive(sz), sz) * quant[comp[c].tq][kZigzag[k]];
+                            ++k;
+                        }
+                        const size_t x0 = (size_t(mx) * comp[c].h + bx) * 8, y0 = (size_t(my) * comp[c].v + by) * 8;
+                        jpeg_idct(coef, &comp[c].plane[y0 * comp[c].w + x0], comp[c].w);
+                    }
+            if (restart_interval) --until_restart;
+        }
+    out.width = width, out.height = height, out.channels = uint32_t(n_comp);
+    out.data.assign(size_t(width) * height * n_comp, 0);
+    if (n_comp == 1) {
+        for (uint32_t y = 0; y < height; ++y) std::memcpy(&out.data[size_t(y) * width], &comp[0].plane[size_t(y) * comp[0].w], width);
+        return true;
+    }
+    std::vector<uint8_t> rows[3];
+    for (int c = 0; c < 3; ++c) rows[c].resize(size_t(comp[c].w) * size_t(hmax / comp[c].h) + 8);
+    for (uint32_t y = 0; y < height; ++y) {
+        for (int c = 0; c < 3; ++c) {
+            const int hs = hmax / comp[c].h, vs = vmax / comp[c].v;
+            if (hmax % comp[c].h || vmax % comp[c].v) return bad("fractional JPEG sampling ratios are not decoded");
+            const uint32_t ch = (height * uint32_t(comp[c].v) + uint32_t(vmax) - 1) / uint32_t(vmax);  // the component's own height (not the MCU padding)
+            uint32_t near_y = y / uint32_t(vs), far_y = near_y;
+            if (vs == 2) far_y = (y & 1u) ? std::min(near_y + 1, ch - 1) : (near_y ? near_y - 1 : 0);  // the neighbour on the side this row leans to
+            else if (vs > 2) far_y = near_y;
+            const uint32_t src_w = (width + uint32_t(hs) - 1) / uint32_t(hs);
+            jpeg_upsample_row(&comp[c].plane[size_t(near_y) * comp[c].w], &comp[c].plane[size_t(far_y) * comp[c].w], std::min(src_w, comp[c].w), hs, vs == 2 ? 2 : 1, rows[c].data());
+        }
+        uint8_t* o = &out.data[size_t(y) * width * 3];
+        for (uint32_t x = 0; x < width; ++x) {  // stb_image's fixed-point YCbCr -> RGB
+            const int yf = (int(rows[0][x]) << 20) + (1 << 19), cb = int(rows[1][x]) - 128, cr = int(rows[2][x]) - 128;
+            int r = yf + cr * 1470208, g = yf + cr * -748800 + int(uint32_t(cb * -360960) & 0xFFFF0000u), bl = yf + cb * 1858048;  // int(x * 4096 + 0.5) << 8 of 1.402, 0.71414, 0.34414, 1.772
+            r >>= 20, g >>= 20, bl >>= 20;
+            o[3 * x] = uint8_t(r < 0 ? 0 : r > 255 ? 255 : r), o[3 * x + 1] = uint8_t(g < 0 ? 0 : g > 255 ? 255 : g), o[3 * x + 2] = uint8_t(bl < 0 ? 0 : bl > 255 ? 255 : bl);
+        }
+    }
+    return true;
+}
+
 std::string lower_extension(const std::string& path) {
     const size_t p = path.find_last_of('.');
     std::string e = p == std::string::npos ? std::string() : path.substr(p);
@@ -324,9 +607,9 @@ bool decodeImage(const uint8_t* bytes, size_t size, const std::string& name, Ima
     if (size >= 8 && std::memcmp(bytes, kPngSignature, 8) == 0) return decode_png(bytes, size, name, out, why);
     if (size >= 2 && bytes[0] == 'B' && bytes[1] == 'M') return decode_bmp(bytes, size, name, out, why);
     if (size >= 2 && bytes[0] == 'P' && (bytes[1] == '5' || bytes[1] == '6')) return decode_pnm(bytes, size, name, out, why);
-    if (size >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) return why = name + ": JPEG images are not decoded here (PNG, BMP, TGA, binary PPM / PGM are)", false;
+    if (size >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) return decode_jpeg(bytes, size, name, out, why);
     if (lower_extension(name) == ".tga") return decode_tga(bytes, size, name, out, why);
-    return why = name + ": not an image format decoded here (PNG, BMP, TGA, binary PPM / PGM; the reference uses stb_image)", false;
+    return why = name + ": not an image format decoded here (PNG, JPEG, BMP, TGA, binary PPM / PGM; the reference uses stb_image)", false;
 }
 
 bool readImage(const std::string& path, Image& out, std::string& why) {

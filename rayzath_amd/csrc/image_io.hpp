@@ -7,9 +7,11 @@
 //   PNG  all colour types and bit depths, palette + tRNS, Adam7 interlacing; chunk CRCs are verified; inflate by zlib
 //   BMP  uncompressed 8-bit paletted, 24 and 32 bits per pixel, bottom-up or top-down
 //   TGA  types 2 / 3 / 10 / 11 (true colour or grey, raw or run-length encoded), 8 / 24 / 32 bits, either row order
+//   JPEG baseline / extended sequential (Huffman, 8 bits, grey or YCbCr, any 1-2-4 sampling, restart intervals); progressive refused
 //   PNM  binary P5 / P6
 // with stb_image's conventions where a file leaves a choice: 16-bit samples keep their high byte, 1/2/4-bit grey is scaled to
-// 0..255, a tRNS colour key becomes alpha 0, channels come out in R G B A order, rows top to bottom.  JPEG is not decoded.
+// 0..255, a tRNS colour key becomes alpha 0, JPEG chroma is upsampled with its 3:1 triangle filter and converted with its fixed-point
+// matrix, channels come out in R G B A order, rows top to bottom.
 #pragma once
 
 #include <cstdint>

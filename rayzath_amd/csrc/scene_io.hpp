@@ -8,7 +8,7 @@
 // most 64 per-mesh material slots; MTL `Ns` -> roughness = 1 - log10(Ns)/3, `d` / `Tr` -> colour alpha, `Pm` `Pr` `Ke`
 // `Ni`, `map_Kd` `norm` `map_Pm` `map_Pr` `map_Ke` with `-o` / `-s`; JSON colours are ints 0-255 or floats 0-1.
 // Image files: the reference decodes them with stb_image, which is not part of this repository — image_io.hpp decodes PNG,
-// BMP, TGA and binary PPM / PGM with stb_image's conventions; anything else (JPEG) is reported in the log and the map is left unset.  Groups are parsed and
+// baseline JPEG, BMP, TGA and binary PPM / PGM with stb_image's conventions; anything else is reported in the log and the map is left unset.  Groups are parsed and
 // ignored: the CPU kernel this backend follows uses the instance's own transformation (cpu_engine_kernel.cpp:308).
 #pragma once
 
