@@ -44,6 +44,11 @@ int hiprz_image_read(const char* path, uint32_t channels, uint32_t* width_out, u
                      uint8_t* pixels, size_t capacity);
 /* 8-bit PNG from `channels` (1..4) interleaved channels, rows top to bottom. */
 int hiprz_image_write_png(const char* path, const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels);
+/* One float per pixel, what stbi_loadf(path, .., 1) gives an emission map: Radiance .hdr (RGBE) as (r + g + b) / 3, any 8-bit
+ * format as pow(grey / 255, 2.2).  pixels = NULL reports the size only; capacity counts floats. */
+int hiprz_image_read_f32(const char* path, uint32_t* width_out, uint32_t* height_out, float* pixels, size_t capacity);
+/* Radiance .hdr (RGBE) from one float per pixel (stbi_write_hdr(path, w, h, 1, data), saver.cpp:76-95). */
+int hiprz_image_write_hdr(const char* path, const float* pixels, uint32_t width, uint32_t height);
 const char* hiprz_io_last_error(void);
 
 #ifdef __cplusplus

@@ -88,5 +88,23 @@ int hiprz_image_write_png(const char* path, const uint8_t* pixels, uint32_t widt
     if (!path || !IO::writePNG(path, pixels, width, height, channels, why)) return g_error = path ? why : "null path", HIPRZ_ERR_INVALID;
     return HIPRZ_OK;
 }
+int hiprz_image_read_f32(const char* path, uint32_t* width_out, uint32_t* height_out, float* pixels, size_t capacity) {
+    if (!path) return g_error = "hiprz_image_read_f32: null path", HIPRZ_ERR_INVALID;
+    uint32_t w = 0, h = 0;
+    std::vector<float> values;
+    std::string why;
+    if (!IO::readImageF32(path, w, h, values, why)) return g_error = why, HIPRZ_ERR_INVALID;
+    if (width_out) *width_out = w;
+    if (height_out) *height_out = h;
+    if (!pixels) return HIPRZ_OK;
+    if (capacity < values.size()) return g_error = "hiprz_image_read_f32: destination too small", HIPRZ_ERR_INVALID;
+    std::memcpy(pixels, values.data(), values.size() * sizeof(float));
+    return HIPRZ_OK;
+}
+int hiprz_image_write_hdr(const char* path, const float* pixels, uint32_t width, uint32_t height) {
+    std::string why;
+    if (!path || !IO::writeHDR(path, pixels, width, height, why)) return g_error = path ? why : "null path", HIPRZ_ERR_INVALID;
+    return HIPRZ_OK;
+}
 const char* hiprz_io_last_error(void) { return g_error.c_str(); }
 }

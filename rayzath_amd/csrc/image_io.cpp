@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -617,6 +618,124 @@ bool readImage(const std::string& path, Image& out, std::string& why) {
     if (!f.is_open()) return why = "failed to open " + path, false;
     std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
     return decodeImage(bytes.data(), bytes.size(), path, out, why);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Radiance RGBE (.hdr)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+bool decode_hdr(const std::vector<uint8_t>& bytes, const std::string& name, uint32_t& width, uint32_t& height, std::vector<float>& out, std::string& why) {
+    auto bad = [&](const std::string& m) { return why = name + ": " + m, false; };
+    size_t pos = 0;
+    auto line = [&]() {
+        std::string l;
+        while (pos < bytes.size() && bytes[pos] != '\n') l.push_back(char(bytes[pos++]));
+        ++pos;
+        return l;
+    };
+    const std::string magic = line();
+    if (magic != "#?RADIANCE" && magic != "#?RGBE") return bad("not a Radiance .hdr file");
+    bool format_ok = false;
+    while (pos < bytes.size()) {
+        const std::string l = line();
+        if (l.empty()) break;
+        if (l == "FORMAT=32-bit_rle_rgbe") format_ok = true;
+    }
+    if (!format_ok) return bad("unsupported .hdr format (32-bit_rle_rgbe is decoded)");
+    const std::string res = line();
+    long h = 0, w = 0;
+    if (std::sscanf(res.c_str(), "-Y %ld +X %ld", &h, &w) != 2 || h <= 0 || w <= 0 || h > long(kMaxSide) || w > long(kMaxSide)) return bad("unsupported .hdr orientation / size");
+    width = uint32_t(w), height = uint32_t(h);
+    std::vector<uint8_t> rgbe(size_t(w) * size_t(h) * 4);
+    const bool maybe_rle = w >= 8 && w < 32768;
+    bool flat = !maybe_rle;
+    for (long y = 0; y < h && !flat; ++y) {
+        if (pos + 4 > bytes.size()) return bad("truncated .hdr");
+        if (bytes[pos] != 2 || bytes[pos + 1] != 2 || (bytes[pos + 2] & 0x80)) {
+            if (y != 0) return bad("mixed .hdr scanline encodings");
+            flat = true;  // an old-style file: every pixel stored as it is
+            break;
+        }
+        if (((long(bytes[pos + 2]) << 8) | bytes[pos + 3]) != w) return bad("bad .hdr scanline header");
+        pos += 4;
+        for (int c = 0; c < 4; ++c) {
+            long x = 0;
+            while (x < w) {
+                if (pos >= bytes.size()) return bad("truncated .hdr");
+                uint32_t count = bytes[pos++];
+                if (count > 128) {  // a run
+                    count -= 128;
+                    if (x + long(count) > w || pos >= bytes.size()) return bad("bad .hdr run");
+                    const uint8_t v = bytes[pos++];
+                    for (uint32_t k = 0; k < count; ++k) rgbe[(size_t(y) * w + x++) * 4 + c] = v;
+                } else {
+                    if (count == 0 || x + long(count) > w || pos + count > bytes.size()) return bad("bad .hdr packet");
+                    for (uint32_t k = 0; k < count; ++k) rgbe[(size_t(y) * w + x++) * 4 + c] = bytes[pos++];
+                }
+            }
+        }
+    }
+    if (flat) {
+        if (pos + rgbe.size() > bytes.size()) return bad("truncated .hdr");
+        std::memcpy(rgbe.data(), bytes.data() + pos, rgbe.size());
+    }
+    out.resize(size_t(w) * size_t(h));
+    for (size_t i = 0; i < out.size(); ++i) {
+        const uint8_t* p = &rgbe[i * 4];
+        out[i] = p[3] ? float(int(p[0]) + int(p[1]) + int(p[2])) * std::ldexp(1.0f, int(p[3]) - (128 + 8)) / 3.0f : 0.0f;
+    }
+    return true;
+}
+}  // namespace
+
+bool readImageF32(const std::string& path, uint32_t& width, uint32_t& height, std::vector<float>& out, std::string& why) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f.is_open()) return why = "failed to open " + path, false;
+    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (bytes.size() >= 2 && bytes[0] == '#' && bytes[1] == '?') return decode_hdr(bytes, path, width, height, out, why);
+    Image img;
+    if (!decodeImage(bytes.data(), bytes.size(), path, img, why)) return false;
+    const std::vector<uint8_t> grey = convertChannels(img, 1);
+    width = img.width, height = img.height;
+    out.resize(grey.size());
+    for (size_t i = 0; i < grey.size(); ++i) out[i] = float(std::pow(grey[i] / 255.0f, 2.2f));
+    return true;
+}
+
+bool writeHDR(const std::string& path, const float* pixels, uint32_t width, uint32_t height, std::string& why) {
+    if (!pixels || width == 0 || height == 0 || width > kMaxSide || height > kMaxSide) return why = "writeHDR: bad arguments", false;
+    std::vector<uint8_t> file;
+    const std::string header = "#?RADIANCE\n# Written by hiprz image_io\nFORMAT=32-bit_rle_rgbe\nEXPOSURE=1.0\n\n-Y " + std::to_string(height) + " +X " + std::to_string(width) + "\n";
+    file.insert(file.end(), header.begin(), header.end());
+    std::vector<uint8_t> row(size_t(width) * 4);
+    for (uint32_t y = 0; y < height; ++y) {
+        for (uint32_t x = 0; x < width; ++x) {
+            const float v = pixels[size_t(y) * width + x];
+            uint8_t* p = &row[size_t(x) * 4];
+            if (!(v >= 1e-32f)) {
+                p[0] = p[1] = p[2] = p[3] = 0;
+            } else {
+                int e;
+                const float normalize = float(std::frexp(v, &e)) * 256.0f / v;
+                p[0] = p[1] = p[2] = uint8_t(v * normalize), p[3] = uint8_t(e + 128);
+            }
+        }
+        if (width < 8 || width >= 32768) {
+            file.insert(file.end(), row.begin(), row.end());
+            continue;
+        }
+        file.push_back(2), file.push_back(2), file.push_back(uint8_t(width >> 8)), file.push_back(uint8_t(width & 255));
+        for (int c = 0; c < 4; ++c)  // new-style scanline: each component on its own, here as plain (non-run) packets of <= 128 bytes
+            for (uint32_t x = 0; x < width; x += 128) {
+                const uint32_t n = std::min(128u, width - x);
+                file.push_back(uint8_t(n));
+                for (uint32_t k = 0; k < n; ++k) file.push_back(row[size_t(x + k) * 4 + c]);
+            }
+    }
+    std::ofstream f(path, std::ios::binary);
+    if (!f.is_open()) return why = "failed to open " + path + " for writing", false;
+    f.write(reinterpret_cast<const char*>(file.data()), std::streamsize(file.size()));
+    return f.good() ? true : (why = "failed to write " + path, false);
 }
 
 std::vector<uint8_t> convertChannels(const Image& img, uint32_t channels) {

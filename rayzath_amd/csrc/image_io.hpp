@@ -32,6 +32,12 @@ bool decodeImage(const uint8_t* bytes, size_t size, const std::string& name, Ima
 // stb_image's channel conversion (stbi__convert_format): grey from RGB = (77 r + 150 g + 29 b) >> 8, missing alpha = 255
 std::vector<uint8_t> convertChannels(const Image& img, uint32_t channels);
 
+// stbi_loadf(path, .., 1): one float per pixel.  Radiance .hdr files (RGBE, flat or run-length encoded scanlines) give
+// (r + g + b) / 3 of the decoded floats; every 8-bit format gives pow(grey / 255, 2.2), as stb_image's LDR-to-HDR conversion does.
+bool readImageF32(const std::string& path, uint32_t& width, uint32_t& height, std::vector<float>& out, std::string& why);
+// stbi_write_hdr(path, w, h, 1, data): Radiance RGBE with r = g = b = the value (mantissa of the largest component, shared exponent)
+bool writeHDR(const std::string& path, const float* pixels, uint32_t width, uint32_t height, std::string& why);
+
 // 8-bit PNG, colour type by `channels` (1, 2, 3 or 4), no interlacing, filter chosen per row (minimum sum of absolute differences)
 bool writePNG(const std::string& path, const uint8_t* pixels, uint32_t width, uint32_t height, uint32_t channels, std::string& why);
 

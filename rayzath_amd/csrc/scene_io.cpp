@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <filesystem>
 #include <fstream>
 #include <limits>
 #include <set>
@@ -53,28 +54,29 @@ float clampf(float v, float lo, float hi) { return v < lo ? lo : v > hi ? hi : v
 // BitmapLoader::loadMap<...> (loader.cpp:36-98): RGBA8 (stbi_load(.., 4)) / RGBA8 with green negated / R8 (stbi_load(.., 1)) /
 // R8 / R32F (stbi_loadf(.., 1): stb_image turns 8-bit data into floats with gamma 2.2 and scale 1)
 std::shared_ptr<TextureBuffer> load_map(const std::string& path, uint32_t kind, bool normal_map, LoadLog& log) {
-    Image img;
+    auto t = std::make_shared<TextureBuffer>();
+    t->kind = kind;
     std::string why;
+    if (kind == HIPRZ_TEX_R32F) {  // stbi_loadf(.., 1): Radiance .hdr as it is, 8-bit formats through gamma 2.2
+        std::vector<float> values;
+        if (!readImageF32(path, t->width, t->height, values, why)) return log.error(why), nullptr;
+        t->bitmap.resize(values.size() * 4);
+        std::memcpy(t->bitmap.data(), values.data(), t->bitmap.size());
+        return t;
+    }
+    Image img;
     if (!readImage(path, img, why)) {
         log.error(why);
         return nullptr;
     }
-    auto t = std::make_shared<TextureBuffer>();
-    t->kind = kind, t->width = img.width, t->height = img.height;
+    t->width = img.width, t->height = img.height;
     const size_t n = size_t(img.width) * img.height;
     if (kind == HIPRZ_TEX_RGBA8) {
         t->bitmap = convertChannels(img, 4);
         if (normal_map)
             for (size_t i = 0; i < n; ++i) t->bitmap[i * 4 + 1] = uint8_t(-t->bitmap[i * 4 + 1]);  // loader.cpp:54-66
-    } else if (kind == HIPRZ_TEX_R8) {
-        t->bitmap = convertChannels(img, 1);
     } else {
-        const std::vector<uint8_t> grey = convertChannels(img, 1);
-        t->bitmap.resize(n * 4);
-        for (size_t i = 0; i < n; ++i) {
-            const float v = float(std::pow(grey[i] / 255.0f, 2.2f));
-            std::memcpy(&t->bitmap[i * 4], &v, 4);
-        }
+        t->bitmap = convertChannels(img, 1);
     }
     return t;
 }
@@ -1050,12 +1052,60 @@ std::string vec3(const vec3f& v) { return "[" + num(v.x) + ", " + num(v.y) + ", 
 std::string color(const Color& c) {
     return "[" + std::to_string(c.red) + ", " + std::to_string(c.green) + ", " + std::to_string(c.blue) + ", " + std::to_string(c.alpha) + "]";
 }
-std::string material_body(const Material& m, const std::string& name) {
+// Maps of a saved scene (JsonSaver::saveMap, json_saver.cpp:117-157; BitmapSaver, saver.cpp:16-95): one file per distinct map under
+// <scene dir>/maps/<kind>/ — RGBA PNG for textures and normal maps, grey PNG for metalness / roughness, Radiance .hdr for emission.
+// Deliberate difference: a normal map is written with its green channel negated back, so that the file holds what was loaded
+// (the reference writes the in-memory bitmap, whose green the loader negated: every save / load cycle flips it there).
+struct SavedMaps {
+    static constexpr const char* kJsonKeys[5] = {"Texture", "NormalMap", "MetalnessMap", "RoughnessMap", "EmissionMap"};
+    static constexpr const char* kDirs[5] = {"texture", "normal", "metalness", "roughness", "emission"};
+    static constexpr const char* kMaterialKeys[5] = {"texture", "normal map", "metalness map", "roughness map", "emission map"};
+    std::vector<const TextureBuffer*> list[5];
+    std::map<const TextureBuffer*, std::string> name[5], file[5];  // file: relative to the scene directory, '/' separators
+
+    static const std::shared_ptr<TextureBuffer>& slot(const Material& m, int k) {
+        return k == 0 ? m.texture : k == 1 ? m.normal_map : k == 2 ? m.metalness_map : k == 3 ? m.roughness_map : m.emission_map;
+    }
+    void collect(const Material& m) {
+        for (int k = 0; k < 5; ++k)
+            if (const TextureBuffer* t = slot(m, k).get(); t && !name[k].count(t)) {
+                name[k][t] = std::string(kDirs[k]) + " " + std::to_string(list[k].size());
+                list[k].push_back(t);
+            }
+    }
+    void write(const std::string& scene_dir) {
+        for (int k = 0; k < 5; ++k)
+            for (size_t i = 0; i < list[k].size(); ++i) {
+                const TextureBuffer& t = *list[k][i];
+                const std::string rel_dir = std::string("maps/") + kDirs[k], rel = rel_dir + "/" + kDirs[k] + "_" + std::to_string(i) + (k == 4 ? ".hdr" : ".png");
+                std::error_code ec;
+                std::filesystem::create_directories(scene_dir + rel_dir, ec);
+                std::string why;
+                bool ok;
+                if (k == 4) {
+                    ok = writeHDR(scene_dir + rel, reinterpret_cast<const float*>(t.bitmap.data()), t.width, t.height, why);
+                } else if (k == 1) {
+                    std::vector<uint8_t> px = t.bitmap;
+                    for (size_t p = 1; p < px.size(); p += 4) px[p] = uint8_t(-px[p]);
+                    ok = writePNG(scene_dir + rel, px.data(), t.width, t.height, 4, why);
+                } else {
+                    ok = writePNG(scene_dir + rel, t.bitmap.data(), t.width, t.height, k == 0 ? 4 : 1, why);
+                }
+                if (!ok) fail(why);
+                file[k][&t] = rel;
+            }
+    }
+};
+
+std::string material_body(const Material& m, const std::string& name, const SavedMaps* maps = nullptr) {
     std::string s = "{";
     if (!name.empty()) s += "\"name\": \"" + name + "\", ";
     s += "\"color\": " + color(m.color) + ", \"metalness\": " + num(m.metalness()) + ", \"roughness\": " + num(m.roughness()) +
-         ", \"emission\": " + num(m.emission()) + ", \"ior\": " + num(m.ior()) + ", \"scattering\": " + num(m.scattering()) + "}";
-    return s;
+         ", \"emission\": " + num(m.emission()) + ", \"ior\": " + num(m.ior()) + ", \"scattering\": " + num(m.scattering());
+    if (maps)
+        for (int k = 0; k < 5; ++k)
+            if (const TextureBuffer* t = SavedMaps::slot(m, k).get()) s += std::string(", \"") + SavedMaps::kMaterialKeys[k] + "\": \"" + maps->name[k].at(t) + "\"";
+    return s + "}";
 }
 }  // namespace
 
@@ -1064,10 +1114,27 @@ void saveScene(const std::string& path, const World& world) {
     if (!out.is_open()) fail("Failed to open file " + path + " for writing");
     std::map<const Material*, std::string> mat_name;
     std::map<const Mesh*, std::string> mesh_name;
-    out << "{\n \"Objects\": {\n  \"Material\": [";
+    SavedMaps maps;
+    for (const auto& m : world.materials) maps.collect(*m);
+    maps.collect(world.material), maps.collect(world.default_material);
+    const size_t slash = path.find_last_of("/\\");
+    maps.write(slash == std::string::npos ? std::string() : path.substr(0, slash + 1));
+    out << "{\n \"Objects\": {";
+    for (int k = 0; k < 5; ++k) {
+        if (maps.list[k].empty()) continue;
+        out << "\n  \"" << SavedMaps::kJsonKeys[k] << "\": [";
+        for (size_t i = 0; i < maps.list[k].size(); ++i) {
+            const TextureBuffer& t = *maps.list[k][i];
+            out << (i ? ",\n   " : "\n   ") << "{\"name\": \"" << maps.name[k][&t] << "\", \"filter mode\": \"point\", \"address mode\": \"wrap\", \"scale\": [" << num(t.scale[0]) << ", "
+                << num(t.scale[1]) << "], \"rotation\": " << num(t.rotation) << ", \"translation\": [" << num(t.translation[0]) << ", " << num(t.translation[1]) << "], \"file\": \""
+                << maps.file[k][&t] << "\"}";
+        }
+        out << "\n  ],";
+    }
+    out << "\n  \"Material\": [";
     for (size_t i = 0; i < world.materials.size(); ++i) {
         mat_name[world.materials[i].get()] = "material " + std::to_string(i);
-        out << (i ? ",\n   " : "\n   ") << material_body(*world.materials[i], mat_name[world.materials[i].get()]);
+        out << (i ? ",\n   " : "\n   ") << material_body(*world.materials[i], mat_name[world.materials[i].get()], &maps);
     }
     out << "\n  ],\n  \"Mesh\": [";
     size_t n_mesh = 0;
@@ -1123,7 +1190,7 @@ void saveScene(const std::string& path, const World& world) {
         if (inst.mesh) out << ", \"Mesh\": \"" << mesh_name[inst.mesh.get()] << "\"";
         out << "}";
     }
-    out << "\n  ]\n },\n \"Material\": " << material_body(world.material, "") << ",\n \"DefaultMaterial\": " << material_body(world.default_material, "") << "\n}\n";
+    out << "\n  ]\n },\n \"Material\": " << material_body(world.material, "", &maps) << ",\n \"DefaultMaterial\": " << material_body(world.default_material, "", &maps) << "\n}\n";
 }
 
 void saveOBJ(const std::string& path, const World& world) {
@@ -1132,12 +1199,22 @@ void saveOBJ(const std::string& path, const World& world) {
     std::ofstream obj(path), mtl(mtl_path);
     if (!obj.is_open() || !mtl.is_open()) fail("Failed to open " + path + " / " + mtl_path + " for writing");
     std::map<const Material*, std::string> mat_name;
+    SavedMaps maps;
+    for (const auto& m : world.materials) maps.collect(*m);
+    const size_t slash = path.find_last_of("/\\");
+    maps.write(slash == std::string::npos ? std::string() : path.substr(0, slash + 1));
     for (size_t i = 0; i < world.materials.size(); ++i) {
         const Material& m = *world.materials[i];
         const std::string name = "material_" + std::to_string(i);
         mat_name[&m] = name;
         mtl << "newmtl " << name << "\nKd " << num(m.color.red / 255.0f) << ' ' << num(m.color.green / 255.0f) << ' ' << num(m.color.blue / 255.0f) << "\nd " << num(m.color.alpha / 255.0f)
-            << "\nNi " << num(m.ior()) << "\nPm " << num(m.metalness()) << "\nPr " << num(m.roughness()) << "\nKe " << num(m.emission()) << "\n\n";
+            << "\nNi " << num(m.ior()) << "\nPm " << num(m.metalness()) << "\nPr " << num(m.roughness()) << "\nKe " << num(m.emission()) << "\n";
+        static const char* statements[5] = {"map_Kd", "norm", "map_Pm", "map_Pr", "map_Ke"};  // MTLSaver::saveMTL (saver.cpp:97-170)
+        for (int k = 0; k < 5; ++k)
+            if (const TextureBuffer* t = SavedMaps::slot(m, k).get())
+                mtl << statements[k] << " -o " << num(t->translation[0]) << ' ' << num(t->translation[1]) << " -s " << num(t->scale[0]) << ' ' << num(t->scale[1]) << " \"" << maps.file[k][t]
+                    << "\"\n";
+        mtl << "\n";
     }
     obj << "mtllib " << file_name(mtl_path) << "\n";
     size_t v_base = 0, t_base = 0, n_base = 0;

@@ -39,13 +39,16 @@ def host_lib():
         U32P = C.POINTER(C.c_uint32)
         lib.hiprz_image_read.restype, lib.hiprz_image_read.argtypes = C.c_int, [C.c_char_p, C.c_uint32, U32P, U32P, U32P, P, C.c_size_t]
         lib.hiprz_image_write_png.restype, lib.hiprz_image_write_png.argtypes = C.c_int, [C.c_char_p, P, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.hiprz_image_read_f32.restype, lib.hiprz_image_read_f32.argtypes = C.c_int, [C.c_char_p, U32P, U32P, P, C.c_size_t]
+        lib.hiprz_image_write_hdr.restype, lib.hiprz_image_write_hdr.argtypes = C.c_int, [C.c_char_p, P, C.c_uint32, C.c_uint32]
         _HOST = lib
     return _HOST
 
 
 IO_ENTRY_POINTS = ("hiprz_scene_file_load", "hiprz_scene_file_free", "hiprz_scene_file_scene", "hiprz_scene_file_camera",
                    "hiprz_scene_file_log", "hiprz_scene_file_error_count", "hiprz_scene_file_warning_count",
-                   "hiprz_scene_file_save", "hiprz_io_last_error", "hiprz_image_read", "hiprz_image_write_png")
+                   "hiprz_scene_file_save", "hiprz_io_last_error", "hiprz_image_read", "hiprz_image_write_png", "hiprz_image_read_f32",
+                   "hiprz_image_write_hdr")
 
 
 def read_image(path, channels=0):
@@ -59,6 +62,58 @@ def read_image(path, channels=0):
     if lib.hiprz_image_read(os.fsencode(path), channels, None, None, None, out.ctypes.data_as(C.c_void_p), out.nbytes) != 0:
         raise _lib.HiprzError(-2, lib.hiprz_io_last_error().decode())
     return out
+
+
+def read_image_f32(path):
+    """One float per pixel, as stbi_loadf(path, .., 1) gives an emission map (include/hiprz_io.h) -> float32 array (height, width)."""
+    lib = host_lib()
+    w, h = C.c_uint32(), C.c_uint32()
+    if lib.hiprz_image_read_f32(os.fsencode(path), C.byref(w), C.byref(h), None, 0) != 0:
+        raise _lib.HiprzError(-2, lib.hiprz_io_last_error().decode())
+    out = np.zeros((h.value, w.value), dtype=np.float32)
+    if lib.hiprz_image_read_f32(os.fsencode(path), None, None, out.ctypes.data_as(C.c_void_p), out.size) != 0:
+        raise _lib.HiprzError(-2, lib.hiprz_io_last_error().decode())
+    return out
+
+
+def write_hdr(path, pixels):
+    """float32 array (height, width) -> Radiance .hdr (RGBE), written by the C++ host library."""
+    lib = host_lib()
+    a = np.ascontiguousarray(pixels, dtype=np.float32)
+    if lib.hiprz_image_write_hdr(os.fsencode(path), a.ctypes.data_as(C.c_void_p), a.shape[1], a.shape[0]) != 0:
+        raise _lib.HiprzError(-2, lib.hiprz_io_last_error().decode())
+
+
+_MAP_SLOTS = (("texture", "texture", "Texture"), ("normal_map", "normal map", "NormalMap"), ("metalness_map", "metalness map", "MetalnessMap"),
+              ("roughness_map", "roughness map", "RoughnessMap"), ("emission_map", "emission map", "EmissionMap"))
+_MAP_DIRS = ("texture", "normal", "metalness", "roughness", "emission")
+
+
+def _save_maps(materials, scene_dir):
+    """Every distinct map of `materials` as a file under <scene_dir>/maps/<kind>/ — the layout and conventions of the C++ saver
+    (rayzath_amd/csrc/scene_io.cpp: SavedMaps): RGBA / grey PNG, Radiance .hdr for emission, a normal map's green negated back.
+    Returns per kind {id(map): (name, relative file)} and the ordered lists."""
+    names, order = [dict() for _ in range(5)], [[] for _ in range(5)]
+    for m in materials:
+        for k, (attr, _, _) in enumerate(_MAP_SLOTS):
+            t = getattr(m, attr)
+            if t is None or id(t) in names[k]:
+                continue
+            i = len(order[k])
+            rel = f"maps/{_MAP_DIRS[k]}/{_MAP_DIRS[k]}_{i}" + (".hdr" if k == 4 else ".png")
+            os.makedirs(os.path.join(scene_dir, "maps", _MAP_DIRS[k]), exist_ok=True)
+            full = os.path.join(scene_dir, rel)
+            if k == 4:
+                write_hdr(full, t.bitmap)
+            elif k == 1:
+                px = t.bitmap.copy()
+                px[..., 1] = (-px[..., 1].astype(np.int32)) & 0xFF
+                write_png(full, px)
+            else:
+                write_png(full, t.bitmap)
+            names[k][id(t)] = (f"{_MAP_DIRS[k]} {i}", rel)
+            order[k].append(t)
+    return names, order
 
 
 def write_png(path, pixels):
@@ -148,9 +203,18 @@ def _material(m, name=None):
 
 
 def save_scene_json(world, path):
-    """The World as a RayZath .json scene with inline meshes (json_loader.cpp:538-662 reads them back).  Maps are not
-    written: the host library has no image encoder."""
+    """The World as a RayZath .json scene with inline meshes (json_loader.cpp:538-662 reads them back); maps go to
+    <dir>/maps/<kind>/ as PNG / .hdr files (JsonSaver::saveMap, json_saver.cpp:117-157)."""
     mats = list(world.materials)
+    map_names, map_order = _save_maps(mats + [world.material, world.default_material], os.path.dirname(os.path.abspath(path)))
+
+    def with_maps(body, m):
+        for k, (attr, key, _) in enumerate(_MAP_SLOTS):
+            t = getattr(m, attr)
+            if t is not None:
+                body[key] = map_names[k][id(t)][0]
+        return body
+
     mat_name = {id(m): f"material {i}" for i, m in enumerate(mats)}
     meshes, mesh_name = [], {}
     for inst in world.instances:
@@ -174,7 +238,7 @@ def save_scene_json(world, path):
 
     cam = world.camera
     objects = {
-        "Material": [_material(m, mat_name[id(m)]) for m in mats],
+        "Material": [with_maps(_material(m, mat_name[id(m)]), m) for m in mats],
         "Mesh": [mesh_json(m, mesh_name[id(m)]) for m in meshes],
         "Camera": [{"name": "camera", "position": _v(cam.position), "rotation": _v(cam.rotation),
                     "resolution": [int(cam.width), int(cam.height)], "fov": _f(cam.fov), "near plane": _f(cam.near_far[0]),
@@ -192,7 +256,13 @@ def save_scene_json(world, path):
         if inst.mesh is not None:
             e["Mesh"] = mesh_name[id(inst.mesh)]
         objects["Instance"].append(e)
-    doc = {"Objects": objects, "Material": _material(world.material), "DefaultMaterial": _material(world.default_material)}
+    for k, (_, _, json_key) in enumerate(_MAP_SLOTS):
+        if map_order[k]:
+            objects[json_key] = [{"name": map_names[k][id(t)][0], "filter mode": "point", "address mode": "wrap", "scale": [_f(t.scale[0]), _f(t.scale[1])],
+                                  "rotation": _f(t.rotation), "translation": [_f(t.translation[0]), _f(t.translation[1])],
+                                  "file": map_names[k][id(t)][1]} for t in map_order[k]]
+    doc = {"Objects": objects, "Material": with_maps(_material(world.material), world.material),
+           "DefaultMaterial": with_maps(_material(world.default_material), world.default_material)}
     with open(path, "w") as f:
         json.dump(doc, f)
 
@@ -206,11 +276,17 @@ def save_obj(world, path):
     mats = list(world.materials)
     name = {id(m): f"material_{i}" for i, m in enumerate(mats)}
     r = lambda x: repr(_f(x))  # shortest decimal that reads back to the same float32
+    map_names, _ = _save_maps(mats, os.path.dirname(os.path.abspath(path)))
     with open(mtl_path, "w") as f:
         for m in mats:
             c = [np.float32(x) / np.float32(255.0) for x in m.color]
             f.write(f"newmtl {name[id(m)]}\nKd {r(c[0])} {r(c[1])} {r(c[2])}\nd {r(c[3])}\nNi {r(m.ior)}\nPm {r(m.metalness)}\n"
-                    f"Pr {r(m.roughness)}\nKe {r(m.emission)}\n\n")
+                    f"Pr {r(m.roughness)}\nKe {r(m.emission)}\n")
+            for k, statement in enumerate(("map_Kd", "norm", "map_Pm", "map_Pr", "map_Ke")):
+                t = getattr(m, _MAP_SLOTS[k][0])
+                if t is not None:
+                    f.write(f'{statement} -o {r(t.translation[0])} {r(t.translation[1])} -s {r(t.scale[0])} {r(t.scale[1])} "{map_names[k][id(t)][1]}"\n')
+            f.write("\n")
     unused = 0xFFFFFFFF
     with open(path, "w") as f:
         f.write(f"mtllib {os.path.basename(mtl_path)}\n")

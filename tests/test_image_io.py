@@ -299,3 +299,31 @@ def test_png_maps_reach_the_flattened_scene(tmp_path):
     want[..., 1] = (-want[..., 1].astype(np.int32)) & 0xFF                     # green negated (loader.cpp:54-66)
     assert np.array_equal(f.texels[nrm["offset"]:nrm["offset"] + 16].reshape(2, 2, 4), want)
     assert list(f.texels[rough["offset"]:rough["offset"] + 2]) == [10, 200]   # grey of (10,10,10) / (200,200,200): (77+150+29) * v >> 8 = v
+
+
+def test_radiance_hdr_round_trip_and_float_maps(tmp_path):
+    """writeHDR / readImageF32: Radiance RGBE as stbi_write_hdr(.., 1, ..) / stbi_loadf(.., 1) treat a one-channel float map; 8-bit
+    files come back through gamma 2.2."""
+    rng = np.random.default_rng(8)
+    for shape in ((3, 5), (9, 40), (4, 200)):        # width < 8: flat scanlines; otherwise new-style (component-wise) scanlines
+        values = (rng.random(shape) * np.array([0.001, 1.0, 50.0, 3000.0])[rng.integers(0, 4, size=shape)]).astype(np.float32)
+        values[0, 0] = 0.0
+        path = tmp_path / "e.hdr"
+        scene_io.write_hdr(str(path), values)
+        got = scene_io.read_image_f32(str(path))
+        # expected: mantissa byte m = int(v * frexp-normalisation), exponent e; decoded 3 * m * 2^(e - 136) / 3
+        mant, exp = np.frexp(values.astype(np.float64))
+        m = np.where(values >= 1e-32, np.floor(values * (mant.astype(np.float32) * np.float32(256.0) / np.where(values > 0, values, 1))), 0)
+        want = np.where(values >= 1e-32, (3 * m) * np.ldexp(1.0, exp - 8) / 3.0, 0.0).astype(np.float32)
+        assert got.shape == shape and np.allclose(got, want, rtol=1e-6, atol=0)
+        assert np.all(np.abs(got - values) <= values / 128 + 1e-30)      # 8-bit mantissa
+    # an old-style run-length file written by hand: header, then one scanline with a run and a literal packet per component
+    w = 10
+    comp = [bytes([128 + 6, 64]) + bytes([4, 1, 2, 3, 4]), bytes([128 + 10, 64]), bytes([128 + 10, 64]), bytes([128 + 10, 129])]
+    (tmp_path / "r.hdr").write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 10\n" + bytes([2, 2, 0, w]) + b"".join(comp))
+    got = scene_io.read_image_f32(str(tmp_path / "r.hdr"))[0]
+    first = np.array([64] * 6 + [1, 2, 3, 4], dtype=np.float64)
+    assert np.allclose(got, (first + 128) * 2.0 ** (129 - 136) / 3.0)
+    grey = rng.integers(0, 256, size=(4, 4, 1))
+    (tmp_path / "g.png").write_bytes(encode_png(grey, 0, 8))
+    assert np.allclose(scene_io.read_image_f32(str(tmp_path / "g.png")), (grey[..., 0] / np.float32(255.0)) ** np.float32(2.2), rtol=1e-5)

@@ -403,6 +403,28 @@ def test_scene_file_renders_like_the_model_it_was_written_from(built, tmp_path):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
 
 
+def test_textured_scene_files_render_like_the_model(built, tmp_path):
+    """Config D's kind of scene (displaced sphere with texture, normal map and roughness map) written to .json + PNG maps, read
+    back by the C++ loader (own PNG decoder) and rendered: the same frame as the Python model it was written from, bit for bit."""
+    from rayzath_amd import scene_io
+    world = scenes.textured_sphere_scene(128, 80, resolution=60, map_size=64)
+    path = str(tmp_path / "sphere.json")
+    scene_io.save_scene_json(world, path)
+    assert sorted(os.listdir(tmp_path / "maps")) == ["normal", "roughness", "texture"]
+    loaded = scene_io.load_scene_file(path)
+    assert loaded.errors == 0, loaded.log
+    cfg = RenderConfig(LightSampling(1, 1), Tracing(6, 4)).struct()
+    out = []
+    for flat, cam in ((flatten(world), camera_struct(world.camera)), (loaded.flat, loaded.camera)):
+        c = Context(0)
+        c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+        counters = c.render_counted(1)
+        c.render(5)
+        out.append((c.read_accum(), c.read_depth(), counters))
+    assert out[0][2] == out[1][2] and out[0][2]["texel_fetches"] > 0
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_headless_runner_end_to_end(built, tmp_path):
     """hiprz_headless --headless tasks.json: loads the scene file, renders through Hip::Engine::renderWorld with the reference's
     adaptive passes-per-call loop, writes report.txt in the reference's format and (with -r) the frame."""

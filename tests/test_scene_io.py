@@ -325,3 +325,73 @@ def test_generated_cone_cylinder_torus(tmp_path):
     side &= ~np.isclose(f.tris["v1"][per_mesh[1]][:, 1], f.tris["v3"][per_mesh[1]][:, 1]) | ~np.isclose(f.tris["v1"][per_mesh[1]][:, 1], f.tris["v2"][per_mesh[1]][:, 1])
     p, n = f.tris["v1"][per_mesh[1]][side], attrs["n1"][side]
     assert side.sum() == 18 and (np.einsum("ij,ij->i", p * [1, 0, 1], n) > 0.9).all()
+
+
+def _textured_world():
+    rng = np.random.default_rng(4)
+    from rayzath_amd.scene import TextureBuffer
+    tex = TextureBuffer(rng.integers(0, 256, size=(6, 5, 4)).astype(np.uint8), scale=(2.0, 0.5), rotation=0.25, translation=(0.125, 0.75))
+    nrm = TextureBuffer(rng.integers(0, 256, size=(4, 4, 4)).astype(np.uint8))
+    rough = TextureBuffer(rng.integers(0, 256, size=(3, 7)).astype(np.uint8))
+    metal = TextureBuffer(rng.integers(0, 256, size=(2, 2)).astype(np.uint8))
+    # emission values an 8-bit mantissa holds exactly, so that the .hdr file gives them back bit for bit
+    emis = TextureBuffer((rng.integers(128, 256, size=(3, 3)) * 2.0 ** rng.integers(-9, 3, size=(3, 3))).astype(np.float32))
+    w = World()
+    a = w.add(Material((200, 100, 50, 255), 0.2, 0.4, texture=tex, normal_map=nrm, roughness_map=rough, name="a"))
+    b = w.add(Material((10, 20, 30, 255), 0.0, 1.0, emission=4.0, texture=tex, metalness_map=metal, emission_map=emis, name="b"))
+    w.add(Instance(generate_plane(4, 1.0, 1.0), [a], position=(0, 0, 1)))
+    w.add(Instance(generate_cube(), [b], position=(1, 0.5, 0), scale=(0.5, 0.5, 0.5)))
+    w.camera = Camera(position=(0, 1, -3), resolution=(32, 24))
+    return w
+
+
+def test_saved_scenes_carry_their_maps(tmp_path):
+    """Scene writers put every distinct map into <dir>/maps/<kind>/ (RGBA / grey PNG, Radiance .hdr for emission) and name them in
+    the .json / .mtl; reading the files back — written by the Python model or by the C++ host library — gives the flattened
+    snapshot of the model, texel for texel, with the map transforms."""
+    w = _textured_world()
+    want = flatten(w)
+    os.makedirs(tmp_path / "py")
+    scene_io.save_scene_json(w, str(tmp_path / "py" / "scene.json"))
+    loaded = scene_io.load_scene_file(str(tmp_path / "py" / "scene.json"))
+    assert loaded.errors == 0, loaded.log
+    assert sorted(os.listdir(tmp_path / "py" / "maps")) == ["emission", "metalness", "normal", "roughness", "texture"]
+    assert os.listdir(tmp_path / "py" / "maps" / "texture") == ["texture_0.png"]          # shared by both materials: written once
+    got = loaded.flat
+    assert np.array_equal(got.texels, want.texels)
+    for k in ("kind", "width", "height", "offset", "scale", "rotation", "translation"):
+        assert np.array_equal(got.textures[k], want.textures[k]), k
+    for k in ("texture", "normal_map", "metalness_map", "roughness_map", "emission_map"):
+        assert np.array_equal(got.materials[k], want.materials[k]), k
+    # the C++ writer: load -> save -> load again
+    os.makedirs(tmp_path / "cpp")
+    handle = C.c_void_p()
+    lib = scene_io.host_lib()
+    assert lib.hiprz_scene_file_load(str(tmp_path / "py" / "scene.json").encode(), C.byref(handle)) == 0
+    assert lib.hiprz_scene_file_save(handle, str(tmp_path / "cpp" / "again.json").encode(), 0) == 0, lib.hiprz_io_last_error()
+    assert lib.hiprz_scene_file_save(handle, str(tmp_path / "cpp" / "again.obj").encode(), 1) == 0, lib.hiprz_io_last_error()
+    lib.hiprz_scene_file_free(handle)
+    again = scene_io.load_scene_file(str(tmp_path / "cpp" / "again.json"))
+    assert again.errors == 0, again.log
+    assert np.array_equal(again.flat.texels, want.texels) and np.array_equal(again.flat.textures, got.textures)
+    mtl = (tmp_path / "cpp" / "again.mtl").read_text()
+    assert 'map_Kd -o 0.125 0.75 -s 2.0 0.5 "maps/texture/texture_0.png"' in mtl and "map_Ke" in mtl and "norm " in mtl
+    def maps_of(flat, material):      # {slot: (record fields, texel bytes)}; an .mtl names a file per statement, so a shared map is read twice
+        out = {}
+        for k in ("texture", "normal_map", "metalness_map", "roughness_map", "emission_map"):
+            t = int(flat.materials[material][k])
+            if t >= 0:
+                r = flat.textures[t]
+                n = int(r["width"]) * int(r["height"]) * (1 if r["kind"] == _abi.TEX_R8 else 4)
+                out[k] = (tuple(int(r[f]) for f in ("kind", "width", "height")), tuple(r["scale"]), tuple(r["translation"]),
+                          flat.texels[int(r["offset"]):int(r["offset"]) + n].tobytes())
+        return out
+    from_obj = scene_io.load_scene_file(str(tmp_path / "cpp" / "again.obj"))
+    assert from_obj.errors == 0, from_obj.log
+    # the Python .obj / .mtl writer as well
+    os.makedirs(tmp_path / "pyobj")
+    scene_io.save_obj(w, str(tmp_path / "pyobj" / "scene.obj"))
+    from_pyobj = scene_io.load_scene_file(str(tmp_path / "pyobj" / "scene.obj"))
+    assert from_pyobj.errors == 0, from_pyobj.log
+    for material in (2, 3):
+        assert maps_of(from_obj.flat, material) == maps_of(want, material) == maps_of(from_pyobj.flat, material)
