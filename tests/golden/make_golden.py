@@ -122,10 +122,14 @@ def end_to_end(name, world, max_depth, passes, spot=1, direct=1):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "textured":   # only the fixture added last (the others stay byte-identical)
+        end_to_end("textured_80x48", scenes.textured_sphere_scene(80, 48, resolution=24, map_size=32), 6, 4)
+        sys.exit(0)
     kat()
     end_to_end("cornell_128", scenes.cornell_box(128, 128), 4, 16)       # config A at half resolution
     end_to_end("living_room_96x64", scenes.living_room(96, 64, n_instances=24), 6, 8, spot=2, direct=1)
     end_to_end("sphere_160x90", scenes.cornell_sphere(160, 90, 80), 8, 4)
+    end_to_end("textured_80x48", scenes.textured_sphere_scene(80, 48, resolution=24, map_size=32), 6, 4)   # texture, normal map, roughness map
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

@@ -11,7 +11,7 @@ from rayzath_amd import _abi
 from rayzath_amd.scene import FlatScene
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-NAMES = ["cornell_128", "living_room_96x64", "sphere_160x90"]
+NAMES = ["cornell_128", "living_room_96x64", "sphere_160x90", "textured_80x48"]
 
 
 def load_golden(name):

@@ -275,7 +275,7 @@ def test_shared_reciprocal_division_is_exact(built):
         assert bad == 0, f"{bad} of {n} quotients differ"
 
 
-@pytest.mark.parametrize("name", ["cornell_128", "living_room_96x64", "sphere_160x90"])
+@pytest.mark.parametrize("name", ["cornell_128", "living_room_96x64", "sphere_160x90", "textured_80x48"])
 @pytest.mark.parametrize("mode", [6, 5, 4, 3, 2, 1, 0])
 def test_gpu_matches_committed_golden(built, name, mode):
     """Same comparison without the oracle in the loop: committed fixtures (tests/golden)."""
