@@ -280,6 +280,10 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
         if constexpr (SHADOW == RZ_SHADOW_DEFER) {  // rz_shadow_kernel adds (direct * a) * b once it knows the shadow masks
             lds_column.defer_done = true;
             lds_column.defer_a = ray_color, lds_column.defer_b = lerp(splat(1.0f), sf.color, sf.metalness);
+        } else if constexpr (SHADOW == RZ_SHADOW_NONE) {
+            // direct == 0: (0 * ray_color) * lerp(..) is +0 for the finite, non-negative colours a path carries, and final_color
+            // (+0 plus emission terms) is never -0, so the addition the lit variants perform leaves it unchanged
+            (void)direct;
         } else {
             final_color = final_color + (direct * ray_color) * lerp(splat(1.0f), sf.color, sf.metalness);
         }
@@ -403,7 +407,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene
 // pixel is written on the way out.  Per pixel the arithmetic is that of n_passes launches of the fused kernel: the
 // direction is re-normalised at the start of every segment as load_path does after reading it back, and the
 // accumulator grows by the same sequence of additions.
-template <bool COUNT, int MODE, bool LDS_SCENE>
+template <bool COUNT, int MODE, bool LDS_SCENE, bool NOLIGHTS>
 __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_batch_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f,
                                                                       uint32_t n_passes, uint32_t park_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
@@ -444,7 +448,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_batch_kernel(const DScen
         if (p.active) {
             col4 final_color;
             bool path_continues;
-            shade_segment<COUNT>(s, cam, cfg, p, ps, pass0 + i, found, hit, ShadowCtx{lds_column, TopCache{nullptr, nullptr, 0u}}, cnt, final_color, path_continues);
+            shade_segment<COUNT, NOLIGHTS ? RZ_SHADOW_NONE : 1>(s, cam, cfg, p, ps, pass0 + i, found, hit, ShadowCtx{lds_column, TopCache{nullptr, nullptr, 0u}}, cnt, final_color, path_continues);
             park[4 * 256] = __float_as_uint(__uint_as_float(park[4 * 256]) + final_color.r);
             park[5 * 256] = __float_as_uint(__uint_as_float(park[5 * 256]) + final_color.g);
             park[6 * 256] = __float_as_uint(__uint_as_float(park[6 * 256]) + final_color.b);
@@ -1265,6 +1269,7 @@ struct hiprz_ctx {
     DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
     int coop_walk = 1;    // front-to-back walk with the cooperative triangle phase (rz_trace_coop_kernel); HIPRZ_COOP=0: rz_trace_skip_kernel
     int coop_shadow = 1;  // deferred shadow rays in rz_shadow_coop_kernel (HIPRZ_COOP_SHADOW=0: rz_shadow_kernel)
+    int nolight_kernels = 1;  // scenes without lights use the instantiations without next-event estimation (HIPRZ_NOLIGHT_KERNELS=0: the general ones)
     int sort_bits = 0;    // most significant key bits the radix sorts look at; 0 = by frame size (HIPRZ_SORT_BITS)
     int shadow_sort = 1;  // HIPRZ_SHADOW_SORT=0: the shadow kernel follows the next pass's ray order instead
     DeviceArray<uint8_t> sort_temp;
@@ -1570,7 +1575,10 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
         // shadow rays: LDS-stack walk on a staged scene, skip-link walk with staged tree tops otherwise (no lights: no walk at all)
         const bool lights = c->dscene.n_spot_lights + c->dscene.n_direct_lights != 0u;
         const uint32_t shade_top = std::min<uint32_t>(c->dscene.top_count, kTopCacheNodes);
-        if (lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, 1>), grid, block, blob + stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        if (!lights && c->nolight_kernels) {  // no next-event estimation: the instantiation without it (no shadow walk, no LDS stack)
+            if (lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_NONE>), grid, block, blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+            else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_NONE>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        } else if (lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, 1>), grid, block, blob + stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
         else if (lights && defer_shadows(c)) {
             // shading without shadow walks, then every shadow ray of the pass in a lean single-wave kernel
             hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
@@ -1617,13 +1625,21 @@ void launch_batch(hiprz_ctx* c, const DFrame& f, uint32_t n, hipEvent_t before =
     const size_t lds = blob + walk_lds + park;
     const uint32_t park_offset = uint32_t(walk_lds);
     if (before) (void)hipEventRecord(before, c->stream);
+    // scenes without lights run the instantiation whose next-event-estimation code is compiled out (RZ_SHADOW_NONE)
+    const bool dark = c->dscene.n_spot_lights + c->dscene.n_direct_lights == 0u && c->nolight_kernels;
+#define RZ_BATCH(M, L)                                                                                                                     \
+    do {                                                                                                                                   \
+        if (dark) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, true>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
+        else hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, false>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);     \
+    } while (0)
     if (mode == 2) {
-        if (lds_scene) hipLaunchKernelGGL((rz_batch_kernel<COUNT, 2, true>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);
-        else hipLaunchKernelGGL((rz_batch_kernel<COUNT, 2, false>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);
+        if (lds_scene) RZ_BATCH(2, true);
+        else RZ_BATCH(2, false);
     } else {
-        if (lds_scene) hipLaunchKernelGGL((rz_batch_kernel<COUNT, 1, true>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);
-        else hipLaunchKernelGGL((rz_batch_kernel<COUNT, 1, false>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);
+        if (lds_scene) RZ_BATCH(1, true);
+        else RZ_BATCH(1, false);
     }
+#undef RZ_BATCH
     if (after) (void)hipEventRecord(after, c->stream);
     hipLaunchKernelGGL(rz_pass_add_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr, n);
     c->rgba8_valid = true;
@@ -2090,6 +2106,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     if (const char* w = std::getenv("HIPRZ_DEFER_SHADOWS")) c->defer_shadow_rays = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_COOP")) c->coop_walk = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_COOP_SHADOW")) c->coop_shadow = std::atoi(w) != 0;
+    if (const char* w = std::getenv("HIPRZ_NOLIGHT_KERNELS")) c->nolight_kernels = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SORT_BITS")) c->sort_bits = std::min(24, std::max(0, std::atoi(w)));
     if (const char* w = std::getenv("HIPRZ_SHADOW_SORT")) c->shadow_sort = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SHADOW_WALK")) c->shade_shadow_walk = std::atoi(w) == 1 ? 1 : 3;

@@ -1683,6 +1683,9 @@ RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit
 // MODE 4 ("defer"): no walk here — the sample's shadow ray and its unshadowed radiance term are written out for
 // rz_shadow_kernel, which walks the rays of all pixels in a lean kernel of its own and finishes the sums in this order.
 #define RZ_SHADOW_DEFER 4
+// MODE 5 ("none"): instantiation for scenes WITHOUT lights — directIllumination returns 0 there before it evaluates anything
+// (cpu_engine_kernel.cpp:703, :758), so the whole next-event-estimation code (and its registers) is compiled out.
+#define RZ_SHADOW_NONE 5
 struct ShadowCtx {
     uint32_t* lds_column;
     TopCache top;
@@ -1992,6 +1995,7 @@ RZ_DEV void defer_sample(const ShadowCtx& sc, uint32_t slot, const Ray& sr, col4
 template <int MODE, bool COUNT>
 RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const ShadowCtx& lds_column, v3 ray_d, uint32_t ray_material,
                                 v3 point, v3 next_dir, const Surface& sf, Rng& rng, Counters& cnt) {
+    if constexpr (MODE == RZ_SHADOW_NONE) return splat(0.0f);
     if (s.n_direct_lights == 0u && s.n_spot_lights == 0u) return splat(0.0f);  // both samplers return 0 before they read vS_pdf (:703, :758)
     const float vS_pdf = brdf(ray_d, sf, next_dir);
     col4 direct_total = splat(0.0f);
