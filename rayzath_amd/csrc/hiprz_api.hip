@@ -243,12 +243,13 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
     sf.fresnel = 1.0f, sf.reflectance = 0.0f, sf.tint_factor = 0.0f, sf.refr_x = sf.refr_y = 0.0f;
     sf.metalness = sf.roughness = 0.0f;
 
+    constexpr bool TEX = SHADOW != RZ_SHADOW_PLAIN;  // PLAIN: the scene has no maps at all (every map index is -1)
     Material m;
     if (found == 2) {
-        analyze_intersection<COUNT>(s, hit, sf, m, cnt);
+        analyze_intersection<COUNT, TEX>(s, hit, sf, m, cnt);
     } else {
         m = load_material(s, HIPRZ_MATERIAL_WORLD);
-        if (found == 1) {  // texcrd of the sky sphere (cpu_engine_kernel.cpp:292-295)
+        if (TEX && found == 1) {  // texcrd of the sky sphere (cpu_engine_kernel.cpp:292-295); only a map reads it
             sf.u = -(0.5f + (RZ_ATAN2F(ray.d.z, ray.d.x) / (RZ_PI_F * 2.0f)));
             sf.v = 0.5f + (RZ_ASINF(ray.d.y) / RZ_PI_F);
         }
@@ -256,9 +257,9 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
     sf.surface_scattering = m.scattering;
     // fetchColor / fetchEmission (:505-512, 523-528)
     sf.color = from_u8(m.color);
-    if (m.texture >= 0) sf.color = fetch_rgba8<COUNT>(s, m.texture, sf.u, sf.v, cnt);
+    if (TEX && m.texture >= 0) sf.color = fetch_rgba8<COUNT>(s, m.texture, sf.u, sf.v, cnt);
     sf.color.a = 1.0f - sf.color.a;
-    sf.emission = m.emission_map >= 0 ? fetch_r32f<COUNT>(s, m.emission_map, sf.u, sf.v, cnt) : m.emission;
+    sf.emission = TEX && m.emission_map >= 0 ? fetch_r32f<COUNT>(s, m.emission_map, sf.u, sf.v, cnt) : m.emission;
     if (sf.emission > 0.0f) final_color = final_color + (ray_color * sf.color) * sf.emission;
 
     v3 point = V3(0.0f, 0.0f, 0.0f), next_direction = V3(0.0f, 0.0f, 0.0f);
@@ -267,8 +268,8 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
     } else {
         RZ_COUNT(hits);
         depth += 1u;
-        sf.metalness = m.metalness_map >= 0 ? fetch_r8<COUNT>(s, m.metalness_map, sf.u, sf.v, cnt) : m.metalness;
-        sf.roughness = m.roughness_map >= 0 ? fetch_r8<COUNT>(s, m.roughness_map, sf.u, sf.v, cnt) : m.roughness;
+        sf.metalness = TEX && m.metalness_map >= 0 ? fetch_r8<COUNT>(s, m.metalness_map, sf.u, sf.v, cnt) : m.metalness;
+        sf.roughness = TEX && m.roughness_map >= 0 ? fetch_r8<COUNT>(s, m.roughness_map, sf.u, sf.v, cnt) : m.roughness;
         sf.fresnel = fresnel_specular_ratio(sf.mapped_normal, ray.d, material_ior(s, ray_material), material_ior(s, sf.behind_material),
                                             sf.refr_x, sf.refr_y);
         sf.reflectance = lerpf(sf.fresnel, 1.0f, sf.metalness);
@@ -280,7 +281,7 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
         if constexpr (SHADOW == RZ_SHADOW_DEFER) {  // rz_shadow_kernel adds (direct * a) * b once it knows the shadow masks
             lds_column.defer_done = true;
             lds_column.defer_a = ray_color, lds_column.defer_b = lerp(splat(1.0f), sf.color, sf.metalness);
-        } else if constexpr (SHADOW == RZ_SHADOW_NONE) {
+        } else if constexpr (SHADOW == RZ_SHADOW_NONE || SHADOW == RZ_SHADOW_PLAIN) {
             // direct == 0: (0 * ray_color) * lerp(..) is +0 for the finite, non-negative colours a path carries, and final_color
             // (+0 plus emission terms) is never -0, so the addition the lit variants perform leaves it unchanged
             (void)direct;
@@ -407,7 +408,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene
 // pixel is written on the way out.  Per pixel the arithmetic is that of n_passes launches of the fused kernel: the
 // direction is re-normalised at the start of every segment as load_path does after reading it back, and the
 // accumulator grows by the same sequence of additions.
-template <bool COUNT, int MODE, bool LDS_SCENE, bool NOLIGHTS>
+template <bool COUNT, int MODE, bool LDS_SCENE, int SHADING>  // SHADING: 1 general, RZ_SHADOW_NONE (no lights), RZ_SHADOW_PLAIN (no lights, no maps)
 __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_batch_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f,
                                                                       uint32_t n_passes, uint32_t park_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
@@ -448,7 +449,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_batch_kernel(const DScen
         if (p.active) {
             col4 final_color;
             bool path_continues;
-            shade_segment<COUNT, NOLIGHTS ? RZ_SHADOW_NONE : 1>(s, cam, cfg, p, ps, pass0 + i, found, hit, ShadowCtx{lds_column, TopCache{nullptr, nullptr, 0u}}, cnt, final_color, path_continues);
+            shade_segment<COUNT, SHADING>(s, cam, cfg, p, ps, pass0 + i, found, hit, ShadowCtx{lds_column, TopCache{nullptr, nullptr, 0u}}, cnt, final_color, path_continues);
             park[4 * 256] = __float_as_uint(__uint_as_float(park[4 * 256]) + final_color.r);
             park[5 * 256] = __float_as_uint(__uint_as_float(park[5 * 256]) + final_color.g);
             park[6 * 256] = __float_as_uint(__uint_as_float(park[6 * 256]) + final_color.b);
@@ -1269,6 +1270,7 @@ struct hiprz_ctx {
     DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
     int coop_walk = 1;    // front-to-back walk with the cooperative triangle phase (rz_trace_coop_kernel); HIPRZ_COOP=0: rz_trace_skip_kernel
     int coop_shadow = 1;  // deferred shadow rays in rz_shadow_coop_kernel (HIPRZ_COOP_SHADOW=0: rz_shadow_kernel)
+    uint32_t n_textures = 0;  // of the uploaded scene
     int nolight_kernels = 1;  // scenes without lights use the instantiations without next-event estimation (HIPRZ_NOLIGHT_KERNELS=0: the general ones)
     int sort_bits = 0;    // most significant key bits the radix sorts look at; 0 = by frame size (HIPRZ_SORT_BITS)
     int shadow_sort = 1;  // HIPRZ_SHADOW_SORT=0: the shadow kernel follows the next pass's ray order instead
@@ -1575,7 +1577,10 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
         // shadow rays: LDS-stack walk on a staged scene, skip-link walk with staged tree tops otherwise (no lights: no walk at all)
         const bool lights = c->dscene.n_spot_lights + c->dscene.n_direct_lights != 0u;
         const uint32_t shade_top = std::min<uint32_t>(c->dscene.top_count, kTopCacheNodes);
-        if (!lights && c->nolight_kernels) {  // no next-event estimation: the instantiation without it (no shadow walk, no LDS stack)
+        if (!lights && c->nolight_kernels && c->n_textures == 0u) {  // no lights, no maps
+            if (lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_PLAIN>), grid, block, blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+            else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_PLAIN>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        } else if (!lights && c->nolight_kernels) {  // no next-event estimation: the instantiation without it (no shadow walk, no LDS stack)
             if (lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_NONE>), grid, block, blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
             else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_NONE>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
         } else if (lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, 1>), grid, block, blob + stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
@@ -1625,12 +1630,15 @@ void launch_batch(hiprz_ctx* c, const DFrame& f, uint32_t n, hipEvent_t before =
     const size_t lds = blob + walk_lds + park;
     const uint32_t park_offset = uint32_t(walk_lds);
     if (before) (void)hipEventRecord(before, c->stream);
-    // scenes without lights run the instantiation whose next-event-estimation code is compiled out (RZ_SHADOW_NONE)
+    // scenes without lights run the instantiation whose next-event-estimation code is compiled out (RZ_SHADOW_NONE), scenes that
+    // have no maps either the one without texture fetches and normal mapping (RZ_SHADOW_PLAIN)
     const bool dark = c->dscene.n_spot_lights + c->dscene.n_direct_lights == 0u && c->nolight_kernels;
+    const bool plain = dark && c->n_textures == 0u;
 #define RZ_BATCH(M, L)                                                                                                                     \
     do {                                                                                                                                   \
-        if (dark) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, true>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
-        else hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, false>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);     \
+        if (plain) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_PLAIN>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
+        else if (dark) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_NONE>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
+        else hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, 1>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);     \
     } while (0)
     if (mode == 2) {
         if (lds_scene) RZ_BATCH(2, true);
@@ -2270,6 +2278,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     d.top_count = std::min<uint32_t>(sc->n_nodes, kTopCacheNodes);
     d.nodes64 = reinterpret_cast<const float4*>(c->nodes64.ptr);
     c->n_nodes = sc->n_nodes;
+    c->n_textures = sc->n_textures;
     // mesh walk rounds of at most 4 node steps and 8 triangles per lane (measured: D 3 163 -> 2 891 us, C 935 -> 892 us)
     d.walk_k = 4u, d.walk_l = 8u;
     // ray reordering key: without lights only the closest-hit walk follows the sorted order and the interleaved origin/direction

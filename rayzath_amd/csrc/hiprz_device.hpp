@@ -1686,6 +1686,9 @@ RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit
 // MODE 5 ("none"): instantiation for scenes WITHOUT lights — directIllumination returns 0 there before it evaluates anything
 // (cpu_engine_kernel.cpp:703, :758), so the whole next-event-estimation code (and its registers) is compiled out.
 #define RZ_SHADOW_NONE 5
+// MODE 6 ("plain"): no lights AND no maps of any kind in the scene — texture fetches, normal mapping and the sky's texture
+// coordinates are compiled out as well.
+#define RZ_SHADOW_PLAIN 6
 struct ShadowCtx {
     uint32_t* lds_column;
     TopCache top;
@@ -1787,7 +1790,7 @@ struct Surface {
 };
 
 // analyzeIntersection: cpu_engine_kernel.cpp:354-395; mesh_component.cpp:115-167
-template <bool COUNT>
+template <bool COUNT, bool TEX = true>
 RZ_DEV void analyze_intersection(const DScene& s, const Hit& hit, Surface& sf, Material& m, Counters& cnt) {
     const uint32_t inst = uint32_t(hit.instance);
     const float4 i1 = s.instances[7 * inst + 1], i2 = s.instances[7 * inst + 2],
@@ -1823,7 +1826,7 @@ RZ_DEV void analyze_intersection(const DScene& s, const Hit& hit, Surface& sf, M
     } else {
         sf.mapped_normal = face_normal;
     }
-    if (m.normal_map >= 0 && has_texcrds) {  // Triangle::mapNormal, mesh_component.cpp:132-167
+    if (TEX && m.normal_map >= 0 && has_texcrds) {  // Triangle::mapNormal, mesh_component.cpp:132-167
         const col4 map_color = fetch_rgba8<COUNT>(s, m.normal_map, sf.u, sf.v, cnt);
         // v2 and v3 ride in the padding of the device attribute record (the triangle record holds edges)
         const v3 v1 = xyz(ta), v2 = V3(at[0].w, at[1].w, at[2].w), vv3 = V3(at[3].w, uv3.z, uv3.w);
@@ -1995,7 +1998,7 @@ RZ_DEV void defer_sample(const ShadowCtx& sc, uint32_t slot, const Ray& sr, col4
 template <int MODE, bool COUNT>
 RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const ShadowCtx& lds_column, v3 ray_d, uint32_t ray_material,
                                 v3 point, v3 next_dir, const Surface& sf, Rng& rng, Counters& cnt) {
-    if constexpr (MODE == RZ_SHADOW_NONE) return splat(0.0f);
+    if constexpr (MODE == RZ_SHADOW_NONE || MODE == RZ_SHADOW_PLAIN) return splat(0.0f);
     if (s.n_direct_lights == 0u && s.n_spot_lights == 0u) return splat(0.0f);  // both samplers return 0 before they read vS_pdf (:703, :758)
     const float vS_pdf = brdf(ray_d, sf, next_dir);
     col4 direct_total = splat(0.0f);
