@@ -532,3 +532,31 @@ def test_cooperative_triangle_phase_equals_the_per_lane_walk(built, monkeypatch)
             assert np.array_equal(out[0][0], out[other][0]) and np.array_equal(out[0][1], out[other][1])
             for k in out[0][2]:
                 assert np.array_equal(out[0][2][k], out[other][2][k]), k
+
+
+def test_scene_specialised_shading_equals_the_general_code(built, monkeypatch):
+    """Scenes without lights (and without maps) run instantiations whose next-event estimation (texture fetches, normal mapping) is
+    compiled out — RZ_SHADOW_NONE / RZ_SHADOW_PLAIN.  Frames, path state and counters equal the general instantiation's bit for bit,
+    in the resident, split and fused pipelines."""
+    cases = ((scenes.cornell_box(96, 64), None), (scenes.cornell_sphere(96, 64, resolution=24), 3),
+             (scenes.textured_sphere_scene(96, 64, resolution=24, map_size=32), 3))       # plain LDS scene, plain global scene, no lights but maps
+    for world, mode in cases:
+        flat, cam = flatten(world), camera_struct(world.camera)
+        cfg = RenderConfig(LightSampling(1, 1), Tracing(6, 4)).struct()
+        for pipeline in (0, 1, 2):
+            out = []
+            for special in ("0", "1"):
+                monkeypatch.setenv("HIPRZ_NOLIGHT_KERNELS", special)
+                c = Context(0)
+                if mode is not None:
+                    c.set_traversal_mode(mode), c.set_lds_scene(0)
+                c.set_pipeline(pipeline)
+                c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+                counters = c.render_counted(2)
+                c.render(6), c.render(4)
+                c.tonemap()
+                out.append((c.read_accum(), c.read_depth(), c.read_state(), counters, c.read_rgba8(), c.pipeline()))
+            assert out[0][3] == out[1][3] and out[0][5] == out[1][5]
+            assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][4], out[1][4])
+            for k in out[0][2]:
+                assert np.array_equal(out[0][2][k], out[1][2][k]), k
