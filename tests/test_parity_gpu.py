@@ -560,3 +560,45 @@ def test_scene_specialised_shading_equals_the_general_code(built, monkeypatch):
             assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][4], out[1][4])
             for k in out[0][2]:
                 assert np.array_equal(out[0][2][k], out[1][2][k]), k
+
+
+def test_exact_ties_pick_the_triangle_the_reference_meets_first(built, monkeypatch):
+    """A mesh whose every triangle exists twice (the copy with ANOTHER material, shuffled in among the originals) and an instance that
+    exists twice in the same place: every hit is an exact tie, inside a leaf, across leaves and across instances.  The reference keeps
+    the triangle it meets first (`t >= far` rejects the later one), so the material a pixel sees tells which one won.  Front to back,
+    cooperative and per-lane walks must agree with the reference-order walk — and all of them with the CPU oracle — on every pixel."""
+    from rayzath_amd.scene import Instance, Material, Mesh, generate_sphere
+    rng = np.random.default_rng(11)
+    base = generate_sphere(20, normals=False, texture_coordinates=False)
+    T = len(base.tri_vertices)
+    order = rng.permutation(2 * T)
+    tri_vertices = np.concatenate([base.tri_vertices, base.tri_vertices])[order]
+    tri_materials = np.concatenate([np.zeros(T), np.ones(T)]).astype(np.uint32)[order]
+    twin = Mesh(base.vertices, tri_vertices, tri_materials=tri_materials)
+    world = scenes.cornell_box(160, 100)
+    red, blue = world.add(Material((220, 40, 40, 255), 0.0, 1.0)), world.add(Material((40, 40, 220, 255), 0.3, 0.2))
+    twin = world.add(twin)
+    for _ in range(2):   # the same instance twice: ties across instances (the world tree keeps the reference's order in every variant)
+        world.add(Instance(twin, [red, blue], position=(0.2, 0.6, 0.1), rotation=(0.3, 0.5, 0.1), scale=(1.3, 1.3, 1.3)))
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(LightSampling(1, 1), Tracing(6, 4)).struct()
+    ref = oracle.OracleRenderer(flat, cam, cfg)
+    ref.render(6)
+    out = []
+    for order_, coop in ((0, "1"), (1, "0"), (1, "1")):
+        monkeypatch.setenv("HIPRZ_COOP", coop)
+        c = Context(0)
+        c.set_traversal_mode(3), c.set_lds_scene(0), c.set_walk_order(order_)
+        c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+        c.render(6)
+        out.append((c.read_accum(), c.read_depth(), c.read_state()))
+    for other in out[1:]:
+        assert np.array_equal(out[0][0], other[0]) and np.array_equal(out[0][1], other[1])
+        for k in out[0][2]:
+            assert np.array_equal(out[0][2][k], other[2][k]), k
+    assert np.array_equal(out[0][1], ref.depth)
+    assert np.array_equal(out[0][2]["material"], ref.state["material"]) and np.array_equal(out[0][0][..., 3], ref.accum[..., 3])
+    assert _close(out[0][0][..., :3], ref.accum[..., :3]).all(-1).mean() >= 1 - FRACTION
+    # both copies win somewhere (the shuffle decides which comes first in a leaf): red-diffuse and blue-glossy pixels are in the picture
+    rgb = ref.accum[..., :3]
+    assert (rgb[..., 0] > 3 * rgb[..., 2]).sum() > 30 and (rgb[..., 2] > 1.5 * rgb[..., 0]).sum() > 30
