@@ -156,6 +156,8 @@ def main():
             import numpy as np
             assert np.array_equal(img.cpu().numpy(), ref.read_accum()), "gathered frame differs from the unsharded frame"
             ref.close()
+        total_rays = frame.ray_count()  # all-reduce over the ranks (every rank calls it)
+        assert total_rays == (1 + RPP) * W * H, f"ray counters of the shards add up to {total_rays}, not {(1 + RPP) * W * H}"
     for _ in range(args.warmup):
         step()
     fence()

@@ -54,6 +54,17 @@ def gather_tiles(local_tiles, rank, world, capacity_max, dist, dst=0):
     return gather_list
 
 
+def total_ray_count(local_rays, dist, device=None):
+    """Sum of the ranks' ray counters (Camera::rayCount of the whole frame): one all-reduce of a 64-bit integer — SURVEY.md §8e.
+    Works with any backend (nccl: pass the rank's cuda device; gloo: CPU tensor)."""
+    import torch
+
+    t = torch.tensor([int(local_rays)], dtype=torch.int64, device=device)
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
 class ShardedFrame:
     """Rank-local driver: renders the owned tiles and assembles full frames on rank 0.
 
@@ -116,6 +127,11 @@ class ShardedFrame:
             return
         stream = self.comm.cuda_stream if self.comm is not None and self.comm is not self.stream else None
         ctx.untile_gathered(gathered.data_ptr(), self.world, self.capacity_max * element_bytes, element_bytes, image.data_ptr(), stream)
+
+    def ray_count(self):
+        """Rays traced by ALL shards since the last reset (each context counts its own pixels)."""
+        on_gpu = self.device is not None and self.device.type == "cuda" and self.dist is not None and self.dist.get_backend() != "gloo"
+        return total_ray_count(self.ctx.ray_count(), self.dist if self.world > 1 else None, self.device if on_gpu else None)
 
     def sync(self):
         """Wait until every enqueued frame has been rendered and (rank 0) assembled."""

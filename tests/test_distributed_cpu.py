@@ -56,6 +56,9 @@ def _worker(rank, world, port, W, H, out_path):
     vals = np.stack([x, y, x * 0 + rank, y * W + x], axis=-1).astype(np.float32)
     local[: len(x)][torch.from_numpy(inside)] = torch.from_numpy(vals[inside])
     parts = gather_tiles(local, rank, world, cap, dist)
+    from rayzath_amd.distributed import total_ray_count
+    owned = int(inside.sum())
+    assert total_ray_count(7 * owned, dist) == 7 * W * H     # every pixel is owned by exactly one rank
     if rank == 0:
         image = np.full((H, W, 4), -1, np.float32)
         for r, part in enumerate(parts):
