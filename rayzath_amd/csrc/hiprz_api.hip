@@ -386,7 +386,8 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene
     Hit hit;
     int found;
     if constexpr (MODE == 2) {  // what the walk does not read is parked in LDS meanwhile
-        uint32_t* park = reinterpret_cast<uint32_t*>(workspace + 15u * 1024u);
+        // 4 KiB behind the binned walk's workspace (launch_pass adds them to the fused kernel's LDS size)
+        uint32_t* park = reinterpret_cast<uint32_t*>(workspace + BinnedLds::kFixedBytes + (s.world_stack_entries + s.mesh_stack_entries) * 1024u);
         park[0 * 256 + threadIdx.x] = __float_as_uint(ps.color.r), park[1 * 256 + threadIdx.x] = __float_as_uint(ps.color.g);
         park[2 * 256 + threadIdx.x] = __float_as_uint(ps.color.b), park[3 * 256 + threadIdx.x] = ps.material | (ps.depth << 16);
         found = trace_path<MODE, COUNT, RZ_FUSED_SHARED_RCP != 0>(s, workspace, lds_column, p.active, ps.ray, hit, cnt);
@@ -408,8 +409,12 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene
 // pixel is written on the way out.  Per pixel the arithmetic is that of n_passes launches of the fused kernel: the
 // direction is re-normalised at the start of every segment as load_path does after reading it back, and the
 // accumulator grows by the same sequence of additions.
-template <bool COUNT, int MODE, bool LDS_SCENE, int SHADING>  // SHADING: 1 general, RZ_SHADOW_NONE (no lights), RZ_SHADOW_PLAIN (no lights, no maps)
-__global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_batch_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f,
+// WAVES = waves per SIMD the register budget is cut for.  With 29 KB of LDS per workgroup (a Cornell-sized scene) five workgroups
+// fit a CU, and when the grid oversubscribes the chip the 5-wave build of the plain instantiation wins although it spills more
+// (96 VGPRs, 148 B of scratch: whole 1080p frame 2.15 -> 2.04 ms per step); a grid that fits the chip at once — an eighth of the
+// frame on each of 8 GPUs — runs faster on the 4-wave build (0.326 against 0.350 ms), so launch_batch picks by grid size.
+template <bool COUNT, int MODE, bool LDS_SCENE, int SHADING, int WAVES = RZ_MIN_WAVES>  // SHADING: 1 general, RZ_SHADOW_NONE (no lights), RZ_SHADOW_PLAIN (no lights, no maps)
+__global__ void __launch_bounds__(256, WAVES) rz_batch_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f,
                                                                       uint32_t n_passes, uint32_t park_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
     DScene s = scene_in;
@@ -1271,6 +1276,7 @@ struct hiprz_ctx {
     int coop_walk = 1;    // front-to-back walk with the cooperative triangle phase (rz_trace_coop_kernel); HIPRZ_COOP=0: rz_trace_skip_kernel
     int coop_shadow = 1;  // deferred shadow rays in rz_shadow_coop_kernel (HIPRZ_COOP_SHADOW=0: rz_shadow_kernel)
     uint32_t n_textures = 0;  // of the uploaded scene
+    int batch_waves = 0;  // HIPRZ_BATCH_WAVES=4: never the 5-wave build of the plain batch kernel
     int nolight_kernels = 1;  // scenes without lights use the instantiations without next-event estimation (HIPRZ_NOLIGHT_KERNELS=0: the general ones)
     int sort_bits = 0;    // most significant key bits the radix sorts look at; 0 = by frame size (HIPRZ_SORT_BITS)
     int shadow_sort = 1;  // HIPRZ_SHADOW_SORT=0: the shadow kernel follows the next pass's ray order instead
@@ -1607,7 +1613,7 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_sha
         else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, 1>), grid, block, stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
     } else {
         // the fused kernel's shadow rays use the stack walk: its columns must exist in every mode
-        const size_t fused_lds = mode == 0 ? stack_lds : walk_lds;
+        const size_t fused_lds = mode == 0 ? stack_lds : mode == 2 ? walk_lds + 4096u : walk_lds;  // mode 2: + the parked path state
         if (mode == 2) RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 2, true>), (rz_pass_kernel<FIRST, COUNT, 2, false>), fused_lds, c->dscene, c->dcamera, cfg, f);
         else if (mode == 1) RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 1, true>), (rz_pass_kernel<FIRST, COUNT, 1, false>), fused_lds, c->dscene, c->dcamera, cfg, f);
         else RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 0, true>), (rz_pass_kernel<FIRST, COUNT, 0, false>), fused_lds, c->dscene, c->dcamera, cfg, f);
@@ -1634,9 +1640,12 @@ void launch_batch(hiprz_ctx* c, const DFrame& f, uint32_t n, hipEvent_t before =
     // have no maps either the one without texture fetches and normal mapping (RZ_SHADOW_PLAIN)
     const bool dark = c->dscene.n_spot_lights + c->dscene.n_direct_lights == 0u && c->nolight_kernels;
     const bool plain = dark && c->n_textures == 0u;
+    // 5 workgroups per CU must fit LDS, and the grid must be more than two full loads of the chip (256 CUs x 5)
+    const bool five = lds * 5u <= 160u * 1024u && grid.x > 2u * 5u * 256u && c->batch_waves != 4;
 #define RZ_BATCH(M, L)                                                                                                                     \
     do {                                                                                                                                   \
-        if (plain) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_PLAIN>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
+        if (plain && five) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_PLAIN, 5>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
+        else if (plain) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_PLAIN>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
         else if (dark) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_NONE>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
         else hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, 1>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);     \
     } while (0)
@@ -2114,6 +2123,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     if (const char* w = std::getenv("HIPRZ_DEFER_SHADOWS")) c->defer_shadow_rays = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_COOP")) c->coop_walk = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_COOP_SHADOW")) c->coop_shadow = std::atoi(w) != 0;
+    if (const char* w = std::getenv("HIPRZ_BATCH_WAVES")) c->batch_waves = std::atoi(w);
     if (const char* w = std::getenv("HIPRZ_NOLIGHT_KERNELS")) c->nolight_kernels = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SORT_BITS")) c->sort_bits = std::min(24, std::max(0, std::atoi(w)));
     if (const char* w = std::getenv("HIPRZ_SHADOW_SORT")) c->shadow_sort = std::atoi(w) != 0;

@@ -810,9 +810,8 @@ struct BinnedLds {  // per-workgroup workspace carved from dynamic LDS (256 lane
     uint32_t* hit;      // [5][256]  triangle, external, b1, b2, instance
     uint32_t* items;    // [256]     instance << 8 | source lane
     uint32_t* bins;     // [2][64] per-instance item counts, double-buffered by round
-    uint32_t* park;     // [4][256]  values the walk does not need (kept out of registers while it runs)
     uint32_t* stacks;   // [(world + mesh entries)][256] level-major stack columns
-    static constexpr uint32_t kFixedBytes = 19u * 1024u;
+    static constexpr uint32_t kFixedBytes = 15u * 1024u;
     static __host__ uint32_t bytes_host(uint32_t world_entries, uint32_t mesh_entries) {
         return kFixedBytes + (world_entries + mesh_entries) * 1024u;
     }
@@ -821,7 +820,6 @@ struct BinnedLds {  // per-workgroup workspace carved from dynamic LDS (256 lane
         hit = reinterpret_cast<uint32_t*>(base + 8u * 1024u);
         items = reinterpret_cast<uint32_t*>(base + 13u * 1024u);
         bins = reinterpret_cast<uint32_t*>(base + 14u * 1024u);
-        park = reinterpret_cast<uint32_t*>(base + 15u * 1024u);
         stacks = reinterpret_cast<uint32_t*>(base + kFixedBytes);
     }
 };
