@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <filesystem>
 #include <fstream>
 #include <sstream>
 
@@ -186,6 +187,11 @@ int run(const std::string& task_file, std::string report_dir, bool save_images, 
     try {
         if (report_dir.empty()) report_dir = parent_dir(task_file);
         if (!report_dir.empty() && report_dir.back() != '/') report_dir.push_back('/');
+        if (!report_dir.empty()) {  // the reference creates benchmark_<date>_<time>/ inside an existing directory (headless.cpp:35-41); here the
+            std::error_code ec;     // directory named on the command line is the report directory itself and is created when missing
+            std::filesystem::create_directories(report_dir, ec);
+            if (ec) throw Exception(HIPRZ_ERR_INVALID, "cannot create the report directory " + report_dir);
+        }
         if (!quiet) std::printf("Reading config file: \"%s\"\n", task_file.c_str());
         const auto tasks = prepareTasks(task_file);
         std::vector<TaskResult> results;

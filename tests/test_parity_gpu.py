@@ -434,8 +434,10 @@ def test_headless_runner_end_to_end(built, tmp_path):
     scene_io.save_scene_json(world, str(tmp_path / "cornell.json"))
     (tmp_path / "tasks.json").write_text('{"tasks": [{"scene path": "cornell.json", "engine": ["HIPGPU"], "rpp": 40, "timeout": 20.0, "max depth": 4}]}')
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rayzath_amd", "csrc", "hiprz_headless")
-    r = subprocess.run([exe, "--headless", str(tmp_path / "tasks.json"), str(tmp_path), "-r", "--quiet"], capture_output=True, text=True, timeout=300)
+    out_dir = tmp_path / "reports" / "run1"        # does not exist yet: the runner creates it
+    r = subprocess.run([exe, "--headless", str(tmp_path / "tasks.json"), str(out_dir), "-r", "--quiet"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
+    tmp_path = out_dir
     report = (tmp_path / "report.txt").read_text()
     m = re.fullmatch(r"Scene: cornell\.json\n\tengine: HIPGPU \| max depth: 4\n\tduration: \d+\.\d{3}s \| traced (\S+) rays \((\S+) rps\)\n", report)
     assert m, report
