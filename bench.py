@@ -69,9 +69,8 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="B", help="scene preset of rayzath_amd/scenes.py (B = the quoted config)")
-    ap.add_argument("--traversal", type=int, default=-1, help="-1 per-scene choice (default), 1 nested walk with LDS stack, 2 workgroup-binned, 0 threaded, 3 skip links (front to back, cooperative triangle phase), 4 persistent lanes, 5 = 3 in requeue rounds")
+    ap.add_argument("--traversal", type=int, default=-1, help="-1 per-scene choice (default), 1 nested walk with LDS stack, 2 workgroup-binned, 3 skip links (front to back, cooperative triangle phase)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather on the render stream instead of overlapping it with the next step's rendering")
-    ap.add_argument("--requeue", type=str, default="", help="mode 5 schedule: comma-separated lane thresholds per bailing round")
     ap.add_argument("--pipeline", type=int, default=-1, help="0 fused pass kernel, 1 trace + shade kernels, 2 resident batch kernel (-1: chosen per scene)")
     ap.add_argument("--ray-sort", type=int, default=-1, help="-1 auto, 0 off, 1 on")
     ap.add_argument("--walk-order", type=int, default=-1, help="mesh child order of the skip-link walk: 0 reference order, 1 front to back (-1: library default)")
@@ -114,8 +113,6 @@ def main():
 
     ctx = Context(local_rank)
     ctx.set_traversal_mode(args.traversal)
-    if args.requeue:
-        ctx.set_requeue_schedule([int(t) for t in args.requeue.split(",") if t != ""])
     if args.pipeline >= 0:
         ctx.set_pipeline(args.pipeline)
     ctx.set_ray_sort(args.ray_sort)
@@ -180,7 +177,6 @@ def main():
 
     kernel_ms, launches = ctx.kernel_time_ms()
     breakdown = ctx.kernel_breakdown_ms()  # trace / shade kernel times of the last timed step
-    requeue_counts = [c for c in ctx.requeue_counts()[1:] if c] if ctx.traversal_mode() == 5 else None
     ctx.time_kernels(False)
     rays = args.steps * RPP * W * H
     result = None
@@ -222,8 +218,8 @@ def main():
             # dominant kernel = the BVH-traversal kernel.  Its algorithmic bytes: the ray it reads (40 B of path state) and
             # the hit record it writes (20 B) per segment + 32 B per box test + 36 B per triangle test of the closest-hit
             # walk (shadow-ray tests run in the shade kernel and are not counted here).
-            mode3 = "rz_trace_coop_kernel" if (args.walk_order if args.walk_order >= 0 else 1) != 0 and os.environ.get("HIPRZ_COOP", "1") != "0" else "rz_trace_skip_kernel"
-            kernel_name = {3: mode3, 5: "rz_trace_requeue_kernel", 6: "rz_trace_pool_kernel"}.get(ctx.traversal_mode(), "rz_trace_kernel") + " (closest-hit walk)"
+            mode3 = "rz_trace_coop_kernel" if (args.walk_order if args.walk_order >= 0 else 1) != 0 else "rz_trace_skip_kernel"
+            kernel_name = {3: mode3}.get(ctx.traversal_mode(), "rz_trace_kernel") + " (closest-hit walk)"
             kernel_s = breakdown[0] / 1e3 / breakdown[2]
             kernel_bytes = (60 * counters["segments"] + 32 * (counters["box_tests"] - counters["shadow_box_tests"])
                             + 36 * (counters["tri_tests"] - counters["shadow_tri_tests"])) / RPP
@@ -254,8 +250,7 @@ def main():
             "config": {"workload": preset["note"], "resolution": [W, H], "max_depth": preset["max_depth"], "passes_per_step": RPP,
                        "triangles": int(len(flat.tris)), "instances": int(len(flat.instances)),
                        "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
-                       "requeued_rays_per_round": requeue_counts,
-                       "traversal": {0: "threaded", 1: "lds-stack", 2: "workgroup-binned", 3: "skip-links", 4: "persistent-lanes", 5: "skip-links+requeue-rounds", 6: "wave-pool"}[ctx.traversal_mode()],
+                       "traversal": {1: "lds-stack", 2: "workgroup-binned", 3: "skip-links"}[ctx.traversal_mode()],
                        "pipeline": {0: "fused (one kernel per pass)", 1: "trace+shade (two kernels per pass)", 2: "resident (one kernel per step)"}[pipeline]},
             "spp_per_s": spp_per_s,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,

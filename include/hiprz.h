@@ -264,15 +264,12 @@ int hiprz_set_config(hiprz_ctx* ctx, const hiprz_config* config);
  * unchanged, so results are identical for any world size).  Default rank 0 of 1. */
 int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
 
-/* Tree-walk variant of the pass kernel.  -1 (default) = chosen per scene; 1 = nested loops with a
- * per-lane stack in LDS; 2 = workgroup-binned (rays advance in rounds, the (ray, instance) visits of
- * a round are compacted and sorted by instance in LDS and processed by dense waves); 0 = threaded
- * (skip links + instance pseudo-nodes, no stack); 3 = nested walk on skip links, one wave per workgroup (see
- * hiprz_set_walk_order: front to back with a cooperative triangle phase by default; in the reference's child order with
- * the tree tops cached in LDS); 4 = persistent lanes (a workgroup owns a pool of rays, a lane that finishes its ray takes the next one)
- * on the flat walk graph with postponed leaves; 5 = the walk of 3 in rounds: a ray whose wave has run thin stops,
- * is queued (48 B of walk state) and resumed by the next round's kernel in a dense wave.  All visit the same boxes
- * and triangles in the same per-ray order and give identical results. */
+/* Tree-walk variant of the pass kernels.  -1 (default) = chosen per scene; 1 = nested loops with a per-lane stack in LDS;
+ * 2 = workgroup-binned (rays advance in rounds, the (ray, instance) visits of a round are compacted and sorted by instance
+ * in LDS and processed by dense waves; scenes staged in LDS); 3 = skip links, one wave per workgroup, for scenes that are not
+ * staged in LDS (see hiprz_set_walk_order: front to back with a cooperative triangle phase by default; in the reference's
+ * child order with the tree tops cached in LDS).  All reach the same hits and give identical results; 1, 2 and 3 in the
+ * reference's order also execute the same box / triangle tests in the same per-ray order. */
 int hiprz_set_traversal_mode(hiprz_ctx* ctx, int mode);
 /* Order in which the single-wave skip-link walk (mode 3) enters the two children of a MESH-tree node.  0 = the reference's
  * fixed order, first child then second (cpu_engine_kernel.cpp:331-352): box / triangle test counters equal the CPU kernel's.
@@ -284,15 +281,6 @@ int hiprz_set_traversal_mode(hiprz_ctx* ctx, int mode);
  * hiprz_render_counted() walks in the reference's order under 0 and 1, so its counters are the work of the reference's
  * algorithm (what the roofline's algorithmic bytes are made of); 2 = front to back there too: counters = tests executed. */
 int hiprz_set_walk_order(hiprz_ctx* ctx, int order);
-/* Mode 5 schedule: thresholds[r] (0..64) = lanes of a wave that must remain inside a mesh walk during round r for
- * it to go on; otherwise they are queued for round r+1.  After n_rounds (<= 30) rounds a final round finishes every ray. */
-int hiprz_set_requeue_schedule(hiprz_ctx* ctx, const uint32_t* thresholds, uint32_t n_rounds);
-/* Diagnostics: the split pipeline's trace kernel records the start and end time (100 MHz device clock) of each of its
- * workgroups; start_end_out[2*b], [2*b+1] = those of workgroup b in the most recent pass.  Enable after the camera upload. */
-int hiprz_set_workgroup_timing(hiprz_ctx* ctx, int enabled);
-int hiprz_read_workgroup_times(hiprz_ctx* ctx, uint64_t* start_end_out, uint32_t n_workgroups);
-/* Diagnostics: counts_out[r] = rays the most recent pass queued for round r (r >= 1; up to 32 entries). */
-int hiprz_requeue_counts(hiprz_ctx* ctx, uint32_t* counts_out, uint32_t n);
 int hiprz_traversal_mode(hiprz_ctx* ctx, int* effective_mode_out); /* valid after hiprz_upload_scene */
 
 /* Stage the scene's geometry + shading records into LDS in every workgroup (ds_read instead of

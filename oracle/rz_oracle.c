@@ -20,19 +20,7 @@
 #include <omp.h>
 #endif
 
-/* All transcendental calls go through these, so a build with -DRZ_PORTABLE_MATH can swap
- * libm for the bit-reproducible implementations shared with the device build. */
-#ifdef RZ_PORTABLE_MATH
-#include "../include/hiprz_portable_math.h"
-#define RZ_SINF(x) hiprz_pm_sinf(x)
-#define RZ_COSF(x) hiprz_pm_cosf(x)
-#define RZ_ACOSF(x) hiprz_pm_acosf(x)
-#define RZ_ASINF(x) hiprz_pm_asinf(x)
-#define RZ_ATAN2F(y, x) hiprz_pm_atan2f(y, x)
-#define RZ_POWF(x, y) hiprz_pm_powf(x, y)
-#define RZ_EXPF(x) hiprz_pm_expf(x)
-const char* rzo_math_mode(void) { return "portable"; }
-#else
+/* All transcendental calls go through these (glibc's libm on the CPU side; the device build uses ocml). */
 #define RZ_SINF(x) sinf(x)
 #define RZ_COSF(x) cosf(x)
 #define RZ_ACOSF(x) acosf(x)
@@ -41,7 +29,6 @@ const char* rzo_math_mode(void) { return "portable"; }
 #define RZ_POWF(x, y) powf(x, y)
 #define RZ_EXPF(x) expf(x)
 const char* rzo_math_mode(void) { return "libm"; }
-#endif
 
 #define RZ_PI 3.14159265358979323846f /* std::numbers::pi_v<float> */
 

@@ -110,10 +110,6 @@ ENTRY_POINTS = {
     "hiprz_set_shard": (C.c_int, [P, U32, U32]),
     "hiprz_set_traversal_mode": (C.c_int, [P, C.c_int]),
     "hiprz_set_walk_order": (C.c_int, [P, C.c_int]),
-    "hiprz_set_requeue_schedule": (C.c_int, [P, C.POINTER(C.c_uint32), C.c_uint32]),
-    "hiprz_set_workgroup_timing": (C.c_int, [P, C.c_int]),
-    "hiprz_read_workgroup_times": (C.c_int, [P, C.POINTER(C.c_uint64), C.c_uint32]),
-    "hiprz_requeue_counts": (C.c_int, [P, C.POINTER(C.c_uint32), C.c_uint32]),
     "hiprz_set_lds_scene": (C.c_int, [P, C.c_int]),
     "hiprz_set_pipeline": (C.c_int, [P, C.c_int]),
     "hiprz_traversal_mode": (C.c_int, [P, C.POINTER(C.c_int)]),

@@ -1,12 +1,11 @@
-// hiprz_api.hip — kernels + the device half of the C-ABI declared in include/hiprz.h.
+// hiprz_api.hip — the device half of the C-ABI declared in include/hiprz.h: context, scene mirroring, render calls, readback.
 //
-// Replaces, for the HIPGPU backend, what the reference's CUDA backend does in
-// cuda_engine_core.cu (host<->device mirroring, readback), cuda_engine_renderer.cu
-// (launch sequence) and cuda_render_kernel.cu / cuda_postprocess_kernel.cu (kernels).
-// Written for gfx950 only: wave64, 256-thread workgroups = one 32x8-pixel tile.
+// Replaces, for the HIPGPU backend, what the reference's CUDA backend does in cuda_engine_core.cu (host<->device
+// mirroring, readback), cuda_engine_renderer.cu (launch sequence) and cuda_postprocess_kernel.cu (tone map, pass update).
+// The pass kernels live in hiprz_kernels.hpp and are instantiated by hiprz_launch_*.hip.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -16,1005 +15,14 @@
 #include <vector>
 
 #include "hiprz.h"
+#include "hiprz_ctx.hpp"
 #include "hiprz_device.hpp"
 
 using namespace hiprz;
 
 // =======================================================================================
-// Kernels
+// Small kernels: pass index, tone map, tile <-> image, picking, self-test
 // =======================================================================================
-
-// One pass = one path segment per owned pixel: renderFirstPass (cpu_engine_kernel.cpp:15-57)
-// when FIRST, else renderCumulativePass (:58-101), with traceRay (:113-178) inlined.
-//
-// The pass is written as three pieces — load_path, the closest-hit walk, shade_and_store — used by two
-// pipelines that give identical results:
-//   fused  (rz_pass_kernel):   all three in one kernel; state + accumulator cross HBM once (112 B/pixel).
-//   split  (rz_trace_kernel -> rz_shade_kernel): the walk runs in its own lean kernel (ray + hit only: no
-//          register spills with the packed shared-reciprocal box test, higher occupancy) and hands a 20-B hit
-//          record per pixel to the shading kernel through HBM (+88 B/pixel of traffic).
-//
-// LDS_SCENE: the workgroup first stages the scene's hot blob (geometry + shading records) into LDS and
-// every traversal / shading fetch becomes a ds_read instead of a dependent global load.
-struct PathState {
-    Ray ray;
-    col4 color;
-    uint32_t material, depth;
-};
-
-template <bool LDS_SCENE>
-RZ_DEV uint32_t stage_scene(DScene& s, unsigned char* lds) {
-    if constexpr (LDS_SCENE) {
-        float4* dst = reinterpret_cast<float4*>(lds);
-        const uint32_t n16 = s.hot_bytes >> 4;
-        for (uint32_t i = threadIdx.x; i < n16; i += 256u) dst[i] = s.hot[i];
-        __syncthreads();
-        repoint_hot(s, lds);
-        return s.hot_bytes;
-    }
-    return 0u;
-}
-
-// the segment's ray: generateSimpleRay on the first pass, CameraContext::getRay afterwards
-template <bool FIRST>
-RZ_DEV void load_path(const DFrame& f, const DCamera& cam, const PixelId& p, PathState& ps) {
-    ps.color = splat(1.0f);
-    ps.material = HIPRZ_MATERIAL_WORLD, ps.depth = 0u;
-    ps.ray.o = ps.ray.d = V3(0.0f, 0.0f, 1.0f), ps.ray.near_ = 0.0f, ps.ray.far_ = 0.0f;
-    if (!p.active) return;
-    if constexpr (FIRST) {
-        generate_simple_ray(cam, ps.ray, p.x, p.y);
-    } else {
-        const float4 s0 = f.st0[p.local], s1 = f.st1[p.local];
-        const float2 s2 = f.st2[p.local];
-        const uint32_t bits = __float_as_uint(s2.y);
-        ps.ray.o = V3(s0.x, s0.y, s0.z);
-        ps.ray.d = normalized(V3(s0.w, s1.x, s1.y));  // SceneRay ctor normalises (cpu_render_utils.hpp:41-46)
-        ps.ray.near_ = 0.0f, ps.ray.far_ = RZ_FLT_MAX;
-        ps.color = col4{s1.z, s1.w, s2.x, 1.0f};
-        ps.material = bits & 0xFFFFu;
-        ps.depth = (bits >> 16) & 0xFFu;
-        if (ps.depth == 0u) ps.ray.near_ = cam.near_, ps.ray.far_ = cam.far_;
-    }
-}
-
-// pool = local pixel slots [pool_begin, pool_end) (through f.perm when rays are sorted); results go to f.hit0/hit1.
-template <bool FIRST, bool COUNT>
-__device__ __forceinline__ void trace_persistent(const DScene& s, const WalkTop& top, const DCamera& cam, const DFrame& f,
-                                                 uint32_t* pool_next, uint32_t pool_begin, uint32_t pool_end, Counters& cnt) {
-    const bool scene_fast = s.fast_div != 0u;
-    // per-ray state
-    bool has_ray = false, pool_empty = false;
-    uint32_t pixel = 0u;
-    WalkRay cur;
-    cur.o = cur.d = cur.y = V3(0.0f, 0.0f, 1.0f), cur.near_ = cur.far_ = 0.0f, cur.fast = false;
-    v3 world_o = cur.o, world_d = cur.d;
-    float world_near = 0.0f, world_far = 0.0f, len = 1.0f;
-    uint32_t n = RZ_END, ret = RZ_END, inst = 0u;
-    bool in_mesh = false, found_here = false, root_missed = false;
-    Hit hit;
-    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
-    uint32_t guard = 0u;
-
-    while (true) {
-        // ---- refill ----
-        if (!has_ray && !pool_empty) {
-            const uint32_t slot = pool_begin + atomicAdd(pool_next, 1u);
-            if (slot >= pool_end) {
-                pool_empty = true;
-            } else {
-                const PixelId p = pixel_of_local(f, cam, (!FIRST && f.perm) ? f.perm[slot] : slot);
-                pixel = p.local;
-                if (p.active) {
-                    PathState ps;
-                    load_path<FIRST>(f, cam, p, ps);
-                    cur.o = ps.ray.o, cur.d = ps.ray.d, cur.near_ = ps.ray.near_, cur.far_ = ps.ray.far_;
-                    prepare<true>(cur, scene_fast);
-                    world_o = cur.o, world_d = cur.d, world_near = cur.near_, world_far = cur.far_;
-                    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
-                    in_mesh = false, found_here = false, root_missed = false;
-                    n = s.n_instances ? s.tlas_root : RZ_END;
-                    if (s.n_instances == 0u) root_missed = true;
-                    has_ray = true;
-                }
-            }
-        }
-        if (!__any(has_ray)) {
-            if (__all(pool_empty)) break;
-            continue;
-        }
-        RZ_GUARD(guard);
-
-        // ---- node phase: step until this lane holds a leaf or its ray has ended ----
-        uint32_t leaf_begin = 0u, leaf_end = 0u;
-        while (has_ray && leaf_end == leaf_begin) {
-            if (n == RZ_END) {
-                if (in_mesh) {  // leave the instance: cpu_engine_kernel.cpp:320-329
-                    if (found_here) {
-                        hit.instance = int32_t(inst);
-                        world_near = cur.near_ / len;
-                        world_far = cur.far_ / len;
-                    }
-                    cur.o = world_o, cur.d = world_d, cur.near_ = world_near, cur.far_ = world_far;
-                    prepare<true>(cur, scene_fast);
-                    in_mesh = false;
-                    n = ret;
-                    continue;
-                }
-                // the ray's walk is complete: publish the hit record (rz_trace_kernel's layout)
-                const int found = root_missed ? 0 : (hit.instance >= 0 ? 2 : 1);
-                f.hit0[pixel] = make_float4(world_far, hit.bx, hit.by, __uint_as_float(hit.triangle));
-                f.hit1[pixel] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
-                has_ray = false;
-                break;
-            }
-            float4 n0, n1;
-            uint32_t link;
-            fetch_walk_node(s, top, n, n0, n1, link);
-            RZ_COUNT(box_tests);
-            if (box_hit<true>(n0, n1, cur)) {
-                const uint32_t a = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
-                const uint32_t type = meta >> RZ_WALK_TYPE_SHIFT;
-                if (type == RZ_WALK_INNER || type == RZ_WALK_CHAIN) {
-                    n = a;
-                } else if (type == RZ_WALK_INSTANCE) {  // enter: cpu_engine_kernel.cpp:307-319
-                    inst = a;
-                    const InstanceXform x = load_instance_xform(s, inst);
-                    world_o = cur.o, world_d = cur.d, world_near = cur.near_, world_far = cur.far_;
-                    cur.o = transform_backward(x.xa, x.ya, x.za, cur.o - x.position);
-                    cur.d = transform_backward(x.xa, x.ya, x.za, cur.d);
-                    if (!x.unit_scale) {
-                        cur.o = cur.o / x.scale;
-                        cur.d = cur.d / x.scale;
-                    }
-                    len = magnitude(cur.d);
-                    cur.near_ = cur.near_ * len;
-                    cur.far_ = cur.far_ * len;
-                    cur.d = cur.d * (1.0f / len);
-                    prepare<true>(cur, scene_fast);
-                    in_mesh = true, found_here = false;
-                    ret = link;
-                    n = x.blas_root;
-                } else {  // triangle leaf: hold it
-                    leaf_begin = a, leaf_end = a + (meta & RZ_WALK_COUNT_MASK);
-                    n = link;
-                }
-            } else {
-                if (n == s.tlas_root) root_missed = true;  // cpu_engine_kernel.cpp:283
-                n = link;
-            }
-        }
-
-        // ---- leaf phase ----
-        for (uint32_t i = leaf_begin; i < leaf_end; ++i) {
-            const float4 ta = s.tris[3 * i], tb = s.tris[3 * i + 1], tc = s.tris[3 * i + 2];
-            float t, b1, b2, det;
-            RZ_COUNT(tri_tests);
-            if (tri_hit(xyz(ta), xyz(tb), xyz(tc), cur, t, b1, b2, det)) {
-                cur.far_ = t;
-                hit.triangle = i;
-                hit.external = det > 0.0f;
-                hit.bx = b1, hit.by = b2;
-                found_here = true;
-            }
-        }
-    }
-}
-
-// closest hit of the segment with the selected walk; MODE 2 must be reached by all 256 threads
-template <int MODE, bool COUNT, bool RCP>
-RZ_DEV int trace_path(const DScene& s, unsigned char* workspace, uint32_t* lds_column, bool active, Ray& ray, Hit& hit, Counters& cnt) {
-    if constexpr (MODE == 2) {
-        return closest_hit_binned<COUNT, RCP>(s, workspace, active, ray, hit, cnt);
-    } else if constexpr (MODE == 3) {  // workspace = [top nodes][top links], staged here by the whole workgroup
-        float4* ln = reinterpret_cast<float4*>(workspace);
-        uint32_t* ls = reinterpret_cast<uint32_t*>(workspace + s.top_count * 32u);
-        for (uint32_t i = threadIdx.x; i < 2u * s.top_count; i += 256u) ln[i] = s.nodes[i];
-        for (uint32_t i = threadIdx.x; i < s.top_count; i += 256u) ls[i] = s.node_skip[i];
-        __syncthreads();
-        hit.instance = -1, hit.triangle = 0, hit.bx = hit.by = 0.0f, hit.external = true;
-        if (!active || s.n_instances == 0) return 0;
-        const TopCache top{ln, ls, s.top_count};
-        return closest_hit_skip<COUNT, RCP>(s, top, ray, hit, cnt);
-    } else {
-        hit.instance = -1, hit.triangle = 0, hit.bx = hit.by = 0.0f, hit.external = true;
-        return active ? closest_hit<MODE, COUNT, RCP>(s, lds_column, ray, hit, cnt) : 0;
-    }
-}
-
-// everything of traceRay after the closest hit (active lanes only): returns the segment's radiance and whether the path
-// goes on, and leaves the NEXT segment's ray / colour / material / depth in `ps` (TracingResult::repositionRay, or a fresh
-// antialiased camera ray when the path ended).  ps.ray.far_ must hold the hit distance.
-template <bool COUNT, int SHADOW = 1>
-RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cfg, const PixelId& p, PathState& ps, uint32_t pass,
-                          int found, const Hit& hit, const ShadowCtx& lds_column, Counters& cnt, col4& final_color, bool& path_continues) {
-    Ray& ray = ps.ray;
-    col4& ray_color = ps.color;
-    uint32_t& ray_material = ps.material;
-    uint32_t& depth = ps.depth;
-    const uint32_t pixel_idx = p.y * cam.width + p.x;
-    Rng rng(float(p.x) / float(cam.width), float(p.y) / float(cam.height), seed_value(cfg.seed, pass, (pixel_idx + depth) & 255u));
-
-    final_color = splat(0.0f);
-    Surface sf;
-    sf.surface_material = sf.behind_material = HIPRZ_MATERIAL_WORLD;
-    sf.u = sf.v = 0.0f;
-    sf.normal = sf.mapped_normal = V3(0.0f, 0.0f, 0.0f);
-    sf.fresnel = 1.0f, sf.reflectance = 0.0f, sf.tint_factor = 0.0f, sf.refr_x = sf.refr_y = 0.0f;
-    sf.metalness = sf.roughness = 0.0f;
-
-    constexpr bool TEX = SHADOW != RZ_SHADOW_PLAIN;  // PLAIN: the scene has no maps at all (every map index is -1)
-    Material m;
-    if (found == 2) {
-        analyze_intersection<COUNT, TEX>(s, hit, sf, m, cnt);
-    } else {
-        m = load_material(s, HIPRZ_MATERIAL_WORLD);
-        if (TEX && found == 1) {  // texcrd of the sky sphere (cpu_engine_kernel.cpp:292-295); only a map reads it
-            sf.u = -(0.5f + (RZ_ATAN2F(ray.d.z, ray.d.x) / (RZ_PI_F * 2.0f)));
-            sf.v = 0.5f + (RZ_ASINF(ray.d.y) / RZ_PI_F);
-        }
-    }
-    sf.surface_scattering = m.scattering;
-    // fetchColor / fetchEmission (:505-512, 523-528)
-    sf.color = from_u8(m.color);
-    if (TEX && m.texture >= 0) sf.color = fetch_rgba8<COUNT>(s, m.texture, sf.u, sf.v, cnt);
-    sf.color.a = 1.0f - sf.color.a;
-    sf.emission = TEX && m.emission_map >= 0 ? fetch_r32f<COUNT>(s, m.emission_map, sf.u, sf.v, cnt) : m.emission;
-    if (sf.emission > 0.0f) final_color = final_color + (ray_color * sf.color) * sf.emission;
-
-    v3 point = V3(0.0f, 0.0f, 0.0f), next_direction = V3(0.0f, 0.0f, 0.0f);
-    if (found != 2) {
-        depth = 255u;  // TracingState::endPath
-    } else {
-        RZ_COUNT(hits);
-        depth += 1u;
-        sf.metalness = TEX && m.metalness_map >= 0 ? fetch_r8<COUNT>(s, m.metalness_map, sf.u, sf.v, cnt) : m.metalness;
-        sf.roughness = TEX && m.roughness_map >= 0 ? fetch_r8<COUNT>(s, m.roughness_map, sf.u, sf.v, cnt) : m.roughness;
-        sf.fresnel = fresnel_specular_ratio(sf.mapped_normal, ray.d, material_ior(s, ray_material), material_ior(s, sf.behind_material),
-                                            sf.refr_x, sf.refr_y);
-        sf.reflectance = lerpf(sf.fresnel, 1.0f, sf.metalness);
-
-        next_direction = sample_direction(ray.d, ray_material, sf, rng);
-        point = (ray.o + ray.d * ray.far_) + sf.normal * (0.0001f * ray.far_);
-
-        const col4 direct = direct_illumination<SHADOW, COUNT>(s, cfg, lds_column, ray.d, ray_material, point, next_direction, sf, rng, cnt);
-        if constexpr (SHADOW == RZ_SHADOW_DEFER) {  // rz_shadow_kernel adds (direct * a) * b once it knows the shadow masks
-            lds_column.defer_done = true;
-            lds_column.defer_a = ray_color, lds_column.defer_b = lerp(splat(1.0f), sf.color, sf.metalness);
-        } else if constexpr (SHADOW == RZ_SHADOW_NONE || SHADOW == RZ_SHADOW_PLAIN) {
-            // direct == 0: (0 * ray_color) * lerp(..) is +0 for the finite, non-negative colours a path carries, and final_color
-            // (+0 plus emission terms) is never -0, so the addition the lit variants perform leaves it unchanged
-            (void)direct;
-        } else {
-            final_color = final_color + (direct * ray_color) * lerp(splat(1.0f), sf.color, sf.metalness);
-        }
-        ray_color = lerp(ray_color, ray_color * sf.color, sf.tint_factor);  // ColorF::Blend
-    }
-    path_continues = depth < cfg.max_depth;
-    if (path_continues) {  // TracingResult::repositionRay
-        ray.o = point;
-        ray.d = next_direction;
-    } else {
-        RZ_COUNT(finished);
-        generate_antialiased_ray(cam, ray, p.x, p.y, rng);
-        ray_material = HIPRZ_MATERIAL_WORLD;
-        ray_color = splat(1.0f);
-        depth = 0u;
-    }
-}
-
-// shade_segment + accumulation + next-segment state to HBM (renderFirstPass / renderCumulativePass after traceRay)
-template <bool FIRST, bool COUNT, int SHADOW = 1>
-RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& cfg, const DFrame& f, const PixelId& p, PathState& ps,
-                            int found, const Hit& hit, const ShadowCtx& lds_column, Counters& cnt) {
-    const float hit_distance = ps.ray.far_;
-    col4 final_color;
-    bool path_continues;
-    shade_segment<COUNT, SHADOW>(s, cam, cfg, p, ps, FIRST ? 0u : *f.pass, found, hit, lds_column, cnt, final_color, path_continues);
-    const Ray& ray = ps.ray;
-    const col4& ray_color = ps.color;
-    const uint32_t ray_material = ps.material, depth = ps.depth;
-
-    // ---- accumulate ----
-    if constexpr (FIRST) f.depth[p.local] = hit_distance;
-    if constexpr (SHADOW == RZ_SHADOW_DEFER) {
-        // the radiance so far + what rz_shadow_kernel needs to finish it; it also does the accumulation
-        const uint32_t bits = (path_continues ? 1u : 0u) | (lds_column.defer_done ? 2u : 0u) | (lds_column.defer_mask << 2);
-        f.nee_base[p.local] = make_float4(final_color.r, final_color.g, final_color.b, __uint_as_float(bits));
-        if (lds_column.defer_done) {
-            f.nee_a[p.local] = make_float4(lds_column.defer_a.r, lds_column.defer_a.g, lds_column.defer_a.b, lds_column.defer_a.a);
-            f.nee_b[p.local] = make_float4(lds_column.defer_b.r, lds_column.defer_b.g, lds_column.defer_b.b, lds_column.defer_b.a);
-        }
-    } else {
-        col4 value;
-        if constexpr (FIRST) {
-            value = col4{final_color.r, final_color.g, final_color.b, float(!path_continues)};
-        } else {
-            const float4 acc = f.accum[p.local];
-            value = col4{acc.x + final_color.r, acc.y + final_color.g, acc.z + final_color.b, acc.w + float(!path_continues)};
-        }
-        f.accum[p.local] = make_float4(value.r, value.g, value.b, value.a);
-    }
-
-    // ---- next segment ----
-    f.st0[p.local] = make_float4(ray.o.x, ray.o.y, ray.o.z, ray.d.x);
-    f.st1[p.local] = make_float4(ray.d.y, ray.d.z, ray_color.r, ray_color.g);
-    f.st2[p.local] = make_float2(ray_color.b, __uint_as_float((ray_material & 0xFFFFu) | (depth << 16)));
-    if (f.sort_key) f.sort_key[p.local] = ray_sort_key(s, ray.o, ray.d, s.sort_variant);
-    if constexpr (SHADOW == RZ_SHADOW_DEFER) {
-        // the shadow rays of this pixel start at the hit point and point at the light the (last) sample chose: rays from one cell to
-        // one light walk the same instances.  Pixels without a sample have nothing to walk and sort to the end.
-        if (f.shadow_key)
-            f.shadow_key[p.local] = lds_column.defer_mask ? ray_sort_key(s, V3(lds_column.key_o[0], lds_column.key_o[1], lds_column.key_o[2]),
-                                                                         V3(lds_column.key_dir[0], lds_column.key_dir[1], lds_column.key_dir[2]), s.shadow_variant)
-                                                          : 0x00FFFFFEu;
-    }
-}
-
-template <bool COUNT>
-RZ_DEV void flush_counters(const DFrame& f, uint32_t segments, const Counters& cnt) {
-    if constexpr (COUNT) {
-        uint32_t v[10] = {segments,        cnt.box_tests,     cnt.tri_tests,     cnt.hits,     cnt.shadow_rays,
-                          cnt.light_samples, cnt.texel_fetches, cnt.finished, cnt.shadow_box_tests, cnt.shadow_tri_tests};
-#pragma unroll
-        for (int k = 0; k < 10; ++k) {
-            uint32_t x = v[k];
-            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-            if ((threadIdx.x & 63u) == 0u && x) atomicAdd(&f.counters[k], (unsigned long long)x);
-        }
-    }
-}
-
-// LDS carve-up shared by the kernels: [staged scene blob][walk workspace].  For MODE 2 the workspace is
-// BinnedLds and its stack columns double as the LDS stack of the shadow rays; otherwise it is the stack.
-template <int MODE>
-RZ_DEV uint32_t* stack_column(unsigned char* workspace) {
-    return reinterpret_cast<uint32_t*>(MODE == 2 ? workspace + BinnedLds::kFixedBytes : workspace) + threadIdx.x;
-}
-
-// ---- fused pipeline ----
-template <bool FIRST, bool COUNT, int MODE, bool LDS_SCENE>
-__global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    DScene s = scene_in;
-    unsigned char* workspace = rz_lds + stage_scene<LDS_SCENE>(s, rz_lds);
-    uint32_t* lds_column = stack_column<MODE>(workspace);
-    const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
-    Counters cnt;
-    PathState ps;
-    load_path<FIRST>(f, cam, p, ps);
-    Hit hit;
-    int found;
-    if constexpr (MODE == 2) {  // what the walk does not read is parked in LDS meanwhile
-        // 4 KiB behind the binned walk's workspace (launch_pass adds them to the fused kernel's LDS size)
-        uint32_t* park = reinterpret_cast<uint32_t*>(workspace + BinnedLds::kFixedBytes + (s.world_stack_entries + s.mesh_stack_entries) * 1024u);
-        park[0 * 256 + threadIdx.x] = __float_as_uint(ps.color.r), park[1 * 256 + threadIdx.x] = __float_as_uint(ps.color.g);
-        park[2 * 256 + threadIdx.x] = __float_as_uint(ps.color.b), park[3 * 256 + threadIdx.x] = ps.material | (ps.depth << 16);
-        found = trace_path<MODE, COUNT, RZ_FUSED_SHARED_RCP != 0>(s, workspace, lds_column, p.active, ps.ray, hit, cnt);
-        ps.color = col4{__uint_as_float(park[0 * 256 + threadIdx.x]), __uint_as_float(park[1 * 256 + threadIdx.x]),
-                        __uint_as_float(park[2 * 256 + threadIdx.x]), 1.0f};
-        const uint32_t bits = park[3 * 256 + threadIdx.x];
-        ps.material = bits & 0xFFFFu, ps.depth = bits >> 16;
-    } else {
-        found = trace_path<MODE, COUNT, RZ_FUSED_SHARED_RCP != 0>(s, workspace, lds_column, p.active, ps.ray, hit, cnt);
-    }
-    if (p.active) shade_and_store<FIRST, COUNT>(s, cam, cfg, f, p, ps, found, hit, ShadowCtx{lds_column, TopCache{nullptr, nullptr, 0u}}, cnt);
-    flush_counters<COUNT>(f, p.active ? 1u : 0u, cnt);
-}
-
-// ---- resident pipeline ----
-// Pixels never interact, so a workgroup can take its tile through ALL the cumulative passes of a render batch in one
-// launch: path state and accumulator stay in registers (parked in LDS during the binned walk) and cross HBM once per
-// batch instead of once per pass, there is one launch per batch instead of two or three per pass, and the tone-mapped
-// pixel is written on the way out.  Per pixel the arithmetic is that of n_passes launches of the fused kernel: the
-// direction is re-normalised at the start of every segment as load_path does after reading it back, and the
-// accumulator grows by the same sequence of additions.
-// WAVES = waves per SIMD the register budget is cut for.  With 29 KB of LDS per workgroup (a Cornell-sized scene) five workgroups
-// fit a CU, and when the grid oversubscribes the chip the 5-wave build of the plain instantiation wins although it spills more
-// (96 VGPRs, 148 B of scratch: whole 1080p frame 2.15 -> 2.04 ms per step); a grid that fits the chip at once — an eighth of the
-// frame on each of 8 GPUs — runs faster on the 4-wave build (0.326 against 0.350 ms), so launch_batch picks by grid size.
-template <bool COUNT, int MODE, bool LDS_SCENE, int SHADING, int WAVES = RZ_MIN_WAVES>  // SHADING: 1 general, RZ_SHADOW_NONE (no lights), RZ_SHADOW_PLAIN (no lights, no maps)
-__global__ void __launch_bounds__(256, WAVES) rz_batch_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f,
-                                                                      uint32_t n_passes, uint32_t park_offset) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    DScene s = scene_in;
-    unsigned char* workspace = rz_lds + stage_scene<LDS_SCENE>(s, rz_lds);
-    uint32_t* lds_column = stack_column<MODE>(workspace);
-    const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
-    Counters cnt;
-    PathState ps;
-    load_path<false>(f, cam, p, ps);
-    // the accumulator lives in LDS for the whole batch (touched once per pass); colour / material / depth join it
-    // there while the binned walk runs
-    uint32_t* park = reinterpret_cast<uint32_t*>(workspace + park_offset) + threadIdx.x;
-    {
-        const float4 acc = p.active ? f.accum[p.local] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        park[4 * 256] = __float_as_uint(acc.x), park[5 * 256] = __float_as_uint(acc.y);
-        park[6 * 256] = __float_as_uint(acc.z), park[7 * 256] = __float_as_uint(acc.w);
-    }
-    const uint32_t pass0 = *f.pass;
-    for (uint32_t i = 0; i < n_passes; ++i) {
-        if (i != 0u && p.active) {  // what load_path does with the state the previous pass stored
-            ps.ray.d = normalized(ps.ray.d);
-            ps.ray.near_ = 0.0f, ps.ray.far_ = RZ_FLT_MAX;
-            if (ps.depth == 0u) ps.ray.near_ = cam.near_, ps.ray.far_ = cam.far_;
-        }
-        Hit hit;
-        int found;
-        if constexpr (MODE == 2) {
-            park[0 * 256] = __float_as_uint(ps.color.r), park[1 * 256] = __float_as_uint(ps.color.g);
-            park[2 * 256] = __float_as_uint(ps.color.b), park[3 * 256] = ps.material | (ps.depth << 16);
-            found = trace_path<MODE, COUNT, RZ_BATCH_SHARED_RCP != 0>(s, workspace, lds_column, p.active, ps.ray, hit, cnt);
-            ps.color = col4{__uint_as_float(park[0 * 256]), __uint_as_float(park[1 * 256]), __uint_as_float(park[2 * 256]), 1.0f};
-            const uint32_t bits = park[3 * 256];
-            ps.material = bits & 0xFFFFu, ps.depth = bits >> 16;
-        } else {
-            found = trace_path<MODE, COUNT, RZ_BATCH_SHARED_RCP != 0>(s, workspace, lds_column, p.active, ps.ray, hit, cnt);
-        }
-        if (p.active) {
-            col4 final_color;
-            bool path_continues;
-            shade_segment<COUNT, SHADING>(s, cam, cfg, p, ps, pass0 + i, found, hit, ShadowCtx{lds_column, TopCache{nullptr, nullptr, 0u}}, cnt, final_color, path_continues);
-            park[4 * 256] = __float_as_uint(__uint_as_float(park[4 * 256]) + final_color.r);
-            park[5 * 256] = __float_as_uint(__uint_as_float(park[5 * 256]) + final_color.g);
-            park[6 * 256] = __float_as_uint(__uint_as_float(park[6 * 256]) + final_color.b);
-            park[7 * 256] = __float_as_uint(__uint_as_float(park[7 * 256]) + float(!path_continues));
-        }
-    }
-    if (p.active) {
-        const float4 acc = make_float4(__uint_as_float(park[4 * 256]), __uint_as_float(park[5 * 256]), __uint_as_float(park[6 * 256]),
-                                       __uint_as_float(park[7 * 256]));
-        f.accum[p.local] = acc;
-        f.st0[p.local] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.d.x);
-        f.st1[p.local] = make_float4(ps.ray.d.y, ps.ray.d.z, ps.color.r, ps.color.g);
-        f.st2[p.local] = make_float2(ps.color.b, __uint_as_float((ps.material & 0xFFFFu) | (ps.depth << 16)));
-        f.rgba8[p.local] = tonemap(col4{acc.x, acc.y, acc.z, acc.w}, cam.aperture, cam.exposure_time);
-    }
-    flush_counters<COUNT>(f, p.active ? n_passes : 0u, cnt);
-}
-
-// ---- split pipeline ----
-// hit record: hit0 = (far, b1, b2, bits(triangle)), hit1 = instance | found << 29 | external << 31
-template <bool FIRST, bool COUNT, int MODE, bool LDS_SCENE>
-__global__ void __launch_bounds__(256, RZ_TRACE_MIN_WAVES) rz_trace_kernel(const DScene scene_in, const DCamera cam, const DFrame f) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    DScene s = scene_in;
-    unsigned char* workspace = rz_lds + stage_scene<LDS_SCENE>(s, rz_lds);
-    uint32_t* lds_column = stack_column<MODE>(workspace);
-    // sorted order: thread i walks the ray of pixel perm[i] (the hit record still goes to that pixel's slot)
-    // sorted order: thread i walks the ray of pixel perm[i] (the hit record still goes to that pixel's slot)
-    if (f.wg_times && threadIdx.x == 0u) f.wg_times[2u * blockIdx.x] = wall_clock64();
-    const uint32_t sorted_slot = blockIdx.x * 256u + threadIdx.x;
-    const PixelId p = (!FIRST && f.perm) ? pixel_of_local(f, cam, f.perm[sorted_slot]) : pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
-    Counters cnt;
-    Ray ray;
-    {
-        PathState ps;
-        load_path<FIRST>(f, cam, p, ps);
-        ray = ps.ray;
-    }
-    Hit hit;
-    const int found = trace_path<MODE, COUNT, RZ_TRACE_SHARED_RCP != 0>(s, workspace, lds_column, p.active, ray, hit, cnt);
-    if (p.active) {
-        f.hit0[p.local] = make_float4(ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
-        f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
-    }
-    flush_counters<COUNT>(f, 0u, cnt);
-    if (f.wg_times) {
-        __syncthreads();
-        if (threadIdx.x == 0u) f.wg_times[2u * blockIdx.x + 1u] = wall_clock64();
-    }
-}
-
-// MODE 3 trace kernel, one wave per workgroup.  A workgroup's registers and LDS stay allocated until its LAST wave ends and
-// a wave lasts as long as its slowest ray, so with heavy-tailed ray costs single-wave workgroups give their slots back sooner
-// (config D 3 378 -> 3 093 us, C 974 -> 910 us against 256 threads); the price is a smaller share of LDS for the tree-top cache
-// (top_n nodes per workgroup).  MINW = waves per SIMD the register budget is cut for: big trees are bound by the latency of
-// their node fetches and want occupancy (D: 6 waves 2 959 us, 4 waves 3 370 us), trees that live in L2 / LDS want registers
-// (C: 4 waves 879 us, 6 waves 984 us).
-#ifndef RZ_TRACE_PARK
-#define RZ_TRACE_PARK 1
-#endif
-template <bool FIRST, bool COUNT, int MINW, bool ORDERED>
-__global__ void __launch_bounds__(64, MINW) rz_trace_skip_kernel(const DScene s, const DCamera cam, const DFrame f, uint32_t top_n) {
-    constexpr int WG = 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    float4* ln = reinterpret_cast<float4*>(rz_lds);
-    uint32_t* ls = reinterpret_cast<uint32_t*>(rz_lds + top_n * 32u);
-    if constexpr (!ORDERED) {  // the front-to-back walk reads its 64-B records straight from L1 / L2 (top_n = 0): LDS only parks state
-        for (uint32_t i = threadIdx.x; i < 2u * top_n; i += uint32_t(WG)) ln[i] = s.nodes[i];
-        for (uint32_t i = threadIdx.x; i < top_n; i += uint32_t(WG)) ls[i] = s.node_skip[i];
-    }
-    if constexpr (WG > 64) __syncthreads();
-    const uint32_t slot = blockIdx.x * uint32_t(WG) + threadIdx.x;
-    const PixelId p = pixel_of_local(f, cam, (!FIRST && f.perm) ? f.perm[slot] : slot);
-    Counters cnt;
-    Ray ray;
-    {
-        PathState ps;
-        load_path<FIRST>(f, cam, p, ps);
-        ray = ps.ray;
-    }
-    Hit hit;
-    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
-    int found = 0;
-    if (p.active && s.n_instances != 0u) {
-        // MINW 6 (80 VGPRs): the world-space ray waits in LDS while a mesh is walked (closest_hit_skip<.., PARK>)
-        constexpr bool PARK = ORDERED && MINW >= 6 && RZ_TRACE_PARK != 0;
-        const TopCache top{ln, ls, top_n, reinterpret_cast<float*>(rz_lds)};
-        found = closest_hit_skip<COUNT, RZ_TRACE_SHARED_RCP != 0, ORDERED, PARK>(s, top, ray, hit, cnt);
-    }
-    if (p.active) {
-        f.hit0[p.local] = make_float4(ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
-        f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
-    }
-    flush_counters<COUNT>(f, 0u, cnt);
-}
-
-// The front-to-back walk with the cooperative triangle phase (hiprz_device.hpp: closest_hit_coop): one wave per workgroup, all
-// 64 lanes go through the walk together (a lane without a ray only helps with other lanes' triangles).
-template <bool FIRST, bool COUNT, int MINW>
-__global__ void __launch_bounds__(64, MINW) rz_trace_coop_kernel(const DScene s, const DCamera cam, const DFrame f) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
-    const PixelId p = pixel_of_local(f, cam, (!FIRST && f.perm) ? f.perm[slot] : slot);
-    Counters cnt;
-    Ray ray;
-    {
-        PathState ps;
-        load_path<FIRST>(f, cam, p, ps);
-        ray = ps.ray;
-    }
-    Hit hit;
-    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
-    int found = 0;
-    if (s.n_instances != 0u) found = closest_hit_coop<COUNT, RZ_TRACE_SHARED_RCP != 0>(s, CoopLds(rz_lds), p.active, ray, hit, cnt);
-    if (p.active) {
-        f.hit0[p.local] = make_float4(ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
-        f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
-    }
-    flush_counters<COUNT>(f, 0u, cnt);
-}
-
-// MODE 6 trace kernel: "wave pool".  A wave lasts as long as its slowest ray, and with heavy-tailed ray costs (config D:
-// the slowest of 64 rays costs ~12x the mean) the MODE 3 walk leaves 87 % of the lanes idle.  Here a 64-lane workgroup is
-// persistent: it draws rays from a global counter and alternates two phases over in-register per-lane state —
-//   A. lanes that hold a ray but are not inside a mesh advance through the world tree / instance boxes to their next
-//      mesh (or finish the ray, write its hit record and free the lane);
-//   B. lanes inside a mesh walk it ("while-while": node steps until a leaf is held, then the triangles), until fewer
-//      than `threshold` lanes are left in meshes and somebody could join them — then idle lanes are refilled, phase A
-//      brings the others to their next mesh, and phase B resumes with a dense wave while the stragglers simply
-//      kept their state in their lanes.
-// Per ray the boxes and triangles are tested in the reference's order; only the interleaving across lanes differs.
-#ifndef RZ_POOL_MIN_WAVES
-#define RZ_POOL_MIN_WAVES 5
-#endif
-template <bool FIRST, bool COUNT>
-__global__ void __launch_bounds__(64, RZ_POOL_MIN_WAVES) rz_trace_pool_kernel(const DScene s, const DCamera cam, const DFrame f, uint32_t top_n,
-                                                                              uint32_t* fresh_next, uint32_t threshold) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    constexpr bool RCP = RZ_TRACE_SHARED_RCP != 0;
-    float4* ln = reinterpret_cast<float4*>(rz_lds);
-    uint32_t* ls = reinterpret_cast<uint32_t*>(rz_lds + top_n * 32u);
-    for (uint32_t k = threadIdx.x; k < 2u * top_n; k += 64u) ln[k] = s.nodes[k];
-    for (uint32_t k = threadIdx.x; k < top_n; k += 64u) ls[k] = s.node_skip[k];
-    const TopCache top{ln, ls, top_n};
-    const uint32_t n_slots = f.n_local_tiles * 256u, lane = threadIdx.x;
-    const bool scene_fast = s.fast_div != 0u;
-
-    bool has_ray = false, in_mesh = false, found = false, root_missed = false;
-    bool fresh_left = true;  // wave-uniform
-    uint32_t pixel = 0u, n = RZ_END, i = 0u, end = 0u, inst = 0u, m = RZ_END;
-    uint32_t tj = 0u, tj_end = 0u;  // the held leaf's remaining triangles
-    const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? s.walk_l : 0xFFFFFFFFu;
-    float len = 1.0f;
-    WalkRay g, lr;
-    g.o = g.d = g.y = V3(0.0f, 0.0f, 1.0f), g.near_ = g.far_ = 0.0f, g.fast = false;
-    lr = g;
-    Hit hit;
-    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
-    Counters cnt;
-    uint32_t guard = 0u;
-
-    while (true) {
-        RZ_GUARD(guard);
-        // ---- refill the idle lanes from the global ray counter (one atomic per wave) ----
-        if (fresh_left) {
-            const unsigned long long idle = __ballot(!has_ray);
-            if (idle) {
-                const int leader = __ffsll((long long)idle) - 1;
-                const uint32_t want = uint32_t(__popcll(idle));
-                uint32_t base = 0u;
-                if (int(lane) == leader) base = atomicAdd(fresh_next, want);
-                base = __shfl(base, leader);
-                if (base + want >= n_slots) fresh_left = false;
-                if (!has_ray) {
-                    const uint32_t slot = base + uint32_t(__popcll(idle & ((1ull << lane) - 1ull)));
-                    if (slot < n_slots) {
-                        const PixelId p = pixel_of_local(f, cam, (!FIRST && f.perm) ? f.perm[slot] : slot);
-                        if (p.active) {
-                            PathState ps;
-                            load_path<FIRST>(f, cam, p, ps);
-                            pixel = p.local;
-                            g.o = ps.ray.o, g.d = ps.ray.d, g.near_ = ps.ray.near_, g.far_ = ps.ray.far_;
-                            prepare<RCP>(g, scene_fast);
-                            hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
-                            in_mesh = false, found = false, i = end = 0u;
-                            root_missed = s.n_instances == 0u;  // no instances: the reference returns at once (:282)
-                            n = s.n_instances ? s.tlas_root : RZ_END;
-                            has_ray = true;
-                        }
-                    }
-                }
-            }
-        }
-        if (!__any(has_ray)) {
-            if (!fresh_left) break;
-            continue;  // the slots drawn were all outside the frame: draw again (the counter only grows)
-        }
-
-        // ---- phase A: to the next mesh, or to the end of the ray ----
-        while (has_ray && !in_mesh) {
-            RZ_GUARD(guard);
-            if (i < end) {  // instances of the current world leaf (cpu_engine_kernel.cpp:268-275, 299-306)
-                inst = s.tlas_order[i];
-                i += 1u;
-                float4 ib0, ib1;
-                load_instance_box(s, inst, ib0, ib1);
-                RZ_COUNT(box_tests);
-                if (box_hit<RCP>(ib0, ib1, g)) {
-                    const InstanceXform x = load_instance_xform(s, inst);
-                    len = to_local<RCP>(x, g, lr, scene_fast);
-                    in_mesh = true, found = false;
-                    m = x.blas_root;
-                    tj = tj_end = 0u;
-                }
-                continue;
-            }
-            if (n == RZ_END) {  // the ray is complete: publish its hit record (rz_trace_kernel's layout)
-                const int code = root_missed ? 0 : (hit.instance >= 0 ? 2 : 1);
-                f.hit0[pixel] = make_float4(g.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
-                f.hit1[pixel] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(code) << 29) | (hit.external ? 0x80000000u : 0u);
-                has_ray = false;
-                break;
-            }
-            float4 n0, n1;
-            uint32_t link;
-            fetch_node(s, top, n, n0, n1, link);
-            RZ_COUNT(box_tests);
-            if (box_hit<RCP>(n0, n1, g)) {
-                const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
-                if (!(meta & HIPRZ_NODE_LEAF)) {
-                    n = begin;
-                } else {
-                    i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
-                    n = link;
-                }
-            } else {
-                if (n == s.tlas_root) root_missed = true, link = RZ_END;  // root box missed (:283)
-                n = link;
-            }
-        }
-
-        // ---- phase B: the mesh walks (cpu_engine_kernel.cpp:331-352) ----
-        while (true) {
-            RZ_GUARD(guard);
-            const uint32_t walking = uint32_t(__popcll(__ballot(in_mesh)));
-            if (walking == 0u) break;
-            if (walking < threshold && (__any(has_ray && !in_mesh) || (fresh_left && __any(!has_ray)))) break;
-            if (in_mesh) {
-                // one bounded round: up to walk_k node steps for a lane that holds no leaf, then up to walk_l triangles of the held leaf
-                uint32_t k = 0u;
-                while (tj == tj_end && m != RZ_END && k < kmax) {
-                    RZ_GUARD(guard);
-                    k += 1u;
-                    float4 m0, m1;
-                    uint32_t mlink;
-                    fetch_node(s, top, m, m0, m1, mlink);
-                    RZ_COUNT(box_tests);
-                    if (box_hit<RCP>(m0, m1, lr)) {
-                        const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
-                        if (!(mmeta & HIPRZ_NODE_LEAF)) {
-                            m = mbegin;
-                            continue;
-                        }
-                        tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
-                    }
-                    m = mlink;
-                }
-                if (tj == tj_end && m == RZ_END) {  // the mesh is done (:320-329)
-                    if (found) {
-                        hit.instance = int32_t(inst);
-                        g.near_ = lr.near_ / len;
-                        g.far_ = lr.far_ / len;
-                    }
-                    in_mesh = false;
-                } else {
-                    uint32_t l = 0u;
-                    for (; tj < tj_end && l < lmax; ++tj, ++l) {
-                        const float4 a = s.tris[3 * tj], b = s.tris[3 * tj + 1], c = s.tris[3 * tj + 2];
-                        float t, b1, b2, det;
-                        RZ_COUNT(tri_tests);
-                        if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
-                            lr.far_ = t;
-                            hit.triangle = tj;
-                            hit.external = det > 0.0f;
-                            hit.bx = b1, hit.by = b2;
-                            found = true;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    flush_counters<COUNT>(f, 0u, cnt);
-}
-
-// MODE 5 trace kernels: round 0 walks every owned pixel's ray, round r > 0 the rays round r-1 left unfinished.
-// Queue record r of a round (48 B, SoA): q0 = (pixel slot, world leaf, tlas_order slot, mesh node), q1 = (near, far,
-// mesh-space far, bits(found | external << 1)), q2 = (b1, b2, bits(triangle), bits(instance)).
-struct DRequeue {
-    const uint4* in0;
-    const float4* in1;
-    const float4* in2;
-    uint4* out0;
-    float4* out1;
-    float4* out2;
-    uint32_t* counts;    // counts[r] = rays queued FOR round r (counts[0] unused)
-    uint32_t round;
-    uint32_t threshold;  // lanes that must remain in a mesh walk for it to go on (this round)
-};
-template <bool FIRST, bool COUNT, bool ROUND0, bool CAN_BAIL>
-__global__ void __launch_bounds__(256, RZ_TRACE_MIN_WAVES) rz_trace_requeue_kernel(const DScene s, const DCamera cam, const DFrame f, const DRequeue q) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
-    uint32_t n_in = 0u;
-    if constexpr (!ROUND0) {
-        n_in = q.counts[q.round];
-        if (blockIdx.x * 256u >= n_in) return;  // whole workgroup: nothing queued for it
-    }
-    float4* ln = reinterpret_cast<float4*>(rz_lds);
-    uint32_t* ls = reinterpret_cast<uint32_t*>(rz_lds + s.top_count * 32u);
-    for (uint32_t i = threadIdx.x; i < 2u * s.top_count; i += 256u) ln[i] = s.nodes[i];
-    for (uint32_t i = threadIdx.x; i < s.top_count; i += 256u) ls[i] = s.node_skip[i];
-    __syncthreads();
-    const TopCache top{ln, ls, s.top_count};
-
-    Counters cnt;
-    PixelId p;
-    Ray ray;
-    Hit hit;
-    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
-    WalkResume rs;
-    rs.n = s.tlas_root, rs.i = 0u, rs.m = RZ_END, rs.in_mesh = false, rs.found = false, rs.lr_far = 0.0f;
-    if constexpr (ROUND0) {
-        p = (!FIRST && f.perm) ? pixel_of_local(f, cam, f.perm[slot]) : pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
-        PathState ps;
-        load_path<FIRST>(f, cam, p, ps);
-        ray = ps.ray;
-    } else {
-        const bool queued = slot < n_in;
-        const uint4 r0 = queued ? q.in0[slot] : make_uint4(0u, 0u, 0u, 0u);
-        p = pixel_of_local(f, cam, r0.x);
-        if (!queued) p.active = false;
-        PathState ps;
-        load_path<FIRST>(f, cam, p, ps);
-        ray = ps.ray;
-        if (queued) {
-            const float4 r1 = q.in1[slot], r2 = q.in2[slot];
-            const uint32_t bits = __float_as_uint(r1.w);
-            ray.near_ = r1.x, ray.far_ = r1.y;
-            rs.n = r0.y, rs.i = r0.z, rs.m = r0.w, rs.in_mesh = true, rs.found = (bits & 1u) != 0u, rs.lr_far = r1.z;
-            hit.bx = r2.x, hit.by = r2.y, hit.triangle = __float_as_uint(r2.z), hit.instance = int32_t(__float_as_uint(r2.w));
-            hit.external = (bits & 2u) != 0u;
-        }
-    }
-    int found = 0;
-    if (p.active && s.n_instances != 0u) found = closest_hit_requeue<COUNT, RZ_TRACE_SHARED_RCP != 0, CAN_BAIL>(s, top, ray, hit, rs, q.threshold, cnt);
-    if constexpr (CAN_BAIL) {
-        // unfinished rays -> next round's queue, one atomic per wave
-        const bool bailed = found == 3;
-        const unsigned long long mask = __ballot(bailed);
-        if (mask) {
-            const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-            uint32_t base = 0u;
-            if (lane == uint32_t(__ffsll((long long)mask) - 1)) base = atomicAdd(&q.counts[q.round + 1u], uint32_t(__popcll(mask)));
-            base = __shfl(base, __ffsll((long long)mask) - 1);
-            if (bailed) {
-                const uint32_t o = base + uint32_t(__popcll(mask & ((1ull << lane) - 1ull)));
-                q.out0[o] = make_uint4(p.local, rs.n, rs.i, rs.m);
-                q.out1[o] = make_float4(ray.near_, ray.far_, rs.lr_far, __uint_as_float((rs.found ? 1u : 0u) | (hit.external ? 2u : 0u)));
-                q.out2[o] = make_float4(hit.bx, hit.by, __uint_as_float(hit.triangle), __uint_as_float(uint32_t(hit.instance)));
-            }
-        }
-    }
-    if (p.active && found != 3) {
-        f.hit0[p.local] = make_float4(ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
-        f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
-    }
-    flush_counters<COUNT>(f, 0u, cnt);
-}
-
-// MODE 4 trace kernel: persistent lanes over a per-workgroup pool of RZ_POOL_FACTOR * 256 rays
-template <bool FIRST, bool COUNT>
-__global__ void __launch_bounds__(256, RZ_TRACE_MIN_WAVES) rz_trace_persistent_kernel(const DScene s, const DCamera cam, const DFrame f) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    float4* ln = reinterpret_cast<float4*>(rz_lds);
-    uint32_t* ls = reinterpret_cast<uint32_t*>(rz_lds + s.wtop_count * 32u);
-    uint32_t* pool_next = ls + s.wtop_count;
-    for (uint32_t i = threadIdx.x; i < 2u * s.wtop_count; i += 256u) ln[i] = s.wnodes[i];
-    for (uint32_t i = threadIdx.x; i < s.wtop_count; i += 256u) ls[i] = s.wskip[i];
-    if (threadIdx.x == 0u) *pool_next = 0u;
-    __syncthreads();
-    const uint32_t pool_rays = 256u * RZ_POOL_FACTOR, n_slots = f.n_local_tiles * 256u;
-    const uint32_t pool_begin = blockIdx.x * pool_rays, pool_end = pool_begin + pool_rays < n_slots ? pool_begin + pool_rays : n_slots;
-    Counters cnt;
-    const WalkTop top{ln, ls, s.wtop_count};
-    trace_persistent<FIRST, COUNT>(s, top, cam, f, pool_next, pool_begin, pool_end, cnt);
-    flush_counters<COUNT>(f, 0u, cnt);
-}
-
-// SHADOW: the shadow-ray walk — 1 = nested loops with the per-lane LDS stack (scenes staged in LDS), 3 = skip links with the
-// tree tops staged in LDS instead of a stack (everything else; `top_n` nodes).
-template <bool FIRST, bool COUNT, bool LDS_SCENE, int SHADOW>
-__global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f, uint32_t top_n) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    DScene s = scene_in;
-    unsigned char* workspace = rz_lds + stage_scene<LDS_SCENE>(s, rz_lds);
-    ShadowCtx shadow{stack_column<1>(workspace), TopCache{nullptr, nullptr, 0u}};
-    if constexpr (SHADOW == RZ_SHADOW_DEFER) {
-        shadow.lds_column = nullptr;
-        shadow.nee_point = f.nee_point, shadow.nee_dir = f.nee_dir, shadow.nee_term = f.nee_term;
-        shadow.nee_stride = f.n_local_tiles * 256u;
-    }
-    if constexpr (SHADOW == 3) {
-        float4* ln = reinterpret_cast<float4*>(workspace);
-        uint32_t* ls = reinterpret_cast<uint32_t*>(workspace + top_n * 32u);
-        for (uint32_t i = threadIdx.x; i < 2u * top_n; i += 256u) ln[i] = s.nodes[i];
-        for (uint32_t i = threadIdx.x; i < top_n; i += 256u) ls[i] = s.node_skip[i];
-        __syncthreads();
-        shadow.lds_column = nullptr;
-        shadow.top = TopCache{ln, ls, top_n};
-    }
-    const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
-    Counters cnt;
-    if (p.active) {
-        PathState ps;
-        load_path<FIRST>(f, cam, p, ps);
-        const float4 h0 = f.hit0[p.local];
-        const uint32_t h1 = f.hit1[p.local];
-        Hit hit;
-        const int found = int((h1 >> 29) & 3u);
-        ps.ray.far_ = h0.x;
-        hit.bx = h0.y, hit.by = h0.z, hit.triangle = __float_as_uint(h0.w);
-        hit.instance = found == 2 ? int32_t(h1 & 0x1FFFFFFFu) : -1;
-        hit.external = (h1 & 0x80000000u) != 0u;
-        shadow.pixel = p.local;
-        shade_and_store<FIRST, COUNT, SHADOW>(s, cam, cfg, f, p, ps, found, hit, shadow, cnt);
-    } else if (f.sort_key && p.local < f.n_local_tiles * 256u) {
-        f.sort_key[p.local] = 0x00FFFFFFu;  // slots outside the frame sort to the end
-        if (f.shadow_key) f.shadow_key[p.local] = 0x00FFFFFFu;
-    }
-    flush_counters<COUNT>(f, p.active ? 1u : 0u, cnt);
-}
-
-// The shadow rays of a pass, deferred by rz_shade_kernel<..., RZ_SHADOW_DEFER>: anyIntersection (cpu_engine_kernel.cpp:398-481)
-// for every sample slot that holds a ray, then the sums of directLightSampling / spotLightSampling (:742-743, :789-790),
-// `final += (direct * ray_color) * lerp(1, colour, metalness)` (:160-165) and the accumulation of renderFirstPass /
-// renderCumulativePass (:42-45, :82-86), all in the order the inline path has them.  One wave per workgroup, tree tops in
-// LDS, packed box test: the walk runs at the trace kernel's occupancy instead of the shading kernel's 128 VGPRs.
-template <bool FIRST, bool COUNT, int MINW, bool ORDERED>
-__global__ void __launch_bounds__(64, MINW) rz_shadow_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f, uint32_t top_n) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    float4* ln = reinterpret_cast<float4*>(rz_lds);
-    uint32_t* ls = reinterpret_cast<uint32_t*>(rz_lds + top_n * 32u);
-    if constexpr (!ORDERED)
-        for (uint32_t i = threadIdx.x; i < 2u * top_n; i += 64u) ln[i] = s.nodes[i];
-    if constexpr (!ORDERED)
-        for (uint32_t i = threadIdx.x; i < top_n; i += 64u) ls[i] = s.node_skip[i];
-    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
-    const uint32_t* order = f.shadow_perm ? f.shadow_perm : f.perm;
-    const PixelId p = pixel_of_local(f, cam, order ? order[slot] : slot);
-    Counters cnt;
-    if (p.active) {
-        const ShadowCtx sc{nullptr, TopCache{ln, ls, top_n}};
-        const float4 base = f.nee_base[p.local];
-        const uint32_t bits = __float_as_uint(base.w);
-        const bool path_continues = (bits & 1u) != 0u;
-        col4 final_color{base.x, base.y, base.z, 0.0f};
-        if (bits & 2u) {
-            const uint32_t mask = bits >> 2, stride = f.n_local_tiles * 256u;
-            const float4 o = f.nee_point[p.local];
-            auto shadowed_sum = [&](uint32_t first, uint32_t count) {
-                col4 total = splat(0.0f);
-                for (uint32_t k = first; k < first + count; ++k) {
-                    if (!(mask & (1u << k))) continue;
-                    const float4 d = f.nee_dir[size_t(k) * stride + p.local], t = f.nee_term[size_t(k) * stride + p.local];
-                    Ray sr;
-                    sr.o = V3(o.x, o.y, o.z), sr.d = V3(d.x, d.y, d.z), sr.near_ = 0.0f, sr.far_ = d.w;
-                    const col4 V_PL = splat(any_hit<ORDERED ? 7 : 3, COUNT>(s, sc, sr, cnt));
-                    total = total + (col4{t.x, t.y, t.z, t.w} * V_PL) * V_PL.a;
-                }
-                return total;
-            };
-            col4 direct_total = splat(0.0f), spot_total = splat(0.0f);
-            if (s.n_direct_lights != 0u) direct_total = div_scalar(shadowed_sum(0u, cfg.direct_samples), float(cfg.direct_samples) / float(s.n_direct_lights));
-            if (s.n_spot_lights != 0u) spot_total = div_scalar(shadowed_sum(cfg.direct_samples, cfg.spot_samples), float(cfg.spot_samples) / float(s.n_spot_lights));
-            const col4 direct = direct_total + spot_total;
-            const float4 a = f.nee_a[p.local], b = f.nee_b[p.local];
-            final_color = final_color + (direct * col4{a.x, a.y, a.z, a.w}) * col4{b.x, b.y, b.z, b.w};
-        }
-        col4 value;
-        if constexpr (FIRST) {
-            value = col4{final_color.r, final_color.g, final_color.b, float(!path_continues)};
-        } else {
-            const float4 acc = f.accum[p.local];
-            value = col4{acc.x + final_color.r, acc.y + final_color.g, acc.z + final_color.b, acc.w + float(!path_continues)};
-        }
-        f.accum[p.local] = make_float4(value.r, value.g, value.b, value.a);
-    }
-    flush_counters<COUNT>(f, 0u, cnt);
-}
-
-// rz_shadow_kernel with the cooperative any-hit walk (hiprz_device.hpp: any_hit_coop): the sample loop is wave-uniform, a lane
-// whose pixel has no shadow ray in slot k walks along as a helper.  Sums, order and accumulation are those of rz_shadow_kernel.
-template <bool FIRST, bool COUNT, int MINW>
-__global__ void __launch_bounds__(64, MINW) rz_shadow_coop_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    const CoopLds lds(rz_lds);
-    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
-    const uint32_t* order = f.shadow_perm ? f.shadow_perm : f.perm;
-    const PixelId p = pixel_of_local(f, cam, order ? order[slot] : slot);
-    Counters cnt;
-    float4 base = make_float4(0.0f, 0.0f, 0.0f, 0.0f), o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    uint32_t bits = 0u;
-    if (p.active) {
-        base = f.nee_base[p.local];
-        bits = __float_as_uint(base.w);
-        if (bits & 2u) o = f.nee_point[p.local];
-    }
-    const uint32_t mask = (bits & 2u) ? bits >> 2 : 0u, stride = f.n_local_tiles * 256u;
-    col4 direct_total = splat(0.0f), spot_total = splat(0.0f);
-    const uint32_t n_samples = cfg.direct_samples + cfg.spot_samples;
-    for (uint32_t k = 0u; k < n_samples; ++k) {  // wave-uniform
-        const bool has = (mask & (1u << k)) != 0u;
-        if (!__any(has)) continue;
-        float4 d = make_float4(0.0f, 0.0f, 1.0f, 0.0f), t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (has) d = f.nee_dir[size_t(k) * stride + p.local], t = f.nee_term[size_t(k) * stride + p.local];
-        Ray sr;
-        sr.o = V3(o.x, o.y, o.z), sr.d = V3(d.x, d.y, d.z), sr.near_ = 0.0f, sr.far_ = d.w;
-        if (has) { RZ_COUNT(shadow_rays); }
-        float v = 0.0f;
-        if (s.n_instances != 0u) v = any_hit_coop<COUNT, RZ_SHADE_SHARED_RCP != 0>(s, lds, has, sr, cnt);
-        if (has) {
-            const col4 V_PL = splat(v);
-            const col4 term = (col4{t.x, t.y, t.z, t.w} * V_PL) * V_PL.a;
-            if (k < cfg.direct_samples) direct_total = direct_total + term;
-            else spot_total = spot_total + term;
-        }
-    }
-    if (p.active) {
-        const bool path_continues = (bits & 1u) != 0u;
-        col4 final_color{base.x, base.y, base.z, 0.0f};
-        if (bits & 2u) {
-            col4 dt = splat(0.0f), st = splat(0.0f);
-            if (s.n_direct_lights != 0u) dt = div_scalar(direct_total, float(cfg.direct_samples) / float(s.n_direct_lights));
-            if (s.n_spot_lights != 0u) st = div_scalar(spot_total, float(cfg.spot_samples) / float(s.n_spot_lights));
-            const col4 direct = dt + st;
-            const float4 a = f.nee_a[p.local], b = f.nee_b[p.local];
-            final_color = final_color + (direct * col4{a.x, a.y, a.z, a.w}) * col4{b.x, b.y, b.z, b.w};
-        }
-        col4 value;
-        if constexpr (FIRST) {
-            value = col4{final_color.r, final_color.g, final_color.b, float(!path_continues)};
-        } else {
-            const float4 acc = f.accum[p.local];
-            value = col4{acc.x + final_color.r, acc.y + final_color.g, acc.z + final_color.b, acc.w + float(!path_continues)};
-        }
-        f.accum[p.local] = make_float4(value.r, value.g, value.b, value.a);
-    }
-    flush_counters<COUNT>(f, 0u, cnt);
-}
 
 // passUpdate / segmentUpdate (cuda_postprocess_kernel.cu:95-104, cuda_render_kernel.cu:122-129):
 // the pass index lives on the device so a captured graph replays without new arguments.
@@ -1079,15 +87,15 @@ __global__ void __launch_bounds__(256) rz_untile_state_kernel(const float4* st0,
 
 // Kernel::rayCast (cpu_engine_kernel.cpp:102-111, 483-501): one thread.
 __global__ void rz_pick_kernel(const DScene s, const DCamera cam, uint32_t x, uint32_t y, float depth, int32_t* out2) {
-    uint32_t* rz_lds = nullptr;
     Ray ray;
     generate_simple_ray(cam, ray, x, y);
     ray.near_ = depth * 0.99f;
     ray.far_ = depth * 1.01f;
     Hit hit;
+    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
     Counters cnt;
     out2[0] = out2[1] = -1;
-    if (closest_hit<0, false, false>(s, rz_lds, ray, hit, cnt) == 2) {
+    if (s.n_instances != 0u && closest_hit_skip<false, false>(s, TopCache{nullptr, nullptr, 0u}, ray, hit, cnt) == 2) {
         const uint32_t inst = uint32_t(hit.instance);
         const uint32_t material_base = __float_as_uint(s.instances[7 * inst + 1].w);
         const uint32_t material_count = __float_as_uint(s.instances[7 * inst + 2].w);
@@ -1133,192 +141,16 @@ __global__ void __launch_bounds__(256) rz_selftest_div_kernel(uint32_t n_per_thr
 // =======================================================================================
 // Host side of the context
 // =======================================================================================
-namespace {
-
+namespace hiprz {
 thread_local std::string g_create_error;
-
-// Timer/TimeTable of the reference (engine_parts.hpp:34-74): last + EMA(0.05) per stage.
-struct TimeTable {
-    struct Entry {
-        std::string name;
-        double last_ms = 0, avg_ms = 0;
-        bool seen = false;
-    };
-    std::vector<Entry> entries;
-    void set(const char* name, double ms) {
-        for (auto& e : entries)
-            if (e.name == name) {
-                e.last_ms = ms;
-                e.avg_ms = e.seen ? e.avg_ms + (ms - e.avg_ms) * 0.05 : ms;
-                e.seen = true;
-                return;
-            }
-        entries.push_back({name, ms, ms, true});
-    }
-    std::string str() const {
-        std::string out;
-        char line[160];
-        for (const auto& e : entries) {
-            std::snprintf(line, sizeof line, "%-22s %9.3fms (avg %9.3fms)\n", e.name.c_str(), e.last_ms, e.avg_ms);
-            out += line;
-        }
-        return out;
-    }
-};
-struct StageTimer {
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
-};
-
-template <typename T>
-struct DeviceArray {
-    T* ptr = nullptr;
-    size_t count = 0;
-    hipError_t assign(const T* src, size_t n, hipStream_t stream) {
-        if (n > count || !ptr) {
-            if (ptr) (void)hipFree(ptr);
-            ptr = nullptr;
-            count = 0;
-            hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), sizeof(T) * (n ? n : 1));
-            if (e != hipSuccess) return e;
-            count = n ? n : 1;
-        }
-        if (n) return hipMemcpyAsync(ptr, src, sizeof(T) * n, hipMemcpyHostToDevice, stream);
-        return hipSuccess;
-    }
-    hipError_t resize(size_t n) {
-        if (n <= count && ptr) return hipSuccess;
-        if (ptr) (void)hipFree(ptr);
-        ptr = nullptr;
-        count = 0;
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), sizeof(T) * (n ? n : 1));
-        if (e == hipSuccess) count = n ? n : 1;
-        return e;
-    }
-    void release() {
-        if (ptr) (void)hipFree(ptr);
-        ptr = nullptr;
-        count = 0;
-    }
-};
-
-}  // namespace
-
-struct hiprz_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::string error;
-    TimeTable timings;
-
-    // scene mirror
-    DeviceArray<uint8_t> hot;  // nodes | tlas_order | instances | tris | tri_attrs | materials | inst_materials
-    DeviceArray<hiprz_node> wnodes;
-    DeviceArray<uint32_t> wskip;
-    DeviceArray<uint32_t> node_skip;
-    DeviceArray<uint32_t> nodes64;
-    int walk_order = 1;  // 0 = meshes in the reference's child order, 1 = front-to-back, 2 = also when counting (hiprz_set_walk_order)
-    DeviceArray<hiprz_texture> textures;
-    DeviceArray<uint8_t> texels;
-    DeviceArray<hiprz_spot_light> spot_lights;
-    DeviceArray<hiprz_direct_light> direct_lights;
-    DScene dscene{};
-    bool have_scene = false;
-    uint32_t stack_entries = 2;  // LDS stack entries per lane the trees need (MODE 1)
-    bool lds_scene = false;      // hot blob is staged into LDS by every workgroup
-    int lds_scene_override = -1; // -1 auto, 0 never, 1 always (if it fits at all)
-
-    // camera + per-pixel state
-    hiprz_camera camera{};
-    DCamera dcamera{};
-    bool have_camera = false;
-    uint32_t rank = 0, world = 1;
-    uint32_t tiles_x = 0, tiles_y = 0, n_local_tiles = 0;
-    uint64_t owned_pixels = 0;
-    DeviceArray<float4> st0, st1, accum, hit0;
-    DeviceArray<uint32_t> hit1;
-    // 0 fused (one kernel per pass), 1 split (trace kernel -> shade kernel per pass), 2 resident (one kernel per batch
-    // of passes).  -1: resident when the scene is staged in LDS (config B: as fast as split on a whole frame, 2.26 ms per
-    // 8 passes, and 0.34 vs 0.45 ms on an eighth of it — per-pass launch/ramp/tail costs vanish), else split (10-20 % faster
-    // than fused on configs C, D; the resident kernel has no LDS room for the tree-top cache).
-    int pipeline_setting = -1;
-    int pipeline = 1;  // resolved by resolve_pipeline() at upload / set time
-    bool rgba8_valid = false;  // the resident kernel tone-maps on its way out: hiprz_tonemap has nothing to do
-    DeviceArray<float2> st2;
-    DeviceArray<float> depth;
-    DeviceArray<uint32_t> rgba8;
-    DeviceArray<float4> image_f4;  // row-major staging for readback
-    DeviceArray<uint32_t> state_md;
-    DeviceArray<float> state_ray;
-    DeviceArray<uint32_t> pass_dev;
-    DeviceArray<unsigned long long> counters_dev;
-    DeviceArray<int32_t> pick_dev;
-
-    hiprz_config config{8u, 8u, 1u, 1u, 20240501u};
-    bool reset_pending = true;
-    uint32_t passes = 0;
-    uint64_t ray_count = 0;
-    int traversal_mode = -1;  // -1 = choose per scene (effective_mode)
-    // MODE 5: two ping-pong ray queues (48 B per entry, one entry per owned pixel each), per-round counters and the
-    // schedule: requeue_thresholds[r] = lanes that must remain in a mesh walk during round r (the final round never bails)
-    DeviceArray<uint4> rq0[2];
-    DeviceArray<float4> rq1[2], rq2[2];
-    DeviceArray<uint32_t> rq_counts;
-    std::vector<uint32_t> requeue_thresholds{40u, 40u, 32u, 32u, 24u, 16u};
-
-    // hipGraph of one batch of cumulative passes ([pass kernel, pass update] x n): replayed while nothing that
-    // the captured kernel arguments depend on has changed (scene, camera, config, shard, variants)
-    hipGraphExec_t graph_exec = nullptr;
-    uint32_t graph_passes = 0;
-    bool graph_valid = false;
-    // ray reordering between passes (split pipeline): keys from the shade kernel -> radix sort -> permutation
-    DeviceArray<uint32_t> sort_keys, sort_keys_out, sort_iota, sort_perm;
-    DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
-    int coop_walk = 1;    // front-to-back walk with the cooperative triangle phase (rz_trace_coop_kernel); HIPRZ_COOP=0: rz_trace_skip_kernel
-    int coop_shadow = 1;  // deferred shadow rays in rz_shadow_coop_kernel (HIPRZ_COOP_SHADOW=0: rz_shadow_kernel)
-    uint32_t n_textures = 0;  // of the uploaded scene
-    int batch_waves = 0;  // HIPRZ_BATCH_WAVES=4: never the 5-wave build of the plain batch kernel
-    int nolight_kernels = 1;  // scenes without lights use the instantiations without next-event estimation (HIPRZ_NOLIGHT_KERNELS=0: the general ones)
-    int sort_bits = 0;    // most significant key bits the radix sorts look at; 0 = by frame size (HIPRZ_SORT_BITS)
-    int shadow_sort = 1;  // HIPRZ_SHADOW_SORT=0: the shadow kernel follows the next pass's ray order instead
-    DeviceArray<uint8_t> sort_temp;
-    size_t sort_temp_bytes = 0;
-    int sort_rays = -1;  // -1 auto (on for scenes walked with MODE 3), 0 off, 1 on
-    DeviceArray<unsigned long long> wg_times;  // diagnostics: start / end clock of every trace-kernel workgroup of the last pass
-    bool wg_timing = false;
-    uint32_t pool_threshold = 32u;  // MODE 6: lanes that must be inside meshes for the mesh phase to go on while others could join
-    bool sorted_this_pass = false;  // the deferred shadow kernel wants the NEXT pass's ray order: the sort then runs before it
-    bool defer_shadow_rays = true;  // HIPRZ_DEFER_SHADOWS=0: walk them inside the shade kernel
-    DeviceArray<float4> nee_base, nee_a, nee_b, nee_point, nee_dir, nee_term;
-    int shade_shadow_walk = 3;  // shade kernel of scenes not staged in LDS: 3 = skip links + staged tree tops, 1 = LDS stack (HIPRZ_SHADOW_WALK)
-    int trace_wg = 64;    // MODE 3 trace kernel: 64 = one wave per workgroup (rz_trace_skip_kernel); HIPRZ_TRACE_WG=256: the 256-thread kernel
-    int trace_waves = 0;  // 0 = by tree size; HIPRZ_TRACE_WAVES = 4 | 6 forces the register budget
-    uint32_t n_nodes = 0;
-    bool time_kernels = false;  // record events around the trace and the shade kernel of every pass of a batch
-    std::vector<hipEvent_t> kernel_events;
-    uint32_t kernel_event_passes = 0;
-    bool use_graph = true;
-    bool xcd_swizzle = false;  // measured: banding the image per XCD concentrates the expensive region on few XCDs (D: 4.3 -> 5.1 ms)
-
-    // kernel timing (hip events on `stream` around each render batch)
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
-    std::vector<uint32_t> pending_launches;
-    std::vector<hipEvent_t> event_pool;
-};
-
-namespace {
-
 int fail(hiprz_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->error = msg;
     else g_create_error = msg;
     return code;
 }
+}  // namespace hiprz
 
-#define RZ_HIP(ctx, call)                                                                                       \
-    do {                                                                                                        \
-        hipError_t rz_e = (call);                                                                               \
-        if (rz_e != hipSuccess)                                                                                 \
-            return fail(ctx, HIPRZ_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(rz_e));           \
-    } while (0)
+namespace {
 
 struct TreeCheck {
     const hiprz_scene* sc;
@@ -1366,7 +198,6 @@ struct TreeCheck {
 void release_frame(hiprz_ctx* c) {
     c->st0.release(), c->st1.release(), c->st2.release(), c->accum.release(), c->depth.release(), c->rgba8.release();
     c->hit0.release(), c->hit1.release();
-    for (int k = 0; k < 2; ++k) c->rq0[k].release(), c->rq1[k].release(), c->rq2[k].release();
     c->nee_base.release(), c->nee_a.release(), c->nee_b.release(), c->nee_point.release(), c->nee_dir.release(), c->nee_term.release();
     c->sort_keys.release(), c->sort_keys_out.release(), c->sort_iota.release(), c->sort_perm.release(), c->sort_temp.release(), c->shadow_keys.release(), c->shadow_perm.release();
     c->image_f4.release(), c->state_md.release(), c->state_ray.release();
@@ -1408,11 +239,8 @@ int allocate_frame(hiprz_ctx* c) {
         RZ_HIP(c, hipMemsetAsync(c->sort_keys.ptr, 0, n * sizeof(uint32_t), c->stream));
         RZ_HIP(c, hipMemsetAsync(c->shadow_keys.ptr, 0, n * sizeof(uint32_t), c->stream));
         RZ_HIP(c, hipStreamSynchronize(c->stream));
-        size_t bytes = 0;
-        RZ_HIP(c, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, c->sort_keys.ptr, c->sort_keys_out.ptr, c->sort_iota.ptr,
-                                                     c->sort_perm.ptr, int(n), 0, 24, c->stream));
-        RZ_HIP(c, c->sort_temp.resize(bytes));
-        c->sort_temp_bytes = bytes;
+        const int src = sort_workspace(c, n);
+        if (src != HIPRZ_OK) return src;
     }
     RZ_HIP(c, c->depth.resize(n));
     RZ_HIP(c, c->rgba8.resize(n));
@@ -1428,12 +256,12 @@ int allocate_frame(hiprz_ctx* c) {
     return HIPRZ_OK;
 }
 
-constexpr uint32_t kLatencyBoundNodes = 32768u;  // trees beyond ~1 MiB of nodes: fetches come from L2 / HBM, occupancy hides them
-int effective_mode(const hiprz_ctx* c);
-void resolve_pipeline(hiprz_ctx* c);
-bool defer_shadows(const hiprz_ctx* c);
-bool use_lds_scene(const hiprz_ctx* c);
 bool resident_active(const hiprz_ctx* c) { return c->pipeline == 2; }
+
+}  // namespace
+
+namespace hiprz {
+
 // rays are reordered where the walk is bound by scattered fetches: scenes not staged in LDS, split pipeline
 bool sort_enabled(const hiprz_ctx* c) {
     if (c->pipeline != 1 || c->sort_rays == 0) return false;
@@ -1454,7 +282,6 @@ DFrame make_frame(hiprz_ctx* c, bool counted) {
     f.counters = counted ? c->counters_dev.ptr : nullptr;
     f.tiles_x = c->tiles_x, f.rank = c->rank, f.world = c->world, f.n_local_tiles = c->n_local_tiles;
     f.xcd_swizzle = c->xcd_swizzle ? 1u : 0u;
-    f.wg_times = c->wg_timing ? c->wg_times.ptr : nullptr;
     f.nee_base = c->nee_base.ptr, f.nee_a = c->nee_a.ptr, f.nee_b = c->nee_b.ptr;
     f.nee_point = c->nee_point.ptr, f.nee_dir = c->nee_dir.ptr, f.nee_term = c->nee_term.ptr;
     const bool sorting = sort_enabled(c);
@@ -1475,9 +302,7 @@ DConfig make_config(const hiprz_ctx* c) {
 // and the nested walk is faster (config C: 1 668 vs 2 450 us).
 int effective_mode(const hiprz_ctx* c) {
     if (c->traversal_mode >= 0) return c->traversal_mode;
-    // records do not fit LDS: nested skip-link walk with cached tree tops.  (MODE 4, persistent lanes on the flat walk
-    // graph, is selectable but measured slower — config D 6.1 vs 3.5 ms: once lanes are desynchronised every loop
-    // iteration pays for the instance-entry / exit / refill blocks.)
+    // records do not fit LDS: skip-link walks in single-wave workgroups
     if (!c->lds_scene && c->pipeline == 1) return 3;
     return c->dscene.mesh_stack_entries <= 2u ? 2 : 1;
 }
@@ -1490,6 +315,7 @@ bool defer_shadows(const hiprz_ctx* c) {
 }
 
 void resolve_pipeline(hiprz_ctx* c) {
+    const int before = c->pipeline;
     if (c->pipeline_setting >= 0) c->pipeline = c->pipeline_setting;
     else {
         // resident needs blob + walk workspace + 8 KiB of parked state per workgroup, four workgroups per CU
@@ -1497,11 +323,8 @@ void resolve_pipeline(hiprz_ctx* c) {
         const bool mode_ok = c->traversal_mode == -1 || c->traversal_mode == 1 || c->traversal_mode == 2;  // walks the batch kernel has
         c->pipeline = (c->have_scene && c->lds_scene && c->lds_scene_override != 0 && mode_ok && lds <= 40u * 1024u) ? 2 : 1;
     }
+    if (c->pipeline != before) c->graph_valid = false;
 }
-
-constexpr uint32_t kTopCacheNodes = 682u;  // 682 x 36 B = 24 KiB per workgroup: ~9 levels of every tree, 5 workgroups per CU
-
-constexpr size_t kLdsSceneLimit = 52u * 1024u;  // per workgroup: 3 x 52 KiB < 160 KiB per CU
 
 bool use_lds_scene(const hiprz_ctx* c) {
     if (c->lds_scene_override == 0) return false;
@@ -1509,155 +332,48 @@ bool use_lds_scene(const hiprz_ctx* c) {
     return c->lds_scene;
 }
 
-void launch_sort(hiprz_ctx* c);
-void launch_shadow_sort(hiprz_ctx* c);
-template <bool FIRST, bool COUNT>
-void launch_pass(hiprz_ctx* c, const DFrame& f, hipEvent_t between_trace_and_shade = nullptr) {
-    c->sorted_this_pass = false;
+
+// Two radix passes (16 key bits) are enough while a bin of the coarser order still holds a wave's worth of rays: up to ~2 M owned
+// pixels (config C: step 4.53 -> 4.33 ms, the sort 88 -> 59 us per pass).  Bigger frames and scenes with lights (whose shadow rays
+// follow a sorted order of their own) keep all 24 bits (config E: 16 bits 55.9 ms per step against 51.0).
+int effective_sort_bits(const hiprz_ctx* c) {
+    if (c->sort_bits > 0) return c->sort_bits;
+    const bool lights = c->dscene.n_spot_lights + c->dscene.n_direct_lights != 0u;
+    return (!lights && size_t(c->n_local_tiles) * 256u <= (size_t(32) << 16)) ? 16 : 24;
+}
+
+PassGeometry pass_geometry(const hiprz_ctx* c) {
+    PassGeometry g;
     // with the XCD swizzle the grid is padded to a multiple of 8 workgroups (the extra ones find no tile)
-    const dim3 grid(c->xcd_swizzle ? ((c->n_local_tiles + 7u) / 8u) * 8u : c->n_local_tiles), block(256);
-    const DConfig cfg = make_config(c);
-    const bool lds_scene = use_lds_scene(c);
-    const size_t blob = lds_scene ? c->dscene.hot_bytes : 0u;
-    int mode = effective_mode(c);
-    if (mode >= 3 && (lds_scene || c->pipeline != 1)) mode = 1;  // the top cache is for scenes that are not staged whole, in the trace kernel
-    const size_t stack_lds = size_t(c->stack_entries) * 256u * sizeof(uint32_t);
-    const size_t walk_lds = mode == 2 ? size_t(BinnedLds::bytes_host(c->dscene.world_stack_entries, c->dscene.mesh_stack_entries))
-                            : mode == 1 ? stack_lds : 0u;
-#define RZ_LAUNCH(kernel_lds, kernel_global, lds_bytes, ...)                                                        \
-    do {                                                                                                            \
-        if (lds_scene) hipLaunchKernelGGL(kernel_lds, grid, block, blob + (lds_bytes), c->stream, __VA_ARGS__);     \
-        else hipLaunchKernelGGL(kernel_global, grid, block, (lds_bytes), c->stream, __VA_ARGS__);                   \
-    } while (0)
+    g.grid = dim3(c->xcd_swizzle ? ((c->n_local_tiles + 7u) / 8u) * 8u : c->n_local_tiles), g.block = dim3(256);
+    g.lds_scene = use_lds_scene(c);
+    g.blob = g.lds_scene ? c->dscene.hot_bytes : 0u;
+    g.mode = effective_mode(c);
+    if (g.mode >= 3 && (g.lds_scene || c->pipeline != 1)) g.mode = 1;  // skip links are for scenes that are not staged whole, in the trace kernel
+    g.stack_lds = size_t(c->stack_entries) * 256u * sizeof(uint32_t);
+    g.walk_lds = g.mode == 2 ? size_t(BinnedLds::bytes_host(c->dscene.world_stack_entries, c->dscene.mesh_stack_entries)) : g.mode == 1 ? g.stack_lds : 0u;
+    return g;
+}
+
+}  // namespace hiprz
+
+namespace {
+
+// one pass on the stream: trace + shade (split pipeline) or the fused kernel
+void launch_pass(hiprz_ctx* c, const DFrame& f, bool first, bool counted, hipEvent_t between_trace_and_shade = nullptr) {
+    c->sorted_this_pass = false;
     if (c->pipeline == 1) {
-        if (mode == 4) {
-            const uint32_t pools = (c->n_local_tiles + RZ_POOL_FACTOR - 1u) / RZ_POOL_FACTOR;
-            hipLaunchKernelGGL((rz_trace_persistent_kernel<FIRST, COUNT>), dim3(pools), block, c->dscene.wtop_count * 36u + 16u, c->stream, c->dscene, c->dcamera, f);
-        } else if (mode == 5) {
-            // round 0 over all owned pixels, then one launch per scheduled round over the rays the previous one queued
-            // (the grid is sized for the worst case; workgroups past the queue's end return at once)
-            const uint32_t rounds = uint32_t(c->requeue_thresholds.size());
-            const size_t top_lds = TopCache::bytes_host(c->dscene.top_count);
-            (void)hipMemsetAsync(c->rq_counts.ptr, 0, (rounds + 2u) * sizeof(uint32_t), c->stream);
-            for (uint32_t r = 0; r <= rounds; ++r) {
-                const int in = int((r + 1u) & 1u), out = int(r & 1u);
-                DRequeue q{c->rq0[in].ptr, c->rq1[in].ptr, c->rq2[in].ptr, c->rq0[out].ptr, c->rq1[out].ptr, c->rq2[out].ptr,
-                           c->rq_counts.ptr, r, r < rounds ? c->requeue_thresholds[r] : 0u};
-                if (r == 0 && rounds > 0) hipLaunchKernelGGL((rz_trace_requeue_kernel<FIRST, COUNT, true, true>), grid, block, top_lds, c->stream, c->dscene, c->dcamera, f, q);
-                else if (r == 0) hipLaunchKernelGGL((rz_trace_requeue_kernel<FIRST, COUNT, true, false>), grid, block, top_lds, c->stream, c->dscene, c->dcamera, f, q);
-                else if (r < rounds) hipLaunchKernelGGL((rz_trace_requeue_kernel<FIRST, COUNT, false, true>), grid, block, top_lds, c->stream, c->dscene, c->dcamera, f, q);
-                else hipLaunchKernelGGL((rz_trace_requeue_kernel<FIRST, COUNT, false, false>), grid, block, top_lds, c->stream, c->dscene, c->dcamera, f, q);
-            }
-        } else if (mode == 6) {
-            // persistent 64-lane workgroups: as many as the chip holds at once (256 CUs x 4 SIMDs x RZ_POOL_MIN_WAVES), but no
-            // more than there are waves of rays
-            const uint32_t top_n = std::min<uint32_t>(c->dscene.top_count, kTopCacheNodes / 4u);
-            const uint32_t waves = std::min<uint32_t>(c->n_local_tiles * 4u, 256u * 4u * RZ_POOL_MIN_WAVES);
-            (void)hipMemsetAsync(c->rq_counts.ptr, 0, sizeof(uint32_t), c->stream);
-            hipLaunchKernelGGL((rz_trace_pool_kernel<FIRST, COUNT>), dim3(waves), dim3(64), TopCache::bytes_host(top_n), c->stream, c->dscene,
-                               c->dcamera, f, top_n, c->rq_counts.ptr, c->pool_threshold);
-        } else if (mode == 3 && c->trace_wg != 256) {
-            const uint32_t n_wg = c->n_local_tiles * 4u;
-            const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;
-            // tree-top cache: 160 KiB of LDS over 24 (6 waves per SIMD) or 16 (4) single-wave workgroups per CU
-            if (COUNT ? c->walk_order == 2 : c->walk_order != 0) {  // front-to-back mesh walks: 48 B of LDS per cached node instead of 36
-                if (c->coop_walk) {
-                    // cooperative triangle phase; 4 waves per SIMD for every tree size (D: 1 037 us against 1 131 us with 6 waves)
-                    if (c->trace_waves >= 6) hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 6>), dim3(n_wg), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
-                    else hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 4>), dim3(n_wg), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
-                } else {
-                const size_t park = TopCache::park_bytes_host();  // no tree-top cache: see fetch_node_ordered
-                if (big_trees) hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 6, true>), dim3(n_wg), dim3(64), park, c->stream, c->dscene, c->dcamera, f, 0u);
-                else hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 4, true>), dim3(n_wg), dim3(64), park, c->stream, c->dscene, c->dcamera, f, 0u);
-                }
-            } else {
-                const uint32_t top_n = std::min<uint32_t>(c->dscene.top_count, big_trees ? 170u : 272u);
-                if (big_trees) hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 6, false>), dim3(n_wg), dim3(64), TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, f, top_n);
-                else hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 4, false>), dim3(n_wg), dim3(64), TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, f, top_n);
-            }
-        } else if (mode == 3) hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 3, false>), grid, block, TopCache::bytes_host(c->dscene.top_count), c->stream, c->dscene, c->dcamera, f);
-        else if (mode == 2) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 2, true>), (rz_trace_kernel<FIRST, COUNT, 2, false>), walk_lds, c->dscene, c->dcamera, f);
-        else if (mode == 1) RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 1, true>), (rz_trace_kernel<FIRST, COUNT, 1, false>), walk_lds, c->dscene, c->dcamera, f);
-        else RZ_LAUNCH((rz_trace_kernel<FIRST, COUNT, 0, true>), (rz_trace_kernel<FIRST, COUNT, 0, false>), walk_lds, c->dscene, c->dcamera, f);
+        launch_trace(c, f, first, counted);
         if (between_trace_and_shade) (void)hipEventRecord(between_trace_and_shade, c->stream);
-        // shadow rays: LDS-stack walk on a staged scene, skip-link walk with staged tree tops otherwise (no lights: no walk at all)
-        const bool lights = c->dscene.n_spot_lights + c->dscene.n_direct_lights != 0u;
-        const uint32_t shade_top = std::min<uint32_t>(c->dscene.top_count, kTopCacheNodes);
-        if (!lights && c->nolight_kernels && c->n_textures == 0u) {  // no lights, no maps
-            if (lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_PLAIN>), grid, block, blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-            else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_PLAIN>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-        } else if (!lights && c->nolight_kernels) {  // no next-event estimation: the instantiation without it (no shadow walk, no LDS stack)
-            if (lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_NONE>), grid, block, blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-            else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_NONE>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-        } else if (lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, 1>), grid, block, blob + stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-        else if (lights && defer_shadows(c)) {
-            // shading without shadow walks, then every shadow ray of the pass in a lean single-wave kernel
-            hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-            // the shadow rays start where the next segment's rays start: walk them in the order the next trace kernel will use
-            // (origin cell + direction of the next ray), so that a wave's rays meet the same instances
-            launch_sort(c);
-            if (f.shadow_key) launch_shadow_sort(c);
-            const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;
-            const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
-            if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) && c->coop_shadow) {
-                hipLaunchKernelGGL((rz_shadow_coop_kernel<FIRST, COUNT, 4>), sgrid, sblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
-            } else if (COUNT ? c->walk_order == 2 : c->walk_order != 0) {
-                if (big_trees) hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 6, true>), sgrid, sblock, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-                else hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 4, true>), sgrid, sblock, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-            } else {
-                const uint32_t top_n = std::min<uint32_t>(c->dscene.top_count, big_trees ? 170u : 272u);
-                if (big_trees) hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 6, false>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
-                else hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 4, false>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
-            }
-        } else if (lights && c->shade_shadow_walk == 3) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, 3>), grid, block, TopCache::bytes_host(shade_top), c->stream, c->dscene, c->dcamera, cfg, f, shade_top);
-        else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, 1>), grid, block, stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        launch_shade(c, f, first, counted);
     } else {
-        // the fused kernel's shadow rays use the stack walk: its columns must exist in every mode
-        const size_t fused_lds = mode == 0 ? stack_lds : mode == 2 ? walk_lds + 4096u : walk_lds;  // mode 2: + the parked path state
-        if (mode == 2) RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 2, true>), (rz_pass_kernel<FIRST, COUNT, 2, false>), fused_lds, c->dscene, c->dcamera, cfg, f);
-        else if (mode == 1) RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 1, true>), (rz_pass_kernel<FIRST, COUNT, 1, false>), fused_lds, c->dscene, c->dcamera, cfg, f);
-        else RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 0, true>), (rz_pass_kernel<FIRST, COUNT, 0, false>), fused_lds, c->dscene, c->dcamera, cfg, f);
+        launch_fused(c, f, first, counted);
     }
-#undef RZ_LAUNCH
 }
 
 // resident pipeline: all `n` cumulative passes of the batch in one launch (+ one launch that advances the pass index)
-template <bool COUNT>
-void launch_batch(hiprz_ctx* c, const DFrame& f, uint32_t n, hipEvent_t before = nullptr, hipEvent_t after = nullptr) {
-    const dim3 grid(c->xcd_swizzle ? ((c->n_local_tiles + 7u) / 8u) * 8u : c->n_local_tiles), block(256);
-    const DConfig cfg = make_config(c);
-    const bool lds_scene = use_lds_scene(c);
-    const size_t blob = lds_scene ? c->dscene.hot_bytes : 0u;
-    int mode = effective_mode(c);
-    if (mode != 2) mode = 1;
-    const size_t stack_lds = size_t(c->stack_entries) * 256u * sizeof(uint32_t);
-    const size_t walk_lds = mode == 2 ? size_t(BinnedLds::bytes_host(c->dscene.world_stack_entries, c->dscene.mesh_stack_entries)) : stack_lds;
-    const size_t park = 8u * 1024u;
-    const size_t lds = blob + walk_lds + park;
-    const uint32_t park_offset = uint32_t(walk_lds);
-    if (before) (void)hipEventRecord(before, c->stream);
-    // scenes without lights run the instantiation whose next-event-estimation code is compiled out (RZ_SHADOW_NONE), scenes that
-    // have no maps either the one without texture fetches and normal mapping (RZ_SHADOW_PLAIN)
-    const bool dark = c->dscene.n_spot_lights + c->dscene.n_direct_lights == 0u && c->nolight_kernels;
-    const bool plain = dark && c->n_textures == 0u;
-    // 5 workgroups per CU must fit LDS, and the grid must be more than two full loads of the chip (256 CUs x 5)
-    const bool five = lds * 5u <= 160u * 1024u && grid.x > 2u * 5u * 256u && c->batch_waves != 4;
-#define RZ_BATCH(M, L)                                                                                                                     \
-    do {                                                                                                                                   \
-        if (plain && five) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_PLAIN, 5>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
-        else if (plain) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_PLAIN>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
-        else if (dark) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_NONE>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
-        else hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, 1>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);     \
-    } while (0)
-    if (mode == 2) {
-        if (lds_scene) RZ_BATCH(2, true);
-        else RZ_BATCH(2, false);
-    } else {
-        if (lds_scene) RZ_BATCH(1, true);
-        else RZ_BATCH(1, false);
-    }
-#undef RZ_BATCH
-    if (after) (void)hipEventRecord(after, c->stream);
+void launch_resident(hiprz_ctx* c, const DFrame& f, uint32_t n, bool counted, hipEvent_t before = nullptr, hipEvent_t after = nullptr) {
+    launch_batch(c, f, n, counted, before, after);
     hipLaunchKernelGGL(rz_pass_add_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr, n);
     c->rgba8_valid = true;
 }
@@ -1674,41 +390,18 @@ hipEvent_t take_event(hiprz_ctx* c) {
 }
 
 void drop_graph(hiprz_ctx* c) {
+    // a replay of the old exec may still be in flight on the stream (an asynchronous caller that changes a setting between
+    // two render calls): wait for it before the exec goes away
+    if (c->graph_exec && c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     c->graph_exec = nullptr;
     c->graph_valid = false;
 }
 
-// Two radix passes (16 key bits) are enough while a bin of the coarser order still holds a wave's worth of rays: up to ~2 M owned
-// pixels (config C: step 4.53 -> 4.33 ms, the sort 88 -> 59 us per pass).  Bigger frames and scenes with lights (whose shadow rays
-// follow a sorted order of their own) keep all 24 bits (config E: 16 bits 55.9 ms per step against 51.0).
-int effective_sort_bits(const hiprz_ctx* c) {
-    if (c->sort_bits > 0) return c->sort_bits;
-    const bool lights = c->dscene.n_spot_lights + c->dscene.n_direct_lights != 0u;
-    return (!lights && size_t(c->n_local_tiles) * 256u <= (size_t(32) << 16)) ? 16 : 24;
-}
-
-// radix sort of the keys the shade kernel just wrote -> permutation the next trace kernel follows
-void launch_sort(hiprz_ctx* c) {
-    if (!sort_enabled(c) || c->n_local_tiles == 0 || c->sorted_this_pass) return;
-    c->sorted_this_pass = true;
-    size_t bytes = c->sort_temp_bytes;
-    (void)hipcub::DeviceRadixSort::SortPairs(c->sort_temp.ptr, bytes, c->sort_keys.ptr, c->sort_keys_out.ptr, c->sort_iota.ptr,
-                                             c->sort_perm.ptr, int(c->n_local_tiles * 256u), 24 - effective_sort_bits(c), 24, c->stream);
-}
-
-// the same for the keys of the pass's shadow rays -> the order rz_shadow_kernel follows
-void launch_shadow_sort(hiprz_ctx* c) {
-    if (c->n_local_tiles == 0) return;
-    size_t bytes = c->sort_temp_bytes;
-    (void)hipcub::DeviceRadixSort::SortPairs(c->sort_temp.ptr, bytes, c->shadow_keys.ptr, c->sort_keys_out.ptr, c->sort_iota.ptr,
-                                             c->shadow_perm.ptr, int(c->n_local_tiles * 256u), 24 - effective_sort_bits(c), 24, c->stream);
-}
-
 // [cumulative pass, sort, pass update] x n on the stream — eagerly, or into a capture
 void enqueue_cumulative(hiprz_ctx* c, const DFrame& f, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) {
-        launch_pass<false, false>(c, f);
+        launch_pass(c, f, false, false);
         launch_sort(c);
         hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
     }
@@ -1743,16 +436,6 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
         RZ_HIP(c, c->nee_dir.resize(n * k));
         RZ_HIP(c, c->nee_term.resize(n * k));
     }
-    if (effective_mode(c) == 6) RZ_HIP(c, c->rq_counts.resize(32));
-    if (effective_mode(c) == 5 && c->pipeline == 1 && !use_lds_scene(c)) {
-        const size_t n = size_t(c->n_local_tiles) * 256u;
-        for (int k = 0; k < 2; ++k) {
-            RZ_HIP(c, c->rq0[k].resize(n));
-            RZ_HIP(c, c->rq1[k].resize(n));
-            RZ_HIP(c, c->rq2[k].resize(n));
-        }
-        RZ_HIP(c, c->rq_counts.resize(32));
-    }
     const DFrame f = make_frame(c, counted);
     hipEvent_t e0 = take_event(c), e1 = take_event(c);
     RZ_HIP(c, hipEventRecord(e0, c->stream));
@@ -1761,8 +444,7 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
         uint32_t remaining = n_passes;
         if (c->reset_pending) {  // renderFirstPass: the fused kernel
             hipLaunchKernelGGL(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
-            if (counted) launch_pass<true, true>(c, f);
-            else launch_pass<true, false>(c, f);
+            launch_pass(c, f, true, counted);
             hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
             c->reset_pending = false;
             c->passes = 1;
@@ -1771,16 +453,16 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
         }
         if (remaining) {
             c->kernel_event_passes = 0;
-            if (counted) launch_batch<true>(c, f, remaining);
+            if (counted) launch_resident(c, f, remaining, true);
             else if (c->time_kernels) {  // bench.py's roofline: the batch kernel's own duration
                 while (c->kernel_events.size() < 3u) {
                     hipEvent_t e = nullptr;
                     (void)hipEventCreate(&e);
                     c->kernel_events.push_back(e);
                 }
-                launch_batch<false>(c, f, remaining, c->kernel_events[0], c->kernel_events[1]);
+                launch_resident(c, f, remaining, false, c->kernel_events[0], c->kernel_events[1]);
                 c->kernel_event_passes = remaining;
-            } else launch_batch<false>(c, f, remaining);
+            } else launch_resident(c, f, remaining, false);
             c->passes += remaining;
             c->ray_count += uint64_t(remaining) * c->owned_pixels;
         }
@@ -1820,7 +502,7 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     for (uint32_t i = 0; i < n_passes; ++i) {
         if (timed) {
             (void)hipEventRecord(c->kernel_events[3 * i], c->stream);
-            launch_pass<false, false>(c, f, c->kernel_events[3 * i + 1]);
+            launch_pass(c, f, false, false, c->kernel_events[3 * i + 1]);
             (void)hipEventRecord(c->kernel_events[3 * i + 2], c->stream);
             launch_sort(c);
             hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
@@ -1830,14 +512,12 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
         }
         if (c->reset_pending) {
             hipLaunchKernelGGL(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
-            if (counted) launch_pass<true, true>(c, f);
-            else launch_pass<true, false>(c, f);
+            launch_pass(c, f, true, counted);
             c->reset_pending = false;
             c->passes = 0;
             c->ray_count = 0;
         } else {
-            if (counted) launch_pass<false, true>(c, f);
-            else launch_pass<false, false>(c, f);
+            launch_pass(c, f, false, counted);
         }
         launch_sort(c);
         hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
@@ -1935,11 +615,11 @@ int check_scene(const hiprz_scene* sc, SceneCheck& out) {
     return HIPRZ_OK;
 }
 
-// Device-side tables derived from a validated scene (pure host): relayouted nodes + links, walk graph.
+// Device-side tables derived from a validated scene (pure host): relayouted nodes + links (reference order and per octant).
 struct DerivedTables {
     std::vector<uint32_t> new_index;
-    std::vector<hiprz_node> dnodes, wnodes;
-    std::vector<uint32_t> dskip, wskip;
+    std::vector<hiprz_node> dnodes;
+    std::vector<uint32_t> dskip;
     std::vector<uint32_t> dskip8;  // [node][octant]: skip links of the front-to-back mesh walk (hiprz_device.hpp: fetch_node_ordered)
 };
 int derive_tables(const hiprz_scene* sc, SceneCheck& chk, DerivedTables& out) {
@@ -1993,64 +673,26 @@ int derive_tables(const hiprz_scene* sc, SceneCheck& chk, DerivedTables& out) {
         }
     }
 
-    // ---- walk graph of the threaded traversal (hiprz_device.hpp: walk_threaded), in the relayouted numbering ----
-    // every world-tree leaf becomes a CHAIN node whose `begin` points at a run of INSTANCE pseudo-nodes
-    // (box = instance box, begin = instance id) appended after the real nodes and linked by skip; the last one
-    // links to whatever follows the leaf.
-    std::vector<hiprz_node>& wnodes = out.wnodes;
-    std::vector<uint32_t>& wskip = out.wskip;
-    wnodes = dnodes;
-    wskip.assign(dskip.begin(), dskip.begin() + sc->n_nodes);
-    for (auto& n : wnodes) {
-        const bool leaf = (n.meta & HIPRZ_NODE_LEAF) != 0;
-        n.meta = ((leaf ? RZ_WALK_TRIS : RZ_WALK_INNER) << RZ_WALK_TYPE_SHIFT) | (leaf ? (n.meta & HIPRZ_NODE_COUNT_MASK) : 0u);
-    }
-    for (uint32_t old_leaf : chk.world_leaves) {
-        const uint32_t leaf = new_index[old_leaf];
-        const hiprz_node src = dnodes[leaf];
-        const uint32_t count = src.meta & HIPRZ_NODE_COUNT_MASK;
-        if (count == 0) continue;  // stays an empty TRIS leaf: box test, then follow the link
-        const uint32_t chain = uint32_t(wnodes.size());
-        for (uint32_t k = 0; k < count; ++k) {
-            const uint32_t inst = sc->tlas_order[src.begin + k];
-            hiprz_node p{};
-            std::memcpy(p.bb_min, sc->instances[inst].bb_min, 12);
-            std::memcpy(p.bb_max, sc->instances[inst].bb_max, 12);
-            p.begin = inst;
-            p.meta = RZ_WALK_INSTANCE << RZ_WALK_TYPE_SHIFT;
-            wnodes.push_back(p);
-            wskip.push_back(k + 1 < count ? chain + k + 1 : wskip[leaf]);
-        }
-        wnodes[leaf].begin = chain;
-        wnodes[leaf].meta = (RZ_WALK_CHAIN << RZ_WALK_TYPE_SHIFT) | count;
-    }
     // The kernels follow these derived tables blindly: prove on the host that every walk over them terminates
     // (each step moves strictly forward in depth-first order, so a walk may take at most one step per node).
     {
-        auto terminates = [](const std::vector<hiprz_node>& nodes, const std::vector<uint32_t>& links, uint32_t root, bool walk_graph) {
+        auto terminates = [](const std::vector<hiprz_node>& nodes, const std::vector<uint32_t>& links, uint32_t root) {
             uint32_t n = root;
             for (size_t steps = 0; steps <= nodes.size(); ++steps) {
                 if (n == RZ_END) return true;
                 if (n >= nodes.size()) return false;
                 const hiprz_node& nd = nodes[n];
-                bool descend;
-                if (walk_graph) {
-                    const uint32_t type = nd.meta >> RZ_WALK_TYPE_SHIFT;
-                    descend = type == RZ_WALK_INNER || type == RZ_WALK_CHAIN;
-                } else {
-                    descend = !(nd.meta & HIPRZ_NODE_LEAF);
-                }
-                n = descend ? nd.begin : links[n];
+                n = !(nd.meta & HIPRZ_NODE_LEAF) ? nd.begin : links[n];
             }
             return false;
         };
         bool ok = true;
         for (uint32_t old = 0; ok && old < sc->n_nodes; ++old)  // the stack walks reach the second child as first + 1
             if (!(sc->nodes[old].meta & HIPRZ_NODE_LEAF)) ok = new_index[sc->nodes[old].begin + 1] == new_index[sc->nodes[old].begin] + 1u;
-        if (ok && sc->n_instances) ok = terminates(dnodes, dskip, new_index[sc->tlas_root], false) && terminates(wnodes, wskip, new_index[sc->tlas_root], true);
+        if (ok && sc->n_instances) ok = terminates(dnodes, dskip, new_index[sc->tlas_root]);
         for (uint32_t i = 0; ok && i < sc->n_tlas_order; ++i) {
             const uint32_t root = new_index[sc->instances[sc->tlas_order[i]].blas_root];
-            ok = terminates(dnodes, dskip, root, false) && terminates(wnodes, wskip, root, true);
+            ok = terminates(dnodes, dskip, root);
         }
         // the same for every octant's links: a walk that enters every box takes exactly one step per node of the tree it walks
         auto terminates8 = [&](uint32_t root, uint32_t o) {
@@ -2085,6 +727,18 @@ int derive_tables(const hiprz_scene* sc, SceneCheck& chk, DerivedTables& out) {
 
 }  // namespace
 
+namespace {
+// A captured graph of a batch of passes stays valid while nothing its kernel arguments depend on has changed: the setters
+// invalidate it only when a value really differs (both host sides call hiprz_set_config before every frame).
+template <typename T>
+void assign_setting(hiprz_ctx* c, T& field, const T& value) {
+    if (std::memcmp(&field, &value, sizeof(T)) != 0) {
+        field = value;
+        c->graph_valid = false;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 int hiprz_validate_scene(const hiprz_scene* scene, char* message, size_t len) {
@@ -2114,20 +768,12 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, HIPRZ_ERR_DEVICE, std::string("hiprz is built for gfx950 only, device is ") + prop.gcnArchName);
     auto* c = new hiprz_ctx();
-    if (const char* t = std::getenv("HIPRZ_POOL_THRESHOLD")) c->pool_threshold = uint32_t(std::atoi(t));
-    if (const char* wg = std::getenv("HIPRZ_TRACE_WG")) {
-        const int v = std::atoi(wg);
-        if (v == 64 || v == 256) c->trace_wg = v;
-    }
     if (const char* w = std::getenv("HIPRZ_TRACE_WAVES")) c->trace_waves = std::atoi(w);
     if (const char* w = std::getenv("HIPRZ_DEFER_SHADOWS")) c->defer_shadow_rays = std::atoi(w) != 0;
-    if (const char* w = std::getenv("HIPRZ_COOP")) c->coop_walk = std::atoi(w) != 0;
-    if (const char* w = std::getenv("HIPRZ_COOP_SHADOW")) c->coop_shadow = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_BATCH_WAVES")) c->batch_waves = std::atoi(w);
     if (const char* w = std::getenv("HIPRZ_NOLIGHT_KERNELS")) c->nolight_kernels = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SORT_BITS")) c->sort_bits = std::min(24, std::max(0, std::atoi(w)));
     if (const char* w = std::getenv("HIPRZ_SHADOW_SORT")) c->shadow_sort = std::atoi(w) != 0;
-    if (const char* w = std::getenv("HIPRZ_SHADOW_WALK")) c->shade_shadow_walk = std::atoi(w) == 1 ? 1 : 3;
     c->device = device_id;
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = c->pass_dev.resize(1);
@@ -2154,10 +800,10 @@ int hiprz_destroy(hiprz_ctx* c) {
     }
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto e : c->kernel_events) (void)hipEventDestroy(e);
-    c->hot.release(), c->wnodes.release(), c->wskip.release(), c->node_skip.release(), c->nodes64.release(), c->textures.release();
+    c->hot.release(), c->node_skip.release(), c->nodes64.release(), c->textures.release();
     c->texels.release(), c->spot_lights.release(), c->direct_lights.release();
     release_frame(c);
-    c->pass_dev.release(), c->counters_dev.release(), c->pick_dev.release(), c->rq_counts.release(), c->wg_times.release();
+    c->pass_dev.release(), c->counters_dev.release(), c->pick_dev.release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return HIPRZ_OK;
@@ -2172,17 +818,18 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     SceneCheck chk;
     if (check_scene(sc, chk) != HIPRZ_OK) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: " + chk.error);
     const uint32_t world_depth = chk.world_depth, mesh_depth = chk.mesh_depth;
-    c->stack_entries = world_depth + mesh_depth + 2u;
-    c->dscene.world_stack_entries = world_depth + 1u;
-    c->dscene.mesh_stack_entries = mesh_depth + 1u;
 
     DerivedTables derived;
     if (derive_tables(sc, chk, derived) != HIPRZ_OK) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: " + chk.error);
+    // from here on the device buffers of the previous scene are being replaced: until the new one is complete there is no scene
+    // (a failed upload must not leave the old scene's kernels arguments pointing at reallocated buffers)
+    c->have_scene = false;
+    c->stack_entries = world_depth + mesh_depth + 2u;
+    c->dscene.world_stack_entries = world_depth + 1u;
+    c->dscene.mesh_stack_entries = mesh_depth + 1u;
     std::vector<uint32_t>& new_index = derived.new_index;
     std::vector<hiprz_node>& dnodes = derived.dnodes;
-    std::vector<hiprz_node>& wnodes = derived.wnodes;
     std::vector<uint32_t>& dskip = derived.dskip;
-    std::vector<uint32_t>& wskip = derived.wskip;
     // shared-reciprocal division is exact only for coordinates that are 0 or in [2^-60, 2^40)
     auto coord_ok = [](float x) {
         uint32_t b;
@@ -2191,8 +838,10 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
         return (b & 0x7FFFFFFFu) == 0u || (e >= 127u - 60u && e < 127u + 40u);
     };
     bool fast_div = true;
-    for (const auto& n : wnodes)
+    for (const auto& n : dnodes)
         for (int a = 0; a < 3; ++a) fast_div = fast_div && coord_ok(n.bb_min[a]) && coord_ok(n.bb_max[a]);
+    for (uint32_t i = 0; i < sc->n_instances; ++i)
+        for (int a = 0; a < 3; ++a) fast_div = fast_div && coord_ok(sc->instances[i].bb_min[a]) && coord_ok(sc->instances[i].bb_max[a]);
 
     (void)hipSetDevice(c->device);
     // hot blob: one buffer, 16-B aligned sections
@@ -2211,7 +860,6 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
         mn[0] = v[0], mn[1] = v[1], mn[2] = v[2], mx[0] = v[3], mx[1] = v[4], mx[2] = v[5];
     };
     for (auto& n : dnodes) interleave(n.bb_min, n.bb_max);  // bb_min[3] and bb_max[3] are contiguous
-    for (auto& n : wnodes) interleave(n.bb_min, n.bb_max);
     std::vector<hiprz_instance> dinstances(sc->instances, sc->instances + sc->n_instances);
     for (auto& in : dinstances) {
         if (in.blas_root < sc->n_nodes) in.blas_root = new_index[in.blas_root];
@@ -2254,8 +902,6 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
         std::memcpy(&nodes64[n * 16u + 8u], &derived.dskip8[n * 8u], 32);
     }
     RZ_HIP(c, c->nodes64.assign(nodes64.data(), nodes64.size(), c->stream));
-    RZ_HIP(c, c->wnodes.assign(wnodes.data(), wnodes.size(), c->stream));
-    RZ_HIP(c, c->wskip.assign(wskip.data(), wskip.size(), c->stream));
     RZ_HIP(c, c->textures.assign(sc->textures, sc->n_textures, c->stream));
     RZ_HIP(c, c->texels.assign(sc->texels, sc->texel_bytes, c->stream));
     RZ_HIP(c, c->spot_lights.assign(sc->spot_lights, sc->n_spot_lights, c->stream));
@@ -2270,8 +916,6 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     d.tri_attrs = reinterpret_cast<const float4*>(c->hot.ptr + d.off_tri_attrs);
     d.materials = reinterpret_cast<const float4*>(c->hot.ptr + d.off_materials);
     d.inst_materials = reinterpret_cast<const int32_t*>(c->hot.ptr + d.off_inst_materials);
-    d.wnodes = reinterpret_cast<const float4*>(c->wnodes.ptr);
-    d.wskip = c->wskip.ptr;
     d.fast_div = fast_div ? 1u : 0u;
     d.textures = reinterpret_cast<const float4*>(c->textures.ptr);
     d.texels = c->texels.ptr;
@@ -2300,7 +944,6 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     if (const char* v = std::getenv("HIPRZ_SORT_KEY")) d.sort_variant = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_K")) d.walk_k = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_L")) d.walk_l = uint32_t(std::atoi(v));
-    d.wtop_count = std::min<uint32_t>(uint32_t(wnodes.size()), kTopCacheNodes);
     d.n_spot_lights = sc->n_spot_lights;
     d.n_direct_lights = sc->n_direct_lights;
     // Stage the blob in LDS when three workgroups per CU (the kernel's register-limited residency)
@@ -2315,13 +958,13 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
 
 int hiprz_upload_camera(hiprz_ctx* c, const hiprz_camera* cam) {
     if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
     if (!cam) return fail(c, HIPRZ_ERR_INVALID, "upload_camera: camera is null");
     if (cam->width == 0 || cam->height == 0 || cam->width > 32768u || cam->height > 32768u)
         return fail(c, HIPRZ_ERR_INVALID, "upload_camera: resolution must be 1..32768");
     StageTimer timer;
     (void)hipSetDevice(c->device);
     const bool resized = !c->have_camera || cam->width != c->camera.width || cam->height != c->camera.height;
+    if (!c->have_camera || std::memcmp(&c->camera, cam, sizeof(hiprz_camera)) != 0) c->graph_valid = false;
     c->camera = *cam;
     DCamera& d = c->dcamera;
     std::memcpy(d.position, cam->position, 12);
@@ -2344,23 +987,22 @@ int hiprz_upload_camera(hiprz_ctx* c, const hiprz_camera* cam) {
 
 int hiprz_set_config(hiprz_ctx* c, const hiprz_config* cfg) {
     if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
     if (!cfg) return fail(c, HIPRZ_ERR_INVALID, "set_config: config is null");
     if (cfg->max_depth == 0 || cfg->max_depth > 254u) return fail(c, HIPRZ_ERR_INVALID, "max_depth must be 1..254 (u8, 255 = path ended)");
     // The CPU kernel divides by sample_count/light_count and yields NaN for 0 samples
     // (cpu_engine_kernel.cpp:742-743, 789-790); the CUDA backend clamps to >= 1 (cuda_kernel_data.cu:23-31).
     if (cfg->spot_samples == 0 || cfg->direct_samples == 0 || cfg->spot_samples > 255u || cfg->direct_samples > 255u)
         return fail(c, HIPRZ_ERR_INVALID, "light sample counts must be 1..255");
-    c->config = *cfg;
+    assign_setting(c, c->config, *cfg);
     return HIPRZ_OK;
 }
 
 int hiprz_set_shard(hiprz_ctx* c, uint32_t rank, uint32_t world) {
     if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
     if (world == 0 || rank >= world) return fail(c, HIPRZ_ERR_INVALID, "set_shard: need rank < world");
     const bool changed = rank != c->rank || world != c->world;
     c->rank = rank, c->world = world;
+    if (changed) c->graph_valid = false;
     if (changed && c->have_camera) {
         (void)hipSetDevice(c->device);
         const int rc = allocate_frame(c);
@@ -2372,70 +1014,31 @@ int hiprz_set_shard(hiprz_ctx* c, uint32_t rank, uint32_t world) {
 
 int hiprz_set_traversal_mode(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
-    if (mode < -1 || mode > 6) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: -1 = auto, 0 = threaded, 1 = LDS stack, 2 = workgroup-binned, 3 = skip links + LDS-cached tree tops, 4 = persistent lanes on the flat walk graph, 5 = mode 3 in rounds with ray requeueing, 6 = wave pool (persistent waves, phased world / mesh walk)");
-    c->traversal_mode = mode;
+    if (mode < -1 || mode == 0 || mode > 3) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: -1 = per scene, 1 = LDS stack, 2 = workgroup-binned, 3 = skip links (single-wave workgroups)");
+    assign_setting(c, c->traversal_mode, mode);
     resolve_pipeline(c);
     return HIPRZ_OK;
 }
 
 int hiprz_set_walk_order(hiprz_ctx* c, int order) {
     if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
     if (order < 0 || order > 2) return fail(c, HIPRZ_ERR_INVALID, "walk order: 0 = the reference's child order, 1 = front-to-back, 2 = front-to-back also in counted renders");
-    c->walk_order = order;
-    return HIPRZ_OK;
-}
-
-int hiprz_set_requeue_schedule(hiprz_ctx* c, const uint32_t* thresholds, uint32_t n_rounds) {
-    if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
-    if (n_rounds > 30u || (n_rounds && !thresholds)) return fail(c, HIPRZ_ERR_INVALID, "requeue schedule: at most 30 bailing rounds");
-    for (uint32_t r = 0; r < n_rounds; ++r)
-        if (thresholds[r] > 64u) return fail(c, HIPRZ_ERR_INVALID, "requeue schedule: a threshold is a lane count (0..64)");
-    c->requeue_thresholds.assign(thresholds, thresholds + n_rounds);
-    return HIPRZ_OK;
-}
-
-int hiprz_set_workgroup_timing(hiprz_ctx* c, int enabled) {
-    if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
-    c->wg_timing = enabled != 0;
-    if (c->wg_timing) RZ_HIP(c, c->wg_times.resize(size_t(c->n_local_tiles + 8u) * 2u));
-    return HIPRZ_OK;
-}
-
-int hiprz_read_workgroup_times(hiprz_ctx* c, uint64_t* start_end_out, uint32_t n_workgroups) {
-    if (!c || !start_end_out) return HIPRZ_ERR_INVALID;
-    if (!c->wg_timing || !c->wg_times.ptr || n_workgroups > c->n_local_tiles) return fail(c, HIPRZ_ERR_STATE, "workgroup timing is not enabled for this frame");
-    RZ_HIP(c, hipStreamSynchronize(c->stream));
-    RZ_HIP(c, hipMemcpy(start_end_out, c->wg_times.ptr, sizeof(uint64_t) * 2u * n_workgroups, hipMemcpyDeviceToHost));
-    return HIPRZ_OK;
-}
-
-int hiprz_requeue_counts(hiprz_ctx* c, uint32_t* counts_out, uint32_t n) {
-    if (!c || !counts_out) return HIPRZ_ERR_INVALID;
-    for (uint32_t i = 0; i < n; ++i) counts_out[i] = 0u;
-    if (!c->rq_counts.ptr) return HIPRZ_OK;
-    RZ_HIP(c, hipStreamSynchronize(c->stream));
-    RZ_HIP(c, hipMemcpy(counts_out, c->rq_counts.ptr, sizeof(uint32_t) * std::min<uint32_t>(n, 32u), hipMemcpyDeviceToHost));
+    assign_setting(c, c->walk_order, order);
     return HIPRZ_OK;
 }
 
 int hiprz_set_lds_scene(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
     if (mode < -1 || mode > 1) return fail(c, HIPRZ_ERR_INVALID, "lds scene: -1 auto, 0 off, 1 on");
-    c->lds_scene_override = mode;
+    assign_setting(c, c->lds_scene_override, mode);
     resolve_pipeline(c);
     return HIPRZ_OK;
 }
 
 int hiprz_set_pipeline(hiprz_ctx* c, int pipeline) {
     if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
     if (pipeline < -1 || pipeline > 2) return fail(c, HIPRZ_ERR_INVALID, "pipeline: -1 = per scene, 0 = fused pass kernel, 1 = trace kernel + shade kernel, 2 = resident (one launch per batch of passes)");
-    c->pipeline_setting = pipeline;
+    assign_setting(c, c->pipeline_setting, pipeline);
     resolve_pipeline(c);
     return HIPRZ_OK;
 }
@@ -2454,16 +1057,14 @@ int hiprz_traversal_mode(hiprz_ctx* c, int* out) {
 
 int hiprz_set_ray_sort(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
     if (mode < -1 || mode > 1) return fail(c, HIPRZ_ERR_INVALID, "ray sort: -1 auto, 0 off, 1 on");
-    c->sort_rays = mode;
+    assign_setting(c, c->sort_rays, mode);
     return HIPRZ_OK;
 }
 
 int hiprz_set_xcd_swizzle(hiprz_ctx* c, int enabled) {
     if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
-    c->xcd_swizzle = enabled != 0;
+    assign_setting(c, c->xcd_swizzle, enabled != 0);
     return HIPRZ_OK;
 }
 
@@ -2724,8 +1325,7 @@ int hiprz_timings(hiprz_ctx* c, char* buf, size_t len) {
 
 int hiprz_time_kernels(hiprz_ctx* c, int enabled) {
     if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
-    c->time_kernels = enabled != 0;
+    c->time_kernels = enabled != 0;  // timed batches are launched eagerly; a captured graph stays valid for the untimed ones
     return HIPRZ_OK;
 }
 

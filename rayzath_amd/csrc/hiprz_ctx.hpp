@@ -1,0 +1,213 @@
+// hiprz_ctx.hpp — host-side state of a context (struct hiprz_ctx) and what the translation units of libhiprz.so share:
+// hiprz_api.hip (the C-ABI, scene upload, readback), hiprz_launch_trace.hip / hiprz_launch_shade.hip / hiprz_launch_batch.hip
+// (the pass kernels' instantiations and their launch logic) and hiprz_sort.hip (ray reordering).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "hiprz.h"
+#include "hiprz_device.hpp"
+
+namespace hiprz {
+
+// Timer/TimeTable of the reference (engine_parts.hpp:34-74): last + EMA(0.05) per stage.
+struct TimeTable {
+    struct Entry {
+        std::string name;
+        double last_ms = 0, avg_ms = 0;
+        bool seen = false;
+    };
+    std::vector<Entry> entries;
+    void set(const char* name, double ms) {
+        for (auto& e : entries)
+            if (e.name == name) {
+                e.last_ms = ms;
+                e.avg_ms = e.seen ? e.avg_ms + (ms - e.avg_ms) * 0.05 : ms;
+                e.seen = true;
+                return;
+            }
+        entries.push_back({name, ms, ms, true});
+    }
+    std::string str() const {
+        std::string out;
+        char line[160];
+        for (const auto& e : entries) {
+            std::snprintf(line, sizeof line, "%-22s %9.3fms (avg %9.3fms)\n", e.name.c_str(), e.last_ms, e.avg_ms);
+            out += line;
+        }
+        return out;
+    }
+};
+struct StageTimer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double ms() const { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+template <typename T>
+struct DeviceArray {
+    T* ptr = nullptr;
+    size_t count = 0;
+    hipError_t assign(const T* src, size_t n, hipStream_t stream) {
+        if (n > count || !ptr) {
+            if (ptr) (void)hipFree(ptr);
+            ptr = nullptr;
+            count = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), sizeof(T) * (n ? n : 1));
+            if (e != hipSuccess) return e;
+            count = n ? n : 1;
+        }
+        if (n) return hipMemcpyAsync(ptr, src, sizeof(T) * n, hipMemcpyHostToDevice, stream);
+        return hipSuccess;
+    }
+    hipError_t resize(size_t n) {
+        if (n <= count && ptr) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&ptr), sizeof(T) * (n ? n : 1));
+        if (e == hipSuccess) count = n ? n : 1;
+        return e;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+};
+
+}  // namespace hiprz
+
+struct hiprz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string error;
+    hiprz::TimeTable timings;
+
+    // scene mirror
+    hiprz::DeviceArray<uint8_t> hot;  // nodes | tlas_order | instances | tris | tri_attrs | materials | inst_materials
+    hiprz::DeviceArray<uint32_t> node_skip;
+    hiprz::DeviceArray<uint32_t> nodes64;
+    int walk_order = 1;  // 0 = meshes in the reference's child order, 1 = front-to-back, 2 = also when counting (hiprz_set_walk_order)
+    hiprz::DeviceArray<hiprz_texture> textures;
+    hiprz::DeviceArray<uint8_t> texels;
+    hiprz::DeviceArray<hiprz_spot_light> spot_lights;
+    hiprz::DeviceArray<hiprz_direct_light> direct_lights;
+    hiprz::DScene dscene{};
+    bool have_scene = false;
+    uint32_t stack_entries = 2;  // LDS stack entries per lane the trees need (MODE 1)
+    bool lds_scene = false;      // hot blob is staged into LDS by every workgroup
+    int lds_scene_override = -1; // -1 auto, 0 never, 1 always (if it fits at all)
+
+    // camera + per-pixel state
+    hiprz_camera camera{};
+    hiprz::DCamera dcamera{};
+    bool have_camera = false;
+    uint32_t rank = 0, world = 1;
+    uint32_t tiles_x = 0, tiles_y = 0, n_local_tiles = 0;
+    uint64_t owned_pixels = 0;
+    hiprz::DeviceArray<float4> st0, st1, accum, hit0;
+    hiprz::DeviceArray<uint32_t> hit1;
+    // 0 fused (one kernel per pass), 1 split (trace kernel -> shade kernel per pass), 2 resident (one kernel per batch
+    // of passes).  -1: resident when the scene is staged in LDS (config B: as fast as split on a whole frame, 2.26 ms per
+    // 8 passes, and 0.34 vs 0.45 ms on an eighth of it — per-pass launch/ramp/tail costs vanish), else split (10-20 % faster
+    // than fused on configs C, D; the resident kernel has no LDS room for the tree-top cache).
+    int pipeline_setting = -1;
+    int pipeline = 1;  // resolved by resolve_pipeline() at upload / set time
+    bool rgba8_valid = false;  // the resident kernel tone-maps on its way out: hiprz_tonemap has nothing to do
+    hiprz::DeviceArray<float2> st2;
+    hiprz::DeviceArray<float> depth;
+    hiprz::DeviceArray<uint32_t> rgba8;
+    hiprz::DeviceArray<float4> image_f4;  // row-major staging for readback
+    hiprz::DeviceArray<uint32_t> state_md;
+    hiprz::DeviceArray<float> state_ray;
+    hiprz::DeviceArray<uint32_t> pass_dev;
+    hiprz::DeviceArray<unsigned long long> counters_dev;
+    hiprz::DeviceArray<int32_t> pick_dev;
+
+    hiprz_config config{8u, 8u, 1u, 1u, 20240501u};
+    bool reset_pending = true;
+    uint32_t passes = 0;
+    uint64_t ray_count = 0;
+    int traversal_mode = -1;  // -1 = choose per scene (effective_mode)
+
+    // hipGraph of one batch of cumulative passes ([pass kernel, pass update] x n): replayed while nothing that
+    // the captured kernel arguments depend on has changed (scene, camera, config, shard, variants)
+    hipGraphExec_t graph_exec = nullptr;
+    uint32_t graph_passes = 0;
+    bool graph_valid = false;
+    // ray reordering between passes (split pipeline): keys from the shade kernel -> radix sort -> permutation
+    hiprz::DeviceArray<uint32_t> sort_keys, sort_keys_out, sort_iota, sort_perm;
+    hiprz::DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
+    uint32_t n_textures = 0;  // of the uploaded scene
+    int batch_waves = 0;  // HIPRZ_BATCH_WAVES=4: never the 5-wave build of the plain batch kernel
+    int nolight_kernels = 1;  // scenes without lights use the instantiations without next-event estimation (HIPRZ_NOLIGHT_KERNELS=0: the general ones)
+    int sort_bits = 0;    // most significant key bits the radix sorts look at; 0 = by frame size (HIPRZ_SORT_BITS)
+    int shadow_sort = 1;  // HIPRZ_SHADOW_SORT=0: the shadow kernel follows the next pass's ray order instead
+    hiprz::DeviceArray<uint8_t> sort_temp;
+    size_t sort_temp_bytes = 0;
+    int sort_rays = -1;  // -1 auto (on for scenes walked with MODE 3), 0 off, 1 on
+    bool sorted_this_pass = false;  // the deferred shadow kernel wants the NEXT pass's ray order: the sort then runs before it
+    bool defer_shadow_rays = true;  // HIPRZ_DEFER_SHADOWS=0: walk them inside the shade kernel
+    hiprz::DeviceArray<float4> nee_base, nee_a, nee_b, nee_point, nee_dir, nee_term;
+    int trace_waves = 0;  // 0 = by tree size; HIPRZ_TRACE_WAVES = 4 | 6 forces the register budget
+    uint32_t n_nodes = 0;
+    bool time_kernels = false;  // record events around the trace and the shade kernel of every pass of a batch
+    std::vector<hipEvent_t> kernel_events;
+    uint32_t kernel_event_passes = 0;
+    bool use_graph = true;
+    bool xcd_swizzle = false;  // measured: banding the image per XCD concentrates the expensive region on few XCDs (D: 4.3 -> 5.1 ms)
+
+    // kernel timing (hip events on `stream` around each render batch)
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending_events;
+    std::vector<uint32_t> pending_launches;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace hiprz {
+
+int fail(hiprz_ctx* ctx, int code, const std::string& msg);
+
+#define RZ_HIP(ctx, call)                                                                                       \
+    do {                                                                                                        \
+        hipError_t rz_e = (call);                                                                               \
+        if (rz_e != hipSuccess)                                                                                 \
+            return hiprz::fail(ctx, HIPRZ_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(rz_e));    \
+    } while (0)
+
+constexpr uint32_t kLatencyBoundNodes = 32768u;  // trees beyond ~1 MiB of nodes: fetches come from L2 / HBM, occupancy hides them
+constexpr uint32_t kTopCacheNodes = 682u;        // 682 x 36 B = 24 KiB per workgroup: ~9 levels of every tree, 5 workgroups per CU
+constexpr size_t kLdsSceneLimit = 52u * 1024u;   // per workgroup: 3 x 52 KiB < 160 KiB per CU
+
+// choices derived from the context's settings and the uploaded scene (hiprz_api.hip)
+int effective_mode(const hiprz_ctx* c);
+bool defer_shadows(const hiprz_ctx* c);
+bool use_lds_scene(const hiprz_ctx* c);
+bool sort_enabled(const hiprz_ctx* c);
+int effective_sort_bits(const hiprz_ctx* c);
+DConfig make_config(const hiprz_ctx* c);
+// launch geometry of the 256-thread pass kernels: one workgroup per owned 32x8 tile
+struct PassGeometry {
+    dim3 grid, block;
+    bool lds_scene;    // the hot blob is staged into LDS by every workgroup
+    size_t blob;       // its bytes (0 when not staged)
+    int mode;          // walk of this launch: 1 LDS stack, 2 workgroup-binned, 3 skip links (split pipeline, global scene)
+    size_t stack_lds;  // LDS stack columns of the MODE 1 walk (and of inline shadow rays)
+    size_t walk_lds;   // workspace of the closest-hit walk
+};
+PassGeometry pass_geometry(const hiprz_ctx* c);
+
+// launch units.  `first`: renderFirstPass instead of renderCumulativePass; `counted`: the instrumented instantiation.
+void launch_trace(hiprz_ctx* c, const DFrame& f, bool first, bool counted);   // split pipeline: closest-hit walk -> hit records
+void launch_shade(hiprz_ctx* c, const DFrame& f, bool first, bool counted);   // split pipeline: shading (+ deferred shadow rays and their sorts)
+void launch_fused(hiprz_ctx* c, const DFrame& f, bool first, bool counted);   // fused pipeline: one kernel per pass
+void launch_batch(hiprz_ctx* c, const DFrame& f, uint32_t n_passes, bool counted, hipEvent_t before, hipEvent_t after);  // resident pipeline
+void launch_sort(hiprz_ctx* c);         // keys of the next rays -> permutation the next trace kernel follows
+void launch_shadow_sort(hiprz_ctx* c);  // keys of the pass's shadow rays -> the order the shadow kernel follows
+int sort_workspace(hiprz_ctx* c, size_t n);  // (re)allocates the sort's buffers for n keys
+
+}  // namespace hiprz

@@ -2,8 +2,8 @@
 //
 // One thread = one pixel = one path segment per pass, as in the reference
 // (RayZath/cpu_engine_kernel.cpp:15-101; RayZath/cuda_render_kernel.cu:7-121), but on a
-// flattened SoA scene (include/hiprz.h) and with a stack-free threaded walk of the two
-// trees (or, as a selectable variant, an LDS stack).  All arithmetic is fp32 and is spelled
+// flattened SoA scene (include/hiprz.h) and with stack-free walks of the two trees on skip links
+// (or, for scenes staged in LDS, an LDS stack / a workgroup-binned walk).  All arithmetic is fp32 and is spelled
 // operation by operation in the order of the CPU reference, compiled with
 // -ffp-contract=off, so that everything except libm-vs-ocml transcendentals is bit-equal
 // to the CPU result.
@@ -29,9 +29,6 @@ namespace hiprz {
 #ifndef RZ_MIN_WAVES
 #define RZ_MIN_WAVES 4
 #endif
-#ifndef RZ_POOL_FACTOR  // MODE 4: rays per workgroup pool = 256 * RZ_POOL_FACTOR
-#define RZ_POOL_FACTOR 8u
-#endif
 #ifndef RZ_TRACE_MIN_WAVES
 #define RZ_TRACE_MIN_WAVES 5
 #endif
@@ -52,17 +49,6 @@ namespace hiprz {
 #endif
 #define RZ_FLT_MAX 3.402823466e+38f
 
-#ifdef HIPRZ_PORTABLE_MATH
-#include "hiprz_portable_math.h"
-#define RZ_SINF(x) hiprz_pm_sinf(x)
-#define RZ_COSF(x) hiprz_pm_cosf(x)
-#define RZ_SINCOSF(x, s, c) ((s) = hiprz_pm_sinf(x), (c) = hiprz_pm_cosf(x))
-#define RZ_ACOSF(x) hiprz_pm_acosf(x)
-#define RZ_ASINF(x) hiprz_pm_asinf(x)
-#define RZ_ATAN2F(y, x) hiprz_pm_atan2f(y, x)
-#define RZ_POWF(x, y) hiprz_pm_powf(x, y)
-#define RZ_EXPF(x) hiprz_pm_expf(x)
-#else
 #define RZ_SINF(x) sinf(x)
 #define RZ_COSF(x) cosf(x)
 // sine and cosine of one angle with ONE argument reduction; ocml's sincosf returns bit-for-bit what sinf and cosf
@@ -73,7 +59,6 @@ namespace hiprz {
 #define RZ_ATAN2F(y, x) atan2f(y, x)
 #define RZ_POWF(x, y) powf(x, y)
 #define RZ_EXPF(x) expf(x)
-#endif
 
 // ---------------------------------------------------------------------------------------
 // Device-side views.  Every record array is addressed as float4 so a record is fetched
@@ -81,9 +66,7 @@ namespace hiprz {
 // material = 3, texture = 3, spot light = 3, direct light = 2 float4).
 // ---------------------------------------------------------------------------------------
 struct DScene {
-    const float4* nodes;         // hiprz_node records as uploaded (MODE 1)
-    const float4* wnodes;        // walk graph derived on upload (MODE 0): nodes + INSTANCE pseudo-nodes
-    const uint32_t* wskip;       // walk graph: link to the node that follows a node's subtree
+    const float4* nodes;         // hiprz_node records, breadth-first over all trees, boxes interleaved (min.x, max.x, ...)
     const uint32_t* tlas_order;
     const float4* tris;
     const float4* tri_attrs;
@@ -98,7 +81,7 @@ struct DScene {
     uint32_t tlas_root;
     uint32_t n_spot_lights;
     uint32_t n_direct_lights;
-    uint32_t fast_div;  // every walk-graph coordinate is 0 or in [2^-60, 2^40): shared-reciprocal division is exact
+    uint32_t fast_div;  // every node / instance box coordinate is 0 or in [2^-60, 2^40): shared-reciprocal division is exact
     // The geometry + shading records live in ONE device buffer ("hot blob": nodes | tlas_order |
     // instances | tris | tri_attrs | materials | inst_materials, each section 16-B aligned) so a
     // workgroup can stage it into LDS with one strided copy when it is small enough.
@@ -109,7 +92,6 @@ struct DScene {
     uint32_t mesh_stack_entries;
     float bounds_min[3];           // world box (root of the world tree) and 32 / extent per axis: cells of the ray sort key
     float bounds_scale[3];
-    uint32_t wtop_count;           // MODE 4: the same for the walk graph (wnodes / wskip)
     uint32_t top_count;            // MODE 3: the first top_count nodes (+ their links) are staged in LDS by every workgroup
     const uint32_t* node_skip;     // link to the node that follows a node's subtree (same numbering as `nodes`)
     uint32_t walk_k, walk_l;       // MODE 3 mesh walk: node steps / triangle tests per lane per round (0 = unbounded)
@@ -172,7 +154,6 @@ struct DFrame {
     float4* nee_term;   // [sample][pixel] unshadowed contribution
     uint32_t* shadow_key;         // deferred shadow rays: sort key of the pixel's shadow rays (origin cell + direction towards the light)
     const uint32_t* shadow_perm;  // rz_shadow_kernel: thread i finishes local pixel shadow_perm[i] (nullptr: follow `perm`)
-    unsigned long long* wg_times;  // diagnostics (hiprz_set_workgroup_timing): [2 * workgroup] = start, end of the trace kernel's workgroups (100 MHz clock)
 };
 
 struct v3 {
@@ -336,17 +317,16 @@ RZ_DEV float to_local(const InstanceXform& x, const Ray& g, Ray& l) {
 // ---------------------------------------------------------------------------------------
 // Tree walk.  The reference descends depth-first, first child then second, testing a
 // node's box when it is entered (cpu_engine_kernel.cpp:254-277, 331-352) — a FIXED order.
-// Two implementations visit the same boxes and triangles in that same order:
-//
-//  MODE 0 "threaded" (default): stack-free.  On upload the host derives a walk graph
-//  (hiprz_api.hip: build_walk_graph): every node carries a `skip` link to the node that
-//  follows its subtree, and every world-tree leaf becomes a chain of INSTANCE pseudo-nodes
-//  (box = the instance's world box).  World nodes, instance boxes and mesh nodes are then all
-//  "test a box, follow a link", so each LANE advances through its own sequence of box tests
-//  and the wave never serialises over instances.
+// Three walks visit the same boxes and triangles in that same order (and a fourth, the front-to-back
+// cooperative walk, reaches the same hits with fewer tests):
 //
 //  MODE 1 "LDS stack": nested loops (world tree -> instances of a leaf -> mesh tree) with an
 //  explicit per-lane stack in LDS (level-major columns: lanes on one level hit distinct banks).
+//  MODE 2 "workgroup-binned": the (ray, instance) visits of a workgroup's 256 rays are binned by
+//  instance in LDS and processed by dense waves (scenes staged in LDS whose meshes are single leaves).
+//  MODE 3 "skip links": stack-free — every node carries a link to whatever follows its subtree.
+//  Measured and removed (DESIGN.md §5 keeps the numbers): a threaded flat walk graph with instance
+//  pseudo-nodes, persistent lanes on it, requeue rounds, a persistent wave pool.
 // ---------------------------------------------------------------------------------------
 struct Hit {
     int32_t instance;  // -1 = none
@@ -355,12 +335,6 @@ struct Hit {
     bool external;
 };
 
-#define RZ_WALK_INNER 0u
-#define RZ_WALK_TRIS 1u
-#define RZ_WALK_INSTANCE 2u
-#define RZ_WALK_CHAIN 3u
-#define RZ_WALK_TYPE_SHIFT 30
-#define RZ_WALK_COUNT_MASK 0x3FFFFFFFu
 
 // Correctly rounded fp32 division with a reciprocal shared between numerators.  This is the
 // instruction sequence hipcc emits for `n / d` (v_rcp_f32, two fma to refine it, then
@@ -450,26 +424,9 @@ RZ_DEV float vmax3(float a, float b, float c) {
 }
 // BoundingBox::rayIntersection (render_parts.cpp:197-217) on a prepared ray.  The box comes as the
 // device stores it: b0 = (min.x, max.x, min.y, max.y), b1.xy = (min.z, max.z).
-#ifdef RZ_BOXPATH_STATS  // diagnostic build: how many wave-level box tests take the packed path
-__device__ unsigned long long rz_boxpath[4];
-#endif
 template <bool SHARED_RCP>
 RZ_DEV bool box_hit(float4 b0, float4 b1, const WalkRay& r) {
-#ifdef RZ_BOXPATH_STATS
-    if (SHARED_RCP) {
-        const unsigned long long active = __ballot(1), fast = __ballot(r.fast);
-        if (int(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u))) == __ffsll((long long)active) - 1) {  // first ACTIVE lane
-            atomicAdd(&rz_boxpath[fast == active ? 0 : 1], 1ull);
-            atomicAdd(&rz_boxpath[2], (unsigned long long)__popcll(active));
-            atomicAdd(&rz_boxpath[3], (unsigned long long)__popcll(active & ~fast));
-        }
-    }
-#endif
-#ifdef RZ_EXP_FORCE_FAST
-    if (SHARED_RCP) {
-#else
     if (SHARED_RCP && __all(r.fast)) {  // wave-uniform branch
-#endif
         const f2 tx = div_shared2(f2{b0.x, b0.y} - f2{r.o.x, r.o.x}, r.d.x, r.y.x);
         const f2 ty = div_shared2(f2{b0.z, b0.w} - f2{r.o.y, r.o.y}, r.d.y, r.y.y);
         const f2 tz = div_shared2(f2{b1.x, b1.y} - f2{r.o.z, r.o.z}, r.d.z, r.y.z);
@@ -492,102 +449,6 @@ RZ_DEV bool tri_hit(v3 v1, v3 edge1, v3 edge2, const WalkRay& r, float& t, float
     Ray q;
     q.o = r.o, q.d = r.d, q.near_ = r.near_, q.far_ = r.far_;
     return tri_hit(v1, edge1, edge2, q, t, b1, b2, det);
-}
-
-// closest-hit (ANY = false: traverseWorld + closestIntersection, cpu_engine_kernel.cpp:254-352)
-// and any-hit (ANY = true: anyIntersection, :398-481) on the walk graph.
-// closest: returns 0 = root box missed, 1 = walked, nothing hit, 2 = hit.
-// any:     returns 0 = occluded, 1 = clear (the mask alpha; "TODO: texture fetch" :465).
-template <bool ANY, bool COUNT>
-RZ_DEV int walk_threaded(const DScene& s, Ray& ray, Hit& hit, Counters& cnt) {
-    WalkRay cur;
-    cur.o = ray.o, cur.d = ray.d, cur.near_ = ray.near_, cur.far_ = ray.far_;
-    prepare<true>(cur, s.fast_div != 0u);
-    // state saved while a lane is inside an instance (mesh space)
-    v3 world_o = cur.o, world_d = cur.d;
-    float world_near = cur.near_, len = 1.0f;
-    uint32_t ret = RZ_END, inst = 0u;
-    bool in_mesh = false, found_here = false, root_missed = false;
-
-    uint32_t n = s.tlas_root, guard = 0u;
-    while (true) {
-        RZ_GUARD(guard);
-        if (n == RZ_END) {
-            if (!in_mesh) break;
-            // leave the instance: cpu_engine_kernel.cpp:320-329
-            if constexpr (!ANY) {
-                if (found_here) {
-                    hit.instance = int32_t(inst);
-                    world_near = cur.near_ / len;
-                    cur.far_ = cur.far_ / len;
-                } else {
-                    cur.far_ = ray.far_;
-                }
-                ray.far_ = cur.far_;
-            } else {
-                cur.far_ = ray.far_;
-            }
-            cur.o = world_o, cur.d = world_d, cur.near_ = world_near;
-            prepare<true>(cur, s.fast_div != 0u);
-            in_mesh = false;
-            n = ret;
-            continue;
-        }
-        const float4 n0 = s.wnodes[2 * n], n1 = s.wnodes[2 * n + 1];
-        const uint32_t link = s.wskip[n];
-        RZ_COUNT(box_tests);
-        if (box_hit<true>(n0, n1, cur)) {
-            const uint32_t a = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
-            const uint32_t type = meta >> RZ_WALK_TYPE_SHIFT;
-            if (type == RZ_WALK_INNER || type == RZ_WALK_CHAIN) {
-                n = a;
-                continue;
-            }
-            if (type == RZ_WALK_INSTANCE) {  // cpu_engine_kernel.cpp:307-319 / :441-448
-                inst = a;
-                const InstanceXform x = load_instance_xform(s, inst);
-                world_o = cur.o, world_d = cur.d, world_near = cur.near_;
-                if constexpr (!ANY) ray.far_ = cur.far_;
-                cur.o = transform_backward(x.xa, x.ya, x.za, cur.o - x.position);
-                cur.d = transform_backward(x.xa, x.ya, x.za, cur.d);
-                if (!x.unit_scale) {
-                    cur.o = cur.o / x.scale;
-                    cur.d = cur.d / x.scale;
-                }
-                len = magnitude(cur.d);
-                cur.near_ = cur.near_ * len;
-                cur.far_ = cur.far_ * len;
-                cur.d = cur.d * (1.0f / len);
-                prepare<true>(cur, s.fast_div != 0u);
-                in_mesh = true, found_here = false;
-                ret = link;
-                n = x.blas_root;
-                continue;
-            }
-            const uint32_t end = a + (meta & RZ_WALK_COUNT_MASK);
-            for (uint32_t i = a; i < end; ++i) {
-                const float4 ta = s.tris[3 * i], tb = s.tris[3 * i + 1], tc = s.tris[3 * i + 2];
-                float t, b1, b2, det;
-                RZ_COUNT(tri_tests);
-                if (tri_hit(xyz(ta), xyz(tb), xyz(tc), cur, t, b1, b2, det)) {
-                    if constexpr (ANY) return 0;
-                    cur.far_ = t;
-                    hit.triangle = i;
-                    hit.external = det > 0.0f;
-                    hit.bx = b1, hit.by = b2;
-                    found_here = true;
-                }
-            }
-        } else if (n == s.tlas_root) {
-            root_missed = true;  // cpu_engine_kernel.cpp:283 / :402
-        }
-        n = link;
-    }
-    if constexpr (ANY) return 1;
-    ray.near_ = world_near;
-    ray.far_ = cur.far_;
-    if (root_missed) return 0;
-    return hit.instance >= 0 ? 2 : 1;
 }
 
 // ---- MODE 1: nested loops with an LDS stack ----
@@ -785,26 +646,6 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
 // have equal trip counts.  Every ray still sees its instances one after another with an updated
 // range, so results equal the sequential walk bit for bit.
 #define RZ_BIN_NONE 0xFFFFFFFFu
-#ifdef RZ_STAMP  // diagnostic build: where do the rounds spend their cycles (never timed, never shipped)
-__device__ unsigned long long rz_stamp_sums[8];
-#define RZ_STAMP_BEGIN() long long rz_t = __builtin_amdgcn_s_memtime(); long long rz_acc[6] = {0, 0, 0, 0, 0, 0}
-#define RZ_STAMP_MARK(k)                                   \
-    {                                                      \
-        const long long rz_now = __builtin_amdgcn_s_memtime(); \
-        rz_acc[k] += rz_now - rz_t;                        \
-        rz_t = rz_now;                                     \
-    }
-#define RZ_STAMP_END()                                                                                         \
-    if ((threadIdx.x & 63u) == 0u) {                                                                           \
-        for (int k = 0; k < 6; ++k) atomicAdd(&rz_stamp_sums[k], (unsigned long long)rz_acc[k]);               \
-        atomicAdd(&rz_stamp_sums[6], (unsigned long long)round);                                               \
-        atomicAdd(&rz_stamp_sums[7], 1ull);                                                                    \
-    }
-#else
-#define RZ_STAMP_BEGIN()
-#define RZ_STAMP_MARK(k)
-#define RZ_STAMP_END()
-#endif
 struct BinnedLds {  // per-workgroup workspace carved from dynamic LDS (256 lanes)
     float* ray;         // [8][256]  o.xyz d.xyz near far
     uint32_t* hit;      // [5][256]  triangle, external, b1, b2, instance
@@ -852,7 +693,6 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
     uint32_t round = 0u;
     if (tid < 128u) lds.bins[tid] = 0u;
     __syncthreads();
-    RZ_STAMP_BEGIN();
 
     uint32_t guard = 0u;
     while (round < (1u << 20)) {  // workgroup-uniform bound: a ray enters each instance at most once
@@ -893,13 +733,11 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
         // B. bin the items by instance: count (LDS atomics), exclusive prefix over the 64 bins computed
         //    redundantly by every wave (no barrier between scan and scatter), scatter.  The bins are
         //    double-buffered: this round's were zeroed during the previous round.
-        RZ_STAMP_MARK(0);  // A: world walk
         uint32_t* bins = lds.bins + (round & 1u) * 64u;
         uint32_t rank = 0u;
         const uint32_t bin = sorted ? cand : 0u;
         if (cand != RZ_BIN_NONE) rank = atomicAdd(&bins[bin], 1u);
         __syncthreads();
-        RZ_STAMP_MARK(1);  // count + barrier (waiting for the slowest walker)
         const uint32_t lane = tid & 63u;
         const uint32_t c = bins[lane];
         uint32_t incl = c;
@@ -914,7 +752,6 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
         if (cand != RZ_BIN_NONE) lds.items[start + rank] = (cand << 8) | tid;
         if (tid < 64u) lds.bins[((round + 1u) & 1u) * 64u + tid] = 0u;
         __syncthreads();
-        RZ_STAMP_MARK(2);  // scan + scatter + barrier
 
         // C. dense: one lane per item (closestIntersection(instance) + (mesh), :299-352).  The lane that
         //    takes item i rotates with the round and the workgroup, so the busy waves — and with them the
@@ -942,15 +779,12 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
                 lds.hit[4 * 256 + src] = inst;
             }
         }
-        RZ_STAMP_MARK(3);  // C: dense item work
         __syncthreads();
-        RZ_STAMP_MARK(4);  // barrier (waiting for the slowest item)
         round += 1u;
         // D. the ray's owner picks up its (possibly shortened) range
         g.near_ = lds.ray[6 * 256 + tid];
         g.far_ = lds.ray[7 * 256 + tid];
     }
-    RZ_STAMP_END();
     // origin and direction were not kept in registers across the rounds: take them back from the slot
     ray.o = V3(lds.ray[0 * 256 + tid], lds.ray[1 * 256 + tid], lds.ray[2 * 256 + tid]);
     ray.d = V3(lds.ray[3 * 256 + tid], lds.ray[4 * 256 + tid], lds.ray[5 * 256 + tid]);
@@ -974,13 +808,10 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
 // (hiprz_api.hip: relayout), so the levels nearest the roots — the ones every ray visits — form a prefix;
 // each workgroup stages that prefix (nodes + links) into LDS.  Following skip links instead of popping a
 // stack means the walk needs no LDS stack at all, which is what frees the space for the cache.
-#define RZ_PARK_WORDS 16u
 struct TopCache {
     const float4* nodes;   // LDS: top_count x 2 float4
     const uint32_t* skip;  // LDS: top_count
     uint32_t count;
-    float* park = nullptr;            // LDS, RZ_PARK_WORDS x 64 floats: per-lane world-level state while a lane is inside a mesh (closest_hit_skip<.., PARK>)
-    static __host__ uint32_t park_bytes_host() { return RZ_PARK_WORDS * 64u * 4u; }
     static __host__ uint32_t bytes_host(uint32_t top_count) { return top_count * 36u; }
 };
 // Front-to-back mesh walk.  The reference visits a node's first child, then its second (cpu_engine_kernel.cpp:331-352);
@@ -1026,29 +857,18 @@ RZ_DEV void fetch_node(const DScene& s, const TopCache& top, uint32_t n, float4&
         n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1], link = s.node_skip[n];
     }
 }
-// PARK: under a tight register budget (6 waves per SIMD = 80 VGPRs) the compiler keeps the world-space ray alive through the mesh
-// walk and spills the MESH-space ray instead — every box test of the hot loop then reloads 14 dwords from scratch.  With PARK the
-// world-space origin and direction are written to LDS once and read back (and the reciprocals recomputed, the same instructions)
-// after every mesh walk, so they are dead while a mesh is walked.
-template <bool COUNT, bool RCP, bool ORDERED = false, bool PARK = false>
+template <bool COUNT, bool RCP>
 RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit& hit, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
     prepare<RCP>(g, scene_fast);
-    // an LDS-qualified pointer: ds_read / ds_write instead of flat accesses
-    volatile __attribute__((address_space(3))) float* park = (volatile __attribute__((address_space(3))) float*)(top.park) + (threadIdx.x & 63u);
-    if constexpr (PARK) {
-        park[0] = g.o.x, park[64] = g.o.y, park[128] = g.o.z;
-        park[192] = g.d.x, park[256] = g.d.y, park[320] = g.d.z;
-    }
     uint32_t n = s.tlas_root, guard = 0u;
     while (n != RZ_END) {
         RZ_GUARD(guard);
         float4 n0, n1;
         uint32_t link;
-        if constexpr (ORDERED) fetch_node_ordered(s, n, 0u, n0, n1, link);  // the world tree keeps the reference's order
-        else fetch_node(s, top, n, n0, n1, link);
+        fetch_node(s, top, n, n0, n1, link);
         RZ_PHASE(0);
         RZ_COUNT(box_tests);
         if (box_hit<RCP>(n0, n1, g)) {
@@ -1071,11 +891,6 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                 float len = to_local<RCP>(x, g, lr, scene_fast);
                 bool found = false;
                 uint32_t m = x.blas_root;
-                if constexpr (PARK) {  // the world-level loop state waits in LDS as well
-                    park[384] = g.near_, park[448] = g.far_, park[512] = len;
-                    park[576] = __uint_as_float(i), park[640] = __uint_as_float(end), park[704] = __uint_as_float(link), park[768] = __uint_as_float(inst);
-                }
-                const uint32_t oct = ORDERED ? octant_of(lr.d) : 0u;
                 // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352, as a "while-while" walk in bounded
                 // rounds: lanes without a leaf step through nodes until they HOLD one (at most walk_k steps per round), then the
                 // lanes that hold a leaf test its triangles (at most walk_l per round), together.  With the leaf loop nested in
@@ -1092,15 +907,13 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                         k += 1u;
                         float4 m0, m1;
                         uint32_t mlink;
-                        if constexpr (ORDERED) fetch_node_ordered(s, m, oct, m0, m1, mlink);
-                        else fetch_node(s, top, m, m0, m1, mlink);
+                        fetch_node(s, top, m, m0, m1, mlink);
                         RZ_PHASE(3);
                         RZ_COUNT(box_tests);
                         if (box_hit<RCP>(m0, m1, lr)) {
                             const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                             if (!(mmeta & HIPRZ_NODE_LEAF)) {
                                 m = mbegin;
-                                if constexpr (ORDERED) m += (oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u;  // enter the nearer child first
                                 continue;
                             }
                             tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
@@ -1114,35 +927,19 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                         float t, b1, b2, det;
                         RZ_PHASE(4);
                         RZ_COUNT(tri_tests);
-                        bool is_hit;
-                        if constexpr (ORDERED) is_hit = tri_hit_ordered(xyz(a), xyz(b), xyz(c), lr, found && tj < hit.triangle, t, b1, b2, det);
-                        else is_hit = tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det);
-                        if (is_hit) {
+                        if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
                             lr.far_ = t;
                             hit.triangle = tj;
-                            if constexpr (PARK) {  // read back once, when the walk is over
-                                park[832] = b1, park[896] = b2, park[960] = det > 0.0f ? 1.0f : 0.0f;
-                            } else {
-                                hit.external = det > 0.0f;
-                                hit.bx = b1, hit.by = b2;
-                            }
+                            hit.external = det > 0.0f;
+                            hit.bx = b1, hit.by = b2;
                             found = true;
                         }
                     }
-                }
-                if constexpr (PARK) {
-                    g.near_ = park[384], g.far_ = park[448], len = park[512];
-                    i = __float_as_uint(park[576]), end = __float_as_uint(park[640]), link = __float_as_uint(park[704]), inst = __float_as_uint(park[768]);
                 }
                 if (found) {
                     hit.instance = int32_t(inst);
                     g.near_ = lr.near_ / len;
                     g.far_ = lr.far_ / len;
-                }
-                if constexpr (PARK) {
-                    g.o = v3{park[0], park[64], park[128]};
-                    g.d = v3{park[192], park[256], park[320]};
-                    prepare<RCP>(g, scene_fast);
                 }
             }
         } else if (n == s.tlas_root) {
@@ -1151,9 +948,6 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
         n = link;
     }
     ray.near_ = g.near_, ray.far_ = g.far_;
-    if constexpr (PARK) {
-        if (hit.instance >= 0) hit.bx = park[832], hit.by = park[896], hit.external = park[960] != 0.0f;
-    }
     return hit.instance >= 0 ? 2 : 1;
 }
 
@@ -1168,7 +962,7 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
 //   number, and the index in the low word is the reference's "first found wins" — the winning lane leaves the barycentrics in LDS.
 // A leaf's triangles tested against the range the lane held when it reached the leaf, then reduced by (t, index), give what testing
 // them one by one in index order gives (each accepted t is strictly smaller, or equal with a lower index than a hit of another
-// leaf): same boxes, same triangles, same hits as closest_hit_skip<.., ORDERED>.  The caller brings all 64 lanes (`active` = has a
+// leaf): same boxes, same triangles, same hits as a per-lane front-to-back walk with tri_hit_ordered.  The caller brings all 64 lanes (`active` = has a
 // ray).  LDS per wave: CoopLds::kBytes.
 #define RZ_LDS __attribute__((address_space(3)))
 struct CoopLds {  // LDS-qualified pointers: ds_read / ds_write / ds_min_u64, not flat accesses
@@ -1334,7 +1128,7 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
 
 // anyIntersection (cpu_engine_kernel.cpp:398-481) on skip links, with the tree tops from LDS: the shadow-ray walk of the
 // kernels that have a TopCache.  Same tests in the same order as any_hit_stack; returns the mask's alpha (0 or 1).
-template <bool COUNT, bool RCP, bool ORDERED = false>
+template <bool COUNT, bool RCP>
 RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
     WalkRay g;
@@ -1345,8 +1139,7 @@ RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, 
         RZ_GUARD(guard);
         float4 n0, n1;
         uint32_t link;
-        if constexpr (ORDERED) fetch_node_ordered(s, n, 0u, n0, n1, link);
-        else fetch_node(s, top, n, n0, n1, link);
+        fetch_node(s, top, n, n0, n1, link);
         RZ_COUNT(box_tests);
         RZ_COUNT(shadow_box_tests);
         if (box_hit<RCP>(n0, n1, g)) {
@@ -1367,7 +1160,6 @@ RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, 
                 WalkRay lr;
                 to_local<RCP>(x, g, lr, scene_fast);
                 uint32_t m = x.blas_root;
-                const uint32_t oct = ORDERED ? octant_of(lr.d) : 0u;  // any order finds the same answer; occluders tend to be near
                 // anyIntersection(const Mesh&, ...) :450-481, in the bounded while-while rounds of closest_hit_skip
                 uint32_t tj = 0u, tj_end = 0u;
                 const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? s.walk_l : 0xFFFFFFFFu;
@@ -1378,15 +1170,13 @@ RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, 
                         k += 1u;
                         float4 m0, m1;
                         uint32_t mlink;
-                        if constexpr (ORDERED) fetch_node_ordered(s, m, oct, m0, m1, mlink);
-                        else fetch_node(s, top, m, m0, m1, mlink);
+                        fetch_node(s, top, m, m0, m1, mlink);
                         RZ_COUNT(box_tests);
                         RZ_COUNT(shadow_box_tests);
                         if (box_hit<RCP>(m0, m1, lr)) {
                             const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                             if (!(mmeta & HIPRZ_NODE_LEAF)) {
                                 m = mbegin;
-                                if constexpr (ORDERED) m += (oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u;
                                 continue;
                             }
                             tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
@@ -1527,146 +1317,6 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
     return occluded ? 0.0f : 1.0f;
 }
 
-// ---- MODE 5: the MODE 3 walk in ROUNDS, with ray requeueing ----
-// A wave lasts as long as its slowest ray and ray cost is heavy-tailed (config D: the slowest of 64 rays is ~12x the mean;
-// 13 % lane utilisation in MODE 3).  Here a lane that is inside a mesh walk with fewer than `threshold` companions left in
-// that loop stops ("bails"): it stores its walk state (world leaf, slot, mesh node, closest hit so far: 48 B) into a queue
-// and the NEXT round's kernel resumes those rays in dense waves.  The last round never bails.  A ray executes exactly the
-// tests of MODE 3, in the same order, whichever round they happen in: resuming re-derives the mesh-space ray from the same
-// inputs (same instructions) and re-tests nothing.
-struct WalkResume {
-    uint32_t n, i, m;  // world-tree leaf, slot in tlas_order, next mesh node
-    bool in_mesh, found;
-    float lr_far;      // mesh-space far (closest hit so far in this mesh)
-};
-#define RZ_REQUEUE_MIN_STEPS 2u
-// returns 0 root box missed, 1 nothing hit, 2 hit, 3 bailed (rs + ray.near_/far_ + hit hold the state to resume from)
-template <bool COUNT, bool RCP, bool CAN_BAIL>
-RZ_DEV int closest_hit_requeue(const DScene& s, const TopCache& top, Ray& ray, Hit& hit, WalkResume& rs, uint32_t threshold, Counters& cnt) {
-    const bool scene_fast = s.fast_div != 0u;
-    WalkRay g;
-    g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
-    prepare<RCP>(g, scene_fast);
-    uint32_t n = rs.n, guard = 0u;
-    bool resume = rs.in_mesh;
-    while (n != RZ_END) {
-        RZ_GUARD(guard);
-        float4 n0, n1;
-        uint32_t link;
-        fetch_node(s, top, n, n0, n1, link);
-        const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
-        uint32_t i = begin;
-        if (resume) {
-            i = rs.i;  // n is the leaf the ray was in: its box test is done
-        } else {
-            RZ_COUNT(box_tests);
-            if (!box_hit<RCP>(n0, n1, g)) {
-                if (n == s.tlas_root) return 0;  // root box missed (cpu_engine_kernel.cpp:283)
-                n = link;
-                continue;
-            }
-            if (!(meta & HIPRZ_NODE_LEAF)) {
-                n = begin;
-                continue;
-            }
-        }
-        const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
-        for (; i < end; ++i) {
-            const uint32_t inst = s.tlas_order[i];
-            if (!resume) {
-                float4 ib0, ib1;
-                load_instance_box(s, inst, ib0, ib1);
-                RZ_COUNT(box_tests);
-                if (!box_hit<RCP>(ib0, ib1, g)) continue;
-            }
-            const InstanceXform x = load_instance_xform(s, inst);
-            WalkRay lr;
-            const float len = to_local<RCP>(x, g, lr, scene_fast);
-            bool found = false;
-            uint32_t m = x.blas_root;
-            if (resume) {
-                found = rs.found, m = rs.m, lr.far_ = rs.lr_far;
-                resume = false;
-            }
-            uint32_t steps = 0u;
-            while (true) {
-                if constexpr (CAN_BAIL) {
-                    if (steps >= RZ_REQUEUE_MIN_STEPS && uint32_t(__popcll(__ballot(1))) < threshold) {
-                        rs.n = n, rs.i = i, rs.m = m, rs.in_mesh = true, rs.found = found, rs.lr_far = lr.far_;
-                        ray.near_ = g.near_, ray.far_ = g.far_;
-                        return 3;
-                    }
-                    steps += 1u;
-                }
-                uint32_t leaf_begin = 0u, leaf_end = 0u;
-                while (m != RZ_END) {
-                    RZ_GUARD(guard);
-                    float4 m0, m1;
-                    uint32_t mlink;
-                    fetch_node(s, top, m, m0, m1, mlink);
-                    RZ_COUNT(box_tests);
-                    if (box_hit<RCP>(m0, m1, lr)) {
-                        const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
-                        if (!(mmeta & HIPRZ_NODE_LEAF)) {
-                            m = mbegin;
-                            continue;
-                        }
-                        leaf_begin = mbegin, leaf_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
-                        m = mlink;
-                        if (leaf_end > leaf_begin) break;
-                        continue;
-                    }
-                    m = mlink;
-                }
-                if (leaf_end == leaf_begin) break;
-                for (uint32_t j = leaf_begin; j < leaf_end; ++j) {
-                    const float4 a = s.tris[3 * j], b = s.tris[3 * j + 1], c = s.tris[3 * j + 2];
-                    float t, b1, b2, det;
-                    RZ_COUNT(tri_tests);
-                    if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
-                        lr.far_ = t;
-                        hit.triangle = j;
-                        hit.external = det > 0.0f;
-                        hit.bx = b1, hit.by = b2;
-                        found = true;
-                    }
-                }
-            }
-            if (found) {
-                hit.instance = int32_t(inst);
-                g.near_ = lr.near_ / len;
-                g.far_ = lr.far_ / len;
-            }
-        }
-        n = link;
-    }
-    ray.near_ = g.near_, ray.far_ = g.far_;
-    return hit.instance >= 0 ? 2 : 1;
-}
-
-// ---- MODE 4: persistent lanes on the flat walk graph ----
-// A wave is as slow as its slowest ray, and the cost of a ray is heavy-tailed (config D: 7x between the mean and the
-// slowest of 64), so one-ray-per-lane leaves ~87 % of the lanes idle.  Here a workgroup owns a POOL of rays and every
-// lane runs a flat loop over the walk graph of MODE 0 (world nodes, INSTANCE pseudo-nodes and mesh nodes are all "test
-// a box, follow a link"); a lane whose ray is finished takes the next ray of the pool (LDS atomic) at the top of the
-// loop, so lanes stay busy until the pool is empty.  Leaves are postponed: lanes step through nodes until each HOLDS a
-// leaf (or its ray ended), then all test their triangles together.  Per ray the sequence of tests is the reference's.
-struct WalkTop {  // the first `count` walk-graph nodes + links, staged in LDS
-    const float4* nodes;
-    const uint32_t* skip;
-    uint32_t count;
-};
-RZ_DEV void fetch_walk_node(const DScene& s, const WalkTop& top, uint32_t n, float4& n0, float4& n1, uint32_t& link) {
-    if (n < top.count) {
-        n0 = top.nodes[2 * n], n1 = top.nodes[2 * n + 1], link = top.skip[n];
-    } else {
-        n0 = s.wnodes[2 * n], n1 = s.wnodes[2 * n + 1], link = s.wskip[n];
-    }
-}
-
-// Returns 0 = no instances / root box missed (the reference returns before it computes the
-// sky texcrd, cpu_engine_kernel.cpp:282-283), 1 = walked, nothing hit (sky texcrd is computed,
-// :292-295), 2 = hit.
 template <int MODE, bool COUNT, bool RCP>
 RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit, Counters& cnt) {
     hit.instance = -1;
@@ -1674,8 +1324,7 @@ RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit
     hit.bx = hit.by = 0.0f;
     hit.external = true;
     if (s.n_instances == 0) return 0;
-    if constexpr (MODE == 0) return walk_threaded<false, COUNT>(s, ray, hit, cnt);
-    else return closest_hit_stack<COUNT, RCP>(s, lds_column, ray, hit, cnt);  // MODE 2 calls closest_hit_binned directly
+    return closest_hit_stack<COUNT, RCP>(s, lds_column, ray, hit, cnt);  // MODE 2 calls closest_hit_binned directly
 }
 // what a shadow-ray walk needs besides the scene: the lane's LDS stack column (MODE 1) or the staged tree tops (MODE 3)
 // MODE 4 ("defer"): no walk here — the sample's shadow ray and its unshadowed radiance term are written out for
@@ -1712,12 +1361,6 @@ RZ_DEV float any_hit(const DScene& s, const ShadowCtx& sc, const Ray& ray, Count
     if (s.n_instances == 0) return 0.0f;
     if constexpr (MODE == 3) {
         return any_hit_skip<COUNT, RZ_SHADE_SHARED_RCP != 0>(s, sc.top, ray, cnt);
-    } else if constexpr (MODE == 7) {  // MODE 3 with front-to-back mesh walks
-        return any_hit_skip<COUNT, RZ_SHADE_SHARED_RCP != 0, true>(s, sc.top, ray, cnt);
-    } else if constexpr (MODE == 0) {
-        Ray r = ray;
-        Hit unused;
-        return float(walk_threaded<true, COUNT>(s, r, unused, cnt));
     } else {
         return any_hit_stack<COUNT>(s, lds_column, ray, cnt);
     }

@@ -1,0 +1,52 @@
+// hiprz_launch_shade.hip — split pipeline, second half of a pass: everything of traceRay after the closest hit
+// (cpu_engine_kernel.cpp:118-177) in rz_shade_kernel, and — for scenes with lights that are not staged in LDS — the pass's
+// shadow rays (anyIntersection, :398-481) in a lean kernel of their own, walked in their own sorted order.
+#include "hiprz_ctx.hpp"
+#include "hiprz_kernels.hpp"
+
+namespace hiprz {
+namespace {
+
+template <bool FIRST, bool COUNT>
+void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
+    const PassGeometry g = pass_geometry(c);
+    const DConfig cfg = make_config(c);
+    const dim3 grid = g.grid, block = g.block;
+    const bool lights = c->dscene.n_spot_lights + c->dscene.n_direct_lights != 0u;
+    if (!lights && c->nolight_kernels && c->n_textures == 0u) {  // no lights, no maps
+        if (g.lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_PLAIN>), grid, block, g.blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_PLAIN>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+    } else if (!lights && c->nolight_kernels) {  // no next-event estimation: the instantiation without it (no shadow walk, no LDS stack)
+        if (g.lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_NONE>), grid, block, g.blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_NONE>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+    } else if (g.lds_scene) {  // shadow rays inline: LDS-stack walk on the staged scene
+        hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, 1>), grid, block, g.blob + g.stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+    } else if (lights && defer_shadows(c)) {
+        // shading without shadow walks, then every shadow ray of the pass in a lean single-wave kernel
+        hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        // the next pass's ray order is sorted here so that the shadow kernel may follow it when it has no order of its own
+        launch_sort(c);
+        if (f.shadow_key) launch_shadow_sort(c);
+        const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
+        if (COUNT ? c->walk_order == 2 : c->walk_order != 0) {
+            hipLaunchKernelGGL((rz_shadow_coop_kernel<FIRST, COUNT, 4>), sgrid, sblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
+        } else {
+            const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;
+            const uint32_t top_n = std::min<uint32_t>(c->dscene.top_count, big_trees ? 170u : 272u);
+            if (big_trees) hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 6>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
+            else hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 4>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
+        }
+    } else {  // shadow rays inline on skip links with the tree tops staged in LDS
+        const uint32_t shade_top = std::min<uint32_t>(c->dscene.top_count, kTopCacheNodes);
+        hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, 3>), grid, block, TopCache::bytes_host(shade_top), c->stream, c->dscene, c->dcamera, cfg, f, shade_top);
+    }
+}
+
+}  // namespace
+
+void launch_shade(hiprz_ctx* c, const DFrame& f, bool first, bool counted) {
+    if (first) counted ? launch_shade_t<true, true>(c, f) : launch_shade_t<true, false>(c, f);
+    else counted ? launch_shade_t<false, true>(c, f) : launch_shade_t<false, false>(c, f);
+}
+
+}  // namespace hiprz

@@ -1,0 +1,45 @@
+// hiprz_launch_trace.hip — split pipeline, first half of a pass: the closest-hit walk of every owned pixel's ray
+// (traverseWorld + closestIntersection, cpu_engine_kernel.cpp:254-352) -> a 20-byte hit record per pixel.
+// Instantiates rz_trace_coop_kernel / rz_trace_skip_kernel / rz_trace_kernel (hiprz_kernels.hpp).
+#include "hiprz_ctx.hpp"
+#include "hiprz_kernels.hpp"
+
+namespace hiprz {
+namespace {
+
+template <bool FIRST, bool COUNT>
+void launch_trace_t(hiprz_ctx* c, const DFrame& f) {
+    const PassGeometry g = pass_geometry(c);
+    if (g.mode == 3) {
+        // one wave per workgroup: a workgroup's slot is free as soon as ITS slowest ray is done
+        const dim3 grid(c->n_local_tiles * 4u), block(64);
+        if (COUNT ? c->walk_order == 2 : c->walk_order != 0) {
+            // front-to-back mesh walks on per-octant skip links with the cooperative triangle phase; 4 waves per SIMD for every
+            // tree size (D: 1 037 us against 1 131 us with 6 waves)
+            if (c->trace_waves >= 6) hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 6>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
+            else hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 4>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
+        } else {
+            // the reference's child order (what the work counters are anchored on), tree tops cached in LDS: 160 KiB over 24 (6 waves
+            // per SIMD: big trees want occupancy) or 16 (4) single-wave workgroups per CU
+            const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;
+            const uint32_t top_n = std::min<uint32_t>(c->dscene.top_count, big_trees ? 170u : 272u);
+            if (big_trees) hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 6>), grid, block, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, f, top_n);
+            else hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 4>), grid, block, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, f, top_n);
+        }
+    } else if (g.mode == 2) {
+        if (g.lds_scene) hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 2, true>), g.grid, g.block, g.blob + g.walk_lds, c->stream, c->dscene, c->dcamera, f);
+        else hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 2, false>), g.grid, g.block, g.walk_lds, c->stream, c->dscene, c->dcamera, f);
+    } else {
+        if (g.lds_scene) hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 1, true>), g.grid, g.block, g.blob + g.walk_lds, c->stream, c->dscene, c->dcamera, f);
+        else hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 1, false>), g.grid, g.block, g.walk_lds, c->stream, c->dscene, c->dcamera, f);
+    }
+}
+
+}  // namespace
+
+void launch_trace(hiprz_ctx* c, const DFrame& f, bool first, bool counted) {
+    if (first) counted ? launch_trace_t<true, true>(c, f) : launch_trace_t<true, false>(c, f);
+    else counted ? launch_trace_t<false, true>(c, f) : launch_trace_t<false, false>(c, f);
+}
+
+}  // namespace hiprz

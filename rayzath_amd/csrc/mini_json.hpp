@@ -34,6 +34,8 @@ struct Json {
 struct JsonParser {
     const std::string& s;
     size_t i = 0;
+    int depth = 0;                         // nesting of the value being parsed
+    static constexpr int kMaxDepth = 128;  // scene files nest 6 deep; an untrusted file must not recurse the host stack away
     explicit JsonParser(const std::string& text) : s(text) {}
     [[noreturn]] void error(const std::string& why) { throw std::runtime_error("json: " + why + " at byte " + std::to_string(i)); }
     void skip() {
@@ -62,6 +64,12 @@ struct JsonParser {
         if (i >= s.size()) error("unexpected end");
         Json v;
         const char c = s[i];
+        struct Nest {
+            int& d;
+            explicit Nest(int& depth) : d(depth) { ++d; }
+            ~Nest() { --d; }
+        } nest(depth);
+        if (depth > kMaxDepth) error("nested deeper than " + std::to_string(kMaxDepth) + " levels");
         if (c == '{') {
             v.kind = Json::Object;
             ++i;

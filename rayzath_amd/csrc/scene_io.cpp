@@ -341,7 +341,7 @@ MapDesc parse_map_statement(const std::string& statement, const std::string& whe
         if (p == "-o" || p == "-s") {
             float a, b;
             if (!(params >> a >> b)) {
-                log.error(where + "Invalid values for \"" + p + "\" parameter. At least two numeric values are required.");
+                log.error(where + "option \"" + p + "\" needs two numbers");
                 params.clear();
                 continue;
             }
@@ -370,7 +370,7 @@ MapDesc parse_map_statement(const std::string& statement, const std::string& whe
 
 std::vector<NamedMaterial> loadMTL(const std::string& path, LoadLog& log) {
     std::ifstream file(path);
-    if (!file.is_open()) fail("Failed to open file " + path);
+    if (!file.is_open()) fail("cannot open " + path);
     const std::string dir = parent_dir(path);
     std::vector<NamedMaterial> out;
     std::set<std::string> unrecognized;
@@ -392,7 +392,7 @@ std::vector<NamedMaterial> loadMTL(const std::string& path, LoadLog& log) {
             continue;
         }
         if (out.empty()) {
-            log.warning("First statement in file wasn't the \"newmtl\". Ignored.");
+            log.warning("statement before the first newmtl skipped");
             continue;
         }
         Material& mat = *out.back().material;
@@ -409,20 +409,20 @@ std::vector<NamedMaterial> loadMTL(const std::string& path, LoadLog& log) {
         if (statement == "Kd") {
             float c[3] = {0, 0, 0};
             if (!number(in, c[0])) {
-                log.error(where + "invalid color specification (one or three numeric values [0.0, 1.0] required)");
+                log.error(where + "Kd needs one or three numbers in [0, 1]");
                 continue;
             }
             if (!number(in, c[1])) {
                 c[1] = c[2] = c[0];
             } else if (!number(in, c[2])) {
-                log.error(where + "invalid blue value (one or three color numeric values [0.0, 1.0] required)");
+                log.error(where + "Kd: the third (blue) component is not a number in [0, 1]");
                 continue;
             }
             for (float& x : c) x = clampf(x, 0.0f, 1.0f);
             mat.color.red = uint8_t(c[0] * 255.0f), mat.color.green = uint8_t(c[1] * 255.0f), mat.color.blue = uint8_t(c[2] * 255.0f);
         } else if (statement == "Ns") {
             if (!number(in, v)) {
-                log.error(where + "Invalid exponent for \"Ns\" statement. Numeric value [1.0, 1000.0] required.");
+                log.error(where + "Ns needs a number in [1, 1000]");
                 continue;
             }
             const float clamped = clampf(v, 1.0f, 1000.0f);
@@ -430,31 +430,31 @@ std::vector<NamedMaterial> loadMTL(const std::string& path, LoadLog& log) {
             mat.roughness(1.0f - (std::log10(clamped) / std::log10(1000.0f)));
         } else if (statement == "d" || statement == "Tr") {
             if (!number(in, v)) {
-                log.error(where + "Invalid paremeter for \"" + statement + "\" statement. Numeric value in [0.0, 1.0] required.");
+                log.error(where + statement + " needs a number in [0, 1]");
                 continue;
             }
             const float clamped = clampf(v, 0.0f, 1.0f);
-            if (clamped != v) log.warning(where + "Value " + std::to_string(v) + " is outside of [0.0, 1.0] range. Clamped.");
+            if (clamped != v) log.warning(where + std::to_string(v) + " clamped to [0, 1]");
             mat.color.alpha = uint8_t((statement == "d" ? clamped : 1.0f - clamped) * 255.0f);
         } else if (statement == "Ni") {
             if (!number(in, v)) {
-                log.error(where + "Invalid paremeter for \"Ni\" statement. Numeric value >= 1.0 required.");
+                log.error(where + "Ni needs a number >= 1");
                 continue;
             }
-            if (v < 1.0f) log.warning(where + "Value for \"Ni\" was less than 1.0. Clamped.");
+            if (v < 1.0f) log.warning(where + "Ni below 1 raised to 1");
             mat.ior(v);
         } else if (statement == "Pm" || statement == "Pr") {
             if (!number(in, v)) {
-                log.error(where + "Invalid paremeter for \"" + statement + "\" statement. Numeric value in[0.0, 1.0] required.");
+                log.error(where + statement + " needs a number in [0, 1]");
                 continue;
             }
             const float clamped = clampf(v, 0.0f, 1.0f);
-            if (clamped != v) log.warning(where + "Value for \"" + statement + "\" is outside of [0.0, 1.0] range. Clamped.");
+            if (clamped != v) log.warning(where + statement + " clamped to [0, 1]");
             if (statement == "Pm") mat.metalness(clamped);
             else mat.roughness(clamped);
         } else if (statement == "Ke") {
             if (!number(in, v)) {
-                log.error(where + "Invalid paremeter for \"Ke\" statement. Positive numeric value required.");
+                log.error(where + "Ke needs a number >= 0");
                 continue;
             }
             if (v < 0.0f) log.warning(where + "Value for \"Ke\" is less than 0.0. Clamped.");
@@ -470,7 +470,7 @@ std::vector<NamedMaterial> loadMTL(const std::string& path, LoadLog& log) {
         } else if (statement == "map_Ke") {
             attach(mat.emission_map, HIPRZ_TEX_R32F, false);
         } else if (unrecognized.insert(statement).second) {
-            log.warning("Unrecognized statement \"" + statement + "\".");
+            log.warning("unknown statement '" + statement + "' skipped");
         }
     }
     return out;
@@ -481,7 +481,7 @@ std::vector<NamedMaterial> loadMTL(const std::string& path, LoadLog& log) {
 // ---------------------------------------------------------------------------------------------------------
 ObjFile parseOBJ(const std::string& path, LoadLog& log) {
     std::ifstream file(path);
-    if (!file.is_open()) fail("Failed to open file " + path);
+    if (!file.is_open()) fail("cannot open " + path);
     constexpr uint32_t npos = Mesh::ids_unused;
     ObjFile result;
     std::vector<std::array<float, 3>> vertices, normals;
@@ -522,23 +522,23 @@ ObjFile parseOBJ(const std::string& path, LoadLog& log) {
         }
         if (statement == "v") {
             std::array<float, 3> v{};
-            if (!(in >> v[0] >> v[1] >> v[2])) log.error("Vertex definition on line " + ln + " is invalid. Three numeric values are required.");
+            if (!(in >> v[0] >> v[1] >> v[2])) log.error("line " + ln + ": v needs three numbers");
             v[2] = -v[2];  // right-handed -> left-handed
             vertices.push_back(v);
             continue;
         }
         if (statement == "vt") {
             std::array<float, 2> t{};
-            if (!(in >> t[0] >> t[1])) log.error("Texture coordinate definition on line " + ln + " is invalid. Two numeric values are required.");
+            if (!(in >> t[0] >> t[1])) log.error("line " + ln + ": vt needs two numbers");
             texcrds.push_back(t);
             continue;
         }
         if (statement == "vn") {
             std::array<float, 3> n{};
-            if (!(in >> n[0] >> n[1] >> n[2])) log.error("Vertex normal definition on line " + ln + " is invalid. Three numeric values are required.");
+            if (!(in >> n[0] >> n[1] >> n[2])) log.error("line " + ln + ": vn needs three numbers");
             n[2] = -n[2];
             if (std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]) < std::numeric_limits<float>::epsilon()) {
-                log.warning("Line " + ln + ": normal is invalid (vector length close or equal to zero).");
+                log.warning("Line " + ln + ": zero-length normal");
                 n = {0.0f, 1.0f, 0.0f};
             }
             normals.push_back(n);
@@ -555,7 +555,7 @@ ObjFile parseOBJ(const std::string& path, LoadLog& log) {
             continue;
         }
         if (result.meshes.empty()) {
-            log.warning("Statement in line " + ln + " has to be preceded by object or group declaration. Ignored.");
+            log.warning("line " + ln + ": no o / g statement yet, skipped");
             continue;
         }
         ObjMesh& cur = result.meshes.back();
@@ -583,7 +583,7 @@ ObjFile parseOBJ(const std::string& path, LoadLog& log) {
                     if (!part.empty()) {
                         char* stop = nullptr;
                         const long v = std::strtol(part.c_str(), &stop, 10);
-                        if (stop == part.c_str() || *stop != '\0') log.error("Definition of face on line " + ln + ": one of defined indices of " + std::to_string(corners) + " vertex is invalid.");
+                        if (stop == part.c_str() || *stop != '\0') log.error("line " + ln + ": corner " + std::to_string(corners) + " of the face has a malformed index");
                         else idx[corners][k] = int32_t(v);
                     }
                     if (end == std::string::npos) break;
@@ -592,7 +592,7 @@ ObjFile parseOBJ(const std::string& path, LoadLog& log) {
                 ++corners;
             }
             if (corners < 3) {
-                log.error("On line " + ln + ": at least three vertex indices description are required to create a valid face.");
+                log.error("line " + ln + ": a face needs at least three corners");
                 continue;
             }
             uint32_t triplet[max_n_gon][3];
@@ -619,7 +619,7 @@ ObjFile parseOBJ(const std::string& path, LoadLog& log) {
                 cur.mesh->createTriangle({triplet[0][0], triplet[i + 2][0], triplet[i + 1][0]}, {triplet[0][1], triplet[i + 2][1], triplet[i + 1][1]},
                                          {triplet[0][2], triplet[i + 2][2], triplet[i + 1][2]}, material_idx);
         } else if (unrecognized.insert(statement).second) {
-            log.warning("Unrecognized statement \"" + statement + "\".");
+            log.warning("unknown statement '" + statement + "' skipped");
         }
     }
     if (!result.meshes.empty()) finish_mesh(*result.meshes.back().mesh);
@@ -627,14 +627,14 @@ ObjFile parseOBJ(const std::string& path, LoadLog& log) {
 }
 
 std::vector<std::shared_ptr<Instance>> loadObjInstances(const std::string& path, World& world, LoadLog& log) {
-    if (extension(path) != ".obj") fail("Path \"" + path + "\" is not a valid path to .obj file.");
+    if (extension(path) != ".obj") fail(path + ": not an .obj file");
     ObjFile obj = parseOBJ(path, log);
     std::map<std::string, std::shared_ptr<Material>> materials;
     for (const auto& lib : obj.mtllibs) {
         try {
             for (auto& m : loadMTL(make_load_path(lib, parent_dir(path)), log)) {
                 if (!materials.emplace(m.name, m.material).second)
-                    log.error("The file \"" + path + "\" declared usage of material libraries, which resulted in material name duplication (" + m.name + ").");
+                    log.error(path + ": its material libraries define '" + m.name + "' more than once");
                 else world.materials.push_back(m.material);
             }
         } catch (const Exception& e) {
@@ -676,10 +676,10 @@ struct SceneLoader {
         static const uint32_t kinds[5] = {HIPRZ_TEX_RGBA8, HIPRZ_TEX_RGBA8, HIPRZ_TEX_R8, HIPRZ_TEX_R8, HIPRZ_TEX_R32F};
         if (j.is_string()) {
             const auto it = maps[which].find(j.str);
-            if (it == maps[which].end()) return log.error("\"" + j.str + "\" is not yet a loaded map."), nullptr;
+            if (it == maps[which].end()) return log.error("no map named '" + j.str + "' has been loaded so far"), nullptr;
             return it->second;
         }
-        if (!j.is_object()) return log.error("Value of map definition has to be either a string or an object."), nullptr;
+        if (!j.is_object()) return log.error("a map is given by name or as an object"), nullptr;
         std::shared_ptr<TextureBuffer> t;
         if (const Json* f = j.find("file"); f && f->is_string()) t = load_map(make_load_path(f->str, dir), kinds[which], which == 1, log);
         if (!t) return nullptr;
@@ -719,10 +719,10 @@ struct SceneLoader {
     }
     // the world / default material: generate statement, then a whole .mtl, then the json properties (json_loader.cpp:252-281)
     void load_into(const Json& j, Material& m) {
-        if (!j.is_object()) return log.error("Value of material definition has to be either a string or an object.");
+        if (!j.is_object()) return log.error("a material is given by name or as an object");
         generate_material(j, m);
         if (const Json* f = j.find("file")) {
-            if (!f->is_string()) log.error("Value of \"file\" property must be a string.");
+            if (!f->is_string()) log.error("\"file\" must be a string");
             else if (auto loaded = loadMTL(make_load_path(f->str, dir), log); !loaded.empty()) m = *loaded.front().material;
         }
         do_load_material(j, m);
@@ -730,18 +730,18 @@ struct SceneLoader {
     std::shared_ptr<Material> load_material(const Json& j) {  // json_loader.cpp:190-251
         if (j.is_string()) {
             const auto it = materials.find(j.str);
-            if (it == materials.end()) return log.error("\"" + j.str + "\" is not yet a loaded material."), nullptr;
+            if (it == materials.end()) return log.error("no material named '" + j.str + "' has been loaded so far"), nullptr;
             return it->second;
         }
-        if (!j.is_object()) return log.error("Value of material definition has to be either a string or an object."), nullptr;
+        if (!j.is_object()) return log.error("a material is given by name or as an object"), nullptr;
         std::shared_ptr<Material> m;
         std::string name = "material name";
         if (const Json* f = j.find("file")) {
             if (!f->is_string()) {
-                log.error("Value of \"file\" property must be a string.");
+                log.error("\"file\" must be a string");
             } else {
                 auto loaded = loadMTL(make_load_path(f->str, dir), log);
-                if (loaded.size() != 1) log.warning("Expected exactly one material loaded from file \"" + f->str + "\".");
+                if (loaded.size() != 1) log.warning(f->str + " holds " + std::to_string(loaded.size()) + " materials where one is wanted");
                 else m = loaded.front().material, name = loaded.front().name;
             }
         }
@@ -759,7 +759,7 @@ struct SceneLoader {
         const char* which = nullptr;
         for (const char* s : statements)
             if (const Json* g = j.find(s)) {
-                if (!g->is_object()) return log.error(std::string("value of \"") + s + "\" generation definition must be an object"), nullptr;
+                if (!g->is_object()) return log.error(std::string("\"") + s + "\" takes an object of parameters"), nullptr;
                 which = s;
             }
         if (!which) return nullptr;
@@ -783,7 +783,7 @@ struct SceneLoader {
                 if (key == "resolution" && value.is_number()) res = resolution(value);
                 if (key == "normals" && value.is_bool()) normals = value.b;
                 if (key == "texcrds" && value.is_bool()) texcrds = value.b;
-                if (key == "type" && value.is_string() && value.str != "uvsphere") fail(value.str == "icosphere" ? "icosphere is declared but not implemented by the reference (world.cpp:336)" : "invalid sphere type: " + value.str);
+                if (key == "type" && value.is_string() && value.str != "uvsphere") fail(value.str == "icosphere" ? "icosphere is declared but not implemented by the reference (world.cpp:336)" : "unknown sphere type '" + value.str + "'");
             }
             return generateSphere(std::max(res, 4u), normals, texcrds);
         }
@@ -821,11 +821,11 @@ struct SceneLoader {
     std::shared_ptr<Mesh> load_mesh(const Json& j) {  // json_loader.cpp:538-662
         if (j.is_string()) {
             const auto it = meshes.find(j.str);
-            if (it == meshes.end()) return log.error("\"" + j.str + "\" is not yet a loaded mesh."), nullptr;
+            if (it == meshes.end()) return log.error("no mesh named '" + j.str + "' has been loaded so far"), nullptr;
             return it->second;
         }
-        if (!j.is_object()) return log.error("Value of mesh definition has to be either a string or an object."), nullptr;
-        if (!j.contains("name") && !j.contains("file")) return log.error("mesh definition has to contain \"name\" property, when not loaded from file."), nullptr;
+        if (!j.is_object()) return log.error("a mesh is given by name or as an object"), nullptr;
+        if (!j.contains("name") && !j.contains("file")) return log.error("an inline mesh needs a \"name\""), nullptr;
         std::string name = "default";
         if (const Json* n = j.find("name"); n && n->is_string()) name = n->str;
         auto publish = [&](std::shared_ptr<Mesh> m, const std::string& as) {
@@ -840,7 +840,7 @@ struct SceneLoader {
                 log.error("File name has to be a string.");
             } else {
                 ObjFile obj = parseOBJ(make_load_path(f->str, dir), log);
-                if (obj.meshes.size() != 1) log.warning(std::to_string(obj.meshes.size()) + " meshes loaded from " + f->str + ". Exactly one is expected in scene mesh definition.");
+                if (obj.meshes.size() != 1) log.warning(f->str + " holds " + std::to_string(obj.meshes.size()) + " meshes where one is wanted");
                 if (obj.meshes.empty()) fail("no mesh loaded from " + f->str);
                 return publish(obj.meshes.front().mesh, obj.meshes.front().name);
             }
@@ -944,9 +944,9 @@ struct SceneLoader {
         if (!j.is_object()) return log.error("Value of instance definition has to be an object.");
         std::shared_ptr<Instance> inst;
         if (const Json* f = j.find("file")) {
-            if (!f->is_string()) return log.error("Value of \"file\" property in instance definition must be a string.");
+            if (!f->is_string()) return log.error("instance: \"file\" must be a string");
             auto loaded = loadObjInstances(make_load_path(f->str, dir), world, log);
-            if (loaded.size() != 1) log.warning(std::to_string(loaded.size()) + " instances loaded from " + f->str + ". Exactly one is expected in scene instance definition.");
+            if (loaded.size() != 1) log.warning(f->str + " holds " + std::to_string(loaded.size()) + " instances where one is wanted");
             if (!loaded.empty()) inst = loaded.front();
         }
         if (!inst) inst = std::make_shared<Instance>(), world.instances.push_back(inst);
@@ -968,11 +968,11 @@ struct SceneLoader {
                         if (material_count < Instance::materialCapacity()) set_material(load_material(m));
                 } else if (value.is_string() && material_count < Instance::materialCapacity()) {
                     const auto it = materials.find(value.str);
-                    if (it == materials.end()) log.error("Reference to material \"" + value.str + "\" in the definition of instance " + name + " is invalid.");
+                    if (it == materials.end()) log.error("instance " + name + ": no material named '" + value.str + "'");
                     else set_material(it->second);
                 }
             } else if (key == "Mesh") {
-                if (inst->mesh) log.warning("Mesh reference for \"" + name + "\" instance already specified. Ignored.");
+                if (inst->mesh) log.warning("instance " + name + ": second mesh reference skipped");
                 else inst->mesh = load_mesh(value);
             }
         }
@@ -1021,9 +1021,9 @@ struct SceneLoader {
 }  // namespace
 
 void loadScene(const std::string& path, World& world, LoadLog& log) {
-    if (extension(path) != ".json") fail("Unsupported extension '" + extension(path) + "'.");
+    if (extension(path) != ".json") fail("scene files end in .json, not '" + extension(path) + "'");
     std::ifstream file(path, std::ios::binary);
-    if (!file.is_open()) fail("Failed to open file " + path);
+    if (!file.is_open()) fail("cannot open " + path);
     std::stringstream text;
     text << file.rdbuf();
     const std::string s = text.str();

@@ -89,13 +89,13 @@ class ShardedFrame:
         on_gpu = device is not None and device.type == "cuda"
         self.stream = torch.cuda.ExternalStream(ctx.stream(), device=device) if on_gpu else None
         self.comm = torch.cuda.Stream(device=device, priority=-1) if on_gpu and overlap and world > 1 else self.stream
-        self.local8 = torch.zeros((self.capacity_max, 1), dtype=torch.int32, device=device)
+        self.local8 = torch.empty((self.capacity_max, 1), dtype=torch.int32, device=device)
         self.local = None
         root = rank == 0
         # the gathered shards live in ONE buffer (shard r = row r) so that one launch untiles them all
-        self.all8 = torch.zeros((world, self.capacity_max, 1), dtype=torch.int32, device=device) if root and world > 1 else None
+        self.all8 = torch.empty((world, self.capacity_max, 1), dtype=torch.int32, device=device) if root and world > 1 else None
         self.parts8 = [self.all8[r] for r in range(world)] if self.all8 is not None else None
-        self.rgba8 = torch.zeros((height, width), dtype=torch.int32, device=device) if root else None
+        self.rgba8 = torch.empty((height, width), dtype=torch.int32, device=device) if root else None
         self.image = None
 
     def _gather(self, local, parts):
@@ -157,10 +157,10 @@ class ShardedFrame:
 
         ctx = self.ctx
         if self.local is None:
-            self.local = torch.zeros((self.capacity_max, 4), dtype=torch.float32, device=self.device)
-            self.all = torch.zeros((self.world, self.capacity_max, 4), dtype=torch.float32, device=self.device) if self.rank == 0 and self.world > 1 else None
+            self.local = torch.empty((self.capacity_max, 4), dtype=torch.float32, device=self.device)
+            self.all = torch.empty((self.world, self.capacity_max, 4), dtype=torch.float32, device=self.device) if self.rank == 0 and self.world > 1 else None
             self.parts = [self.all[r] for r in range(self.world)] if self.all is not None else None
-            self.image = torch.zeros((self.height, self.width, 4), dtype=torch.float32, device=self.device) if self.rank == 0 else None
+            self.image = torch.empty((self.height, self.width, 4), dtype=torch.float32, device=self.device) if self.rank == 0 else None
         self._before_export()
         ctx.export_accum_tiles(self.local.data_ptr(), self.local.numel() * 4)
         parts = self._gather(self.local, self.parts)

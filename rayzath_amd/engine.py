@@ -86,29 +86,10 @@ class Context:
     def set_pipeline(self, pipeline):
         self._check(self.lib.hiprz_set_pipeline(self._ctx, pipeline))
 
-    def set_requeue_schedule(self, thresholds):
-        """Mode 5: lanes that must remain in a mesh walk per bailing round (see include/hiprz.h)."""
-        arr = (C.c_uint32 * max(len(thresholds), 1))(*thresholds)
-        self._check(self.lib.hiprz_set_requeue_schedule(self._ctx, arr, len(thresholds)))
-
     def pipeline(self):
         v = C.c_int()
         self._check(self.lib.hiprz_pipeline(self._ctx, C.byref(v)))
         return v.value
-
-    def set_workgroup_timing(self, enabled):
-        self._check(self.lib.hiprz_set_workgroup_timing(self._ctx, int(enabled)))
-
-    def read_workgroup_times(self, n_workgroups):
-        """(n, 2) uint64: start / end of each trace-kernel workgroup of the last pass, 10 ns ticks."""
-        out = np.zeros((n_workgroups, 2), dtype=np.uint64)
-        self._check(self.lib.hiprz_read_workgroup_times(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint64)), n_workgroups))
-        return out
-
-    def requeue_counts(self, n=32):
-        arr = (C.c_uint32 * n)()
-        self._check(self.lib.hiprz_requeue_counts(self._ctx, arr, n))
-        return list(arr)
 
     def traversal_mode(self):
         v = C.c_int()

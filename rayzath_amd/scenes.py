@@ -123,3 +123,58 @@ CONFIGS = {
     "D": dict(build=lambda: textured_sphere_scene(1920, 1080, 550), max_depth=8, note="301 400-tri textured sphere, 1920x1080 depth 8"),
     "E": dict(build=lambda: living_room(3840, 2160), max_depth=8, note="living room, lights + glass + scattering, 3840x2160"),
 }
+
+
+def shading_inputs_scene(width=160, height=96, seed=11, lights=True):
+    """Every shading input the CPU kernel reads that the BASELINE stand-ins do not use: a metalness map (R8),
+    an emission map (R32F, cpu_engine_kernel.cpp:523-528), textures with rotation / scale / translation other than the identity
+    (render_parts.hpp:209-221), a texture whose alpha channel makes parts of a surface transmissive (:505-512), an emissive AND
+    textured world material (the sky a ray meets on a miss, :292-295), instances whose material slot is unset or missing
+    (the default material, :359-360), under a spot and a direct light.  Open to the sky: no ceiling, no walls."""
+    rng = np.random.default_rng(seed)
+
+    def rgba(h, w, alpha=None, lo=40):
+        c = rng.integers(lo, 256, size=(h, w, 4), dtype=np.uint8)
+        c[..., 3] = 255 if alpha is None else alpha
+        return c
+
+    world = World()
+    sky_em = (rng.uniform(0.0, 1.0, size=(16, 32)) ** 3 * 4.0).astype(np.float32)
+    sky_em[rng.uniform(size=sky_em.shape) < 0.3] = 0.0          # patches of dark sky: the emission test `> 0` goes both ways
+    world.material = Material((255, 255, 255, 0), 0.0, 0.0, 0.0, 1.0, 0.0,
+                              texture=TextureBuffer(rgba(32, 64, alpha=0), scale=(2.0, 1.0), rotation=0.35, translation=(0.1, 0.2)),
+                              emission_map=TextureBuffer(sky_em, scale=(1.0, 3.0), rotation=-0.2, translation=(0.3, 0.0)), name="sky")
+
+    floor_mat = world.add(Material((255, 255, 255, 255), 0.1, 0.8, name="tiles",
+                                   texture=TextureBuffer(rgba(24, 40), scale=(3.0, 2.0), rotation=0.6, translation=(0.25, 0.4)),
+                                   roughness_map=TextureBuffer(rng.integers(0, 256, size=(16, 16), dtype=np.uint8), scale=(5.0, 5.0), rotation=1.1)))
+    em = np.zeros((12, 12), dtype=np.float32)
+    em[2:5, 3:9] = 6.0
+    em[8:10, 1:4] = 0.75
+    panel = world.add(Material((200, 180, 160, 255), 0.5, 0.3, name="panel",
+                               metalness_map=TextureBuffer(rng.integers(0, 256, size=(20, 28), dtype=np.uint8), scale=(2.0, 2.0), translation=(0.5, 0.25)),
+                               emission_map=TextureBuffer(em, rotation=0.25)))
+    stained = rgba(16, 16)
+    stained[..., 3] = np.where(rng.uniform(size=(16, 16)) < 0.5, 255, rng.integers(0, 200, size=(16, 16))).astype(np.uint8)
+    window = world.add(Material((255, 255, 255, 255), 0.0, 0.05, 0.0, 1.3, 0.0, name="stained glass",
+                                texture=TextureBuffer(stained, scale=(1.5, 1.5), rotation=-0.4, translation=(0.2, 0.7))))
+    plain = world.add(Material((90, 110, 220, 255), 0.1, 0.3, name="blue"))
+
+    ground = world.add(generate_plane(4, 6.0, 6.0))
+    cube = world.add(generate_cube())
+    ball = world.add(generate_sphere(24, normals=True, texture_coordinates=True))
+    two_slots = generate_cube()
+    two_slots.tri_materials[:] = np.arange(12, dtype=np.uint32) % 3      # slots 0, 1, 2: the instance below fills only 0 and 1
+    two_slots = world.add(two_slots)
+    world.add(Instance(ground, [floor_mat], position=(0, -1, 0), name="floor"))
+    world.add(Instance(cube, [panel], position=(-1.1, -0.2, 0.8), rotation=(0.1, 0.5, 0.0), scale=(1.3, 1.6, 1.3), name="panel box"))
+    world.add(Instance(ball, [None], position=(0.9, -0.3, 0.3), scale=(0.7, 0.7, 0.7), name="unset slot"))          # slot present, no material
+    world.add(Instance(cube, [], position=(0.2, -0.6, -0.9), rotation=(0.0, 0.3, 0.0), scale=(0.6, 0.8, 0.6), name="no slots"))
+    world.add(Instance(two_slots, [plain, None], position=(-0.3, 0.9, 1.6), rotation=(0.4, 0.2, 0.1), scale=(0.9, 0.9, 0.9), name="slot beyond the table"))
+    world.add(Instance(ball, [window], position=(1.6, 0.4, 1.5), rotation=(0.0, 1.0, 0.3), scale=(0.9, 0.9, 0.9), name="window ball"))
+    if lights:
+        world.add(SpotLight(position=(-1.5, 3.0, -1.5), direction=(0.5, -1.0, 0.6), color=(255, 240, 220, 255), size=0.2, emission=150.0, beam_angle=0.8))
+        world.add(DirectLight(direction=(0.4, -1.0, 0.5), color=(255, 250, 240, 255), emission=25.0, angular_size=0.06))
+    world.camera = Camera(position=(0.0, 0.6, -3.6), rotation=(0.05, 0.0, 0.0), resolution=(width, height), fov=math.pi / 2,
+                          near_far=(1.0e-2, 1.0e3), focal_distance=4.0, aperture=0.02, exposure_time=1.0 / 60.0)
+    return world

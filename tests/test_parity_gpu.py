@@ -24,15 +24,18 @@ from rayzath_amd.scene import camera_struct, flatten
 pytestmark = pytest.mark.gpu
 
 REL, FRACTION = 1e-3, 0.01
+# scenes with lights (next-event estimation behind expf / cosf / acosf: a sample at the `radiance < 1e-4` threshold or a shadow ray
+# grazing an edge differs): measured on MI355X minus 0.2 points, see the printed reports
+LIT_ALPHA, LIT_RGB = 0.98, 0.97
 
 
-def _run_both(world, max_depth, passes, mode=0, spot=1, direct=1, seed=20240501):
+def _run_both(world, max_depth, passes, mode=-1, spot=1, direct=1, seed=20240501):
     flat, cam = flatten(world), camera_struct(world.camera)
     cfg = RenderConfig(LightSampling(spot, direct), Tracing(max_depth, passes), seed).struct()
     ctx = Context(0)
     ctx.set_traversal_mode(mode)
     if mode >= 3:
-        ctx.set_lds_scene(0)  # modes 3 and 4 are for scenes that are not staged whole in LDS
+        ctx.set_lds_scene(0)  # mode 3 is for scenes that are not staged whole in LDS
     ctx.upload_scene(flat)
     ctx.upload_camera(cam)
     ctx.set_config(cfg)
@@ -60,7 +63,7 @@ def _compare(ctx, ref, tag):
     return report
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_first_pass_is_bit_exact_where_no_libm_is_involved(built, mode):
     world = scenes.cornell_box(256, 256)
     ctx, ref = _run_both(world, 4, 1, mode)
@@ -78,7 +81,7 @@ def test_first_pass_is_bit_exact_where_no_libm_is_involved(built, mode):
     assert ctx.ray_count() == ref.traced_rays == 256 * 256
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("mode", [1, 2, 3])
 def test_cornell_config_a(built, mode):
     """BASELINE config A: Cornell box 256x256, depth 4, until >= 4 finished samples everywhere."""
     world = scenes.cornell_box(256, 256)
@@ -112,10 +115,10 @@ def test_lights_glass_scattering_scene(built):
     ctx.render(8)
     ref.render(8)
     rep = _compare(ctx, ref, "living room")
-    assert rep["alpha_equal"] >= 0.98 and rep["rgb_close"] >= 0.97
+    assert rep["alpha_equal"] >= LIT_ALPHA and rep["rgb_close"] >= LIT_RGB
 
 
-@pytest.mark.parametrize("mode", [1, 3, 4])
+@pytest.mark.parametrize("mode", [1, 3])
 def test_sphere_scene_hits(built, mode):
     """Config-C-like: 6 240-triangle sphere with per-vertex normals, deep mesh tree."""
     world = scenes.cornell_sphere(320, 180, 80)
@@ -199,7 +202,7 @@ def test_resident_pipeline_equals_split(built, mode):
 
 def test_ray_reordering_changes_nothing_but_the_order(built):
     """Sorted walk order (keys from the shade kernel, radix sort, permutation) == pixel order, bit for bit."""
-    for world, depth, mode in ((scenes.cornell_sphere(160, 90, 40), 6, 3), (scenes.living_room(96, 64, 16), 5, 4), (scenes.cornell_box(100, 60), 4, 1)):
+    for world, depth, mode in ((scenes.cornell_sphere(160, 90, 40), 6, 3), (scenes.living_room(96, 64, 16), 5, 3), (scenes.cornell_box(100, 60), 4, 1)):
         flat, cam = flatten(world), camera_struct(world.camera)
         cfg = RenderConfig(LightSampling(1, 1), Tracing(depth, 4)).struct()
         out = []
@@ -213,30 +216,6 @@ def test_ray_reordering_changes_nothing_but_the_order(built):
         assert np.array_equal(out[0][0], out[1][0]) and out[0][2] == out[1][2]
         for k in out[0][1]:
             assert np.array_equal(out[0][1][k], out[1][1][k]), k
-
-
-@pytest.mark.parametrize("schedule", [[64, 64, 64, 64, 64, 64, 64, 64], [32, 16], [1], []])
-def test_requeue_rounds_equal_single_walk(built, schedule):
-    """MODE 5 (rays stop when their wave runs thin, are queued and resumed in dense waves by the next round) gives the
-    results AND the work counters of the uninterrupted MODE 3 walk, whatever the schedule — [64]*8 stops every mesh walk
-    after two steps in each of eight rounds, [] never stops."""
-    for world, depth in ((scenes.cornell_sphere(160, 90, 40), 6), (scenes.living_room(96, 64, 16), 5)):
-        flat, cam = flatten(world), camera_struct(world.camera)
-        cfg = RenderConfig(LightSampling(1, 1), Tracing(depth, 4)).struct()
-        out = []
-        for mode in (3, 5):
-            c = Context(0)
-            c.set_traversal_mode(mode), c.set_lds_scene(0), c.set_ray_sort(0)
-            if mode == 5:
-                c.set_requeue_schedule(schedule)
-            c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
-            counters = [c.render_counted(1), c.render_counted(2)]
-            c.render(4), c.render(4)   # graph capture + replay
-            out.append((c.read_accum(), c.read_depth(), c.read_state(), counters))
-        assert out[0][3] == out[1][3]
-        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
-        for k in out[0][2]:
-            assert np.array_equal(out[0][2][k], out[1][2][k]), k
 
 
 def test_graph_replay_equals_eager_launches(built):
@@ -276,7 +255,7 @@ def test_shared_reciprocal_division_is_exact(built):
 
 
 @pytest.mark.parametrize("name", ["cornell_128", "living_room_96x64", "sphere_160x90", "textured_80x48"])
-@pytest.mark.parametrize("mode", [6, 5, 4, 3, 2, 1, 0])
+@pytest.mark.parametrize("mode", [3, 2, 1])
 def test_gpu_matches_committed_golden(built, name, mode):
     """Same comparison without the oracle in the loop: committed fixtures (tests/golden)."""
     from test_golden_oracle import load_golden
@@ -293,8 +272,10 @@ def test_gpu_matches_committed_golden(built, name, mode):
     acc = ctx.read_accum()
     lights = len(flat.spot_lights) + len(flat.direct_lights) > 0
     frac = 0.02 if lights else FRACTION
-    assert (acc[..., 3] == g["accum"][..., 3]).mean() >= 1 - frac
-    assert _close(acc[..., :3], g["accum"][..., :3]).all(-1).mean() >= 1 - frac
+    alpha_eq, rgb_ok = (acc[..., 3] == g["accum"][..., 3]).mean(), _close(acc[..., :3], g["accum"][..., :3]).all(-1).mean()
+    print(f"golden {name} mode {mode}: alpha equal {alpha_eq:.5f}, rgb within 1e-3 {rgb_ok:.5f}")
+    assert alpha_eq >= (LIT_ALPHA if lights else 1 - FRACTION)
+    assert rgb_ok >= (LIT_RGB if lights else 1 - FRACTION)
     st = ctx.read_state()
     assert (st["depth"] == g["path_depth"]).mean() >= 1 - frac and (st["material"] == g["ray_material"]).mean() >= 1 - frac
     ctx.tonemap()
@@ -401,6 +382,12 @@ def test_scene_file_renders_like_the_model_it_was_written_from(built, tmp_path):
         c.render(5)
         out.append((c.read_accum(), c.read_depth()))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # ... and the oracle on the snapshot the C++ loader produced
+    ref = oracle.OracleRenderer(loaded.flat, loaded.camera, cfg)
+    ref.render(5)
+    assert np.array_equal(out[1][1], ref.depth)
+    assert (out[1][0][..., 3] == ref.accum[..., 3]).mean() >= LIT_ALPHA
+    assert _close(out[1][0][..., :3], ref.accum[..., :3]).all(-1).mean() >= LIT_RGB
 
 
 def test_textured_scene_files_render_like_the_model(built, tmp_path):
@@ -423,6 +410,13 @@ def test_textured_scene_files_render_like_the_model(built, tmp_path):
         out.append((c.read_accum(), c.read_depth(), counters))
     assert out[0][2] == out[1][2] and out[0][2]["texel_fetches"] > 0
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    # ... and the oracle on the snapshot the C++ loader produced (maps decoded by the host library's PNG reader)
+    ref = oracle.OracleRenderer(loaded.flat, loaded.camera, cfg)
+    assert ref.render(1, counted=True) == out[1][2]
+    ref.render(5)
+    assert np.array_equal(out[1][1], ref.depth)
+    assert (out[1][0][..., 3] == ref.accum[..., 3]).mean() >= 1 - FRACTION
+    assert _close(out[1][0][..., :3], ref.accum[..., :3]).all(-1).mean() >= 1 - FRACTION
 
 
 def test_headless_runner_end_to_end(built, tmp_path):
@@ -502,40 +496,6 @@ def test_front_to_back_walk_equals_reference_order(built):
                 assert np.array_equal(out[0][2][k], out[other][2][k]), k
 
 
-def test_cooperative_triangle_phase_equals_the_per_lane_walk(built, monkeypatch):
-    """rz_trace_coop_kernel (all 64 lanes share the triangle tests of the lanes that hold a leaf: prefix sum, ds_bpermute ray fetch,
-    64-bit LDS atomic min on (t, triangle)) == rz_trace_skip_kernel walking front to back: frames, path state AND the executed work
-    counters, bit for bit — it tests the same boxes and triangles, only on other lanes."""
-    cases = ((scenes.cornell_sphere(160, 96, resolution=40), (1, 1)),
-             (scenes.textured_sphere_scene(200, 120, resolution=160, map_size=64), (1, 1)),
-             (scenes.living_room(128, 80, 16), (2, 2)))
-    for world, samples in cases:
-        flat, cam = flatten(world), camera_struct(world.camera)
-        cfg = RenderConfig(LightSampling(*samples), Tracing(6, 4)).struct()
-        out = []
-        for coop, coop_shadow in (("0", "0"), ("1", "0"), ("1", "1")):
-            monkeypatch.setenv("HIPRZ_COOP", coop)
-            monkeypatch.setenv("HIPRZ_COOP_SHADOW", coop_shadow)
-            c = Context(0)
-            c.set_traversal_mode(3), c.set_lds_scene(0), c.set_walk_order(2)
-            c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
-            counters = c.render_counted(2)
-            c.render(6), c.render(4)
-            out.append((c.read_accum(), c.read_depth(), c.read_state(), counters))
-        assert out[0][3] == out[1][3]
-        # the cooperative shadow kernel (rz_shadow_coop_kernel) tests the rest of a leaf that the per-lane walk leaves at its first hit:
-        # same shadow rays, same boxes, same answers, a few more triangle tests
-        for k in out[0][3]:
-            if k in ("tri_tests", "shadow_tri_tests"):
-                assert out[2][3][k] >= out[0][3][k]
-            else:
-                assert out[2][3][k] == out[0][3][k], k
-        for other in (1, 2):
-            assert np.array_equal(out[0][0], out[other][0]) and np.array_equal(out[0][1], out[other][1])
-            for k in out[0][2]:
-                assert np.array_equal(out[0][2][k], out[other][2][k]), k
-
-
 def test_scene_specialised_shading_equals_the_general_code(built, monkeypatch):
     """Scenes without lights (and without maps) run instantiations whose next-event estimation (texture fetches, normal mapping) is
     compiled out — RZ_SHADOW_NONE / RZ_SHADOW_PLAIN.  Frames, path state and counters equal the general instantiation's bit for bit,
@@ -567,8 +527,8 @@ def test_scene_specialised_shading_equals_the_general_code(built, monkeypatch):
 def test_exact_ties_pick_the_triangle_the_reference_meets_first(built, monkeypatch):
     """A mesh whose every triangle exists twice (the copy with ANOTHER material, shuffled in among the originals) and an instance that
     exists twice in the same place: every hit is an exact tie, inside a leaf, across leaves and across instances.  The reference keeps
-    the triangle it meets first (`t >= far` rejects the later one), so the material a pixel sees tells which one won.  Front to back,
-    cooperative and per-lane walks must agree with the reference-order walk — and all of them with the CPU oracle — on every pixel."""
+    the triangle it meets first (`t >= far` rejects the later one), so the material a pixel sees tells which one won.  The front-to-back
+    cooperative walk must agree with the reference-order walk — and all of them with the CPU oracle — on every pixel."""
     from rayzath_amd.scene import Instance, Material, Mesh, generate_sphere
     rng = np.random.default_rng(11)
     base = generate_sphere(20, normals=False, texture_coordinates=False)
@@ -587,8 +547,7 @@ def test_exact_ties_pick_the_triangle_the_reference_meets_first(built, monkeypat
     ref = oracle.OracleRenderer(flat, cam, cfg)
     ref.render(6)
     out = []
-    for order_, coop in ((0, "1"), (1, "0"), (1, "1")):
-        monkeypatch.setenv("HIPRZ_COOP", coop)
+    for order_ in (0, 1, 2):
         c = Context(0)
         c.set_traversal_mode(3), c.set_lds_scene(0), c.set_walk_order(order_)
         c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
