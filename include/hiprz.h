@@ -306,6 +306,9 @@ int hiprz_set_ray_sort(hiprz_ctx* ctx, int mode);
 int hiprz_set_xcd_swizzle(hiprz_ctx* ctx, int enabled);
 /* Replay the cumulative passes of a render call from a captured hipGraph (default on). */
 int hiprz_set_graph(hiprz_ctx* ctx, int enabled);
+/* How many times this context captured and instantiated a graph so far: steady-state frames with unchanged settings replay
+ * the existing one (setters invalidate it only when a value really changes). */
+int hiprz_graph_captures(hiprz_ctx* ctx, uint32_t* out);
 
 /* --- rendering (replaces Renderer::renderFunction, cuda_engine_renderer.cu:73-262) --- */
 /* Restart accumulation: the next hiprz_render starts with renderFirstPass

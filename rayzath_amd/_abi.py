@@ -117,6 +117,7 @@ ENTRY_POINTS = {
     "hiprz_set_ray_sort": (C.c_int, [P, C.c_int]),
     "hiprz_set_xcd_swizzle": (C.c_int, [P, C.c_int]),
     "hiprz_set_graph": (C.c_int, [P, C.c_int]),
+    "hiprz_graph_captures": (C.c_int, [P, C.POINTER(U32)]),
     "hiprz_reset": (C.c_int, [P]),
     "hiprz_render": (C.c_int, [P, U32]),
     "hiprz_render_counted": (C.c_int, [P, U32, C.POINTER(Counters)]),

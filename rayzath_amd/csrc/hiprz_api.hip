@@ -481,6 +481,7 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
             if (ie != hipSuccess) return fail(c, HIPRZ_ERR_DEVICE, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
             c->graph_passes = n_passes;
             c->graph_valid = true;
+            c->graph_captures += 1;
         }
         RZ_HIP(c, hipGraphLaunch(c->graph_exec, c->stream));
         c->passes += n_passes;
@@ -1071,6 +1072,12 @@ int hiprz_set_xcd_swizzle(hiprz_ctx* c, int enabled) {
 int hiprz_set_graph(hiprz_ctx* c, int enabled) {
     if (!c) return HIPRZ_ERR_INVALID;
     c->use_graph = enabled != 0;
+    return HIPRZ_OK;
+}
+
+int hiprz_graph_captures(hiprz_ctx* c, uint32_t* out) {
+    if (!c || !out) return HIPRZ_ERR_INVALID;
+    *out = c->graph_captures;
     return HIPRZ_OK;
 }
 

@@ -140,6 +140,7 @@ struct hiprz_ctx {
     hipGraphExec_t graph_exec = nullptr;
     uint32_t graph_passes = 0;
     bool graph_valid = false;
+    uint32_t graph_captures = 0;  // how often a batch was captured + instantiated (hiprz_graph_captures)
     // ray reordering between passes (split pipeline): keys from the shade kernel -> radix sort -> permutation
     hiprz::DeviceArray<uint32_t> sort_keys, sort_keys_out, sort_iota, sort_perm;
     hiprz::DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)

@@ -91,6 +91,11 @@ class Context:
         self._check(self.lib.hiprz_pipeline(self._ctx, C.byref(v)))
         return v.value
 
+    def graph_captures(self):
+        v = C.c_uint32()
+        self._check(self.lib.hiprz_graph_captures(self._ctx, C.byref(v)))
+        return v.value
+
     def traversal_mode(self):
         v = C.c_int()
         self._check(self.lib.hiprz_traversal_mode(self._ctx, C.byref(v)))

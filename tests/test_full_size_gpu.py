@@ -17,7 +17,7 @@ import pytest
 import oracle
 from rayzath_amd import scenes
 from rayzath_amd.distributed import tile_pixel_coords
-from rayzath_amd.engine import Context, RenderConfig, Tracing
+from rayzath_amd.engine import Context, LightSampling, RenderConfig, Tracing
 from rayzath_amd.scene import camera_struct, flatten
 
 pytestmark = pytest.mark.gpu
@@ -82,6 +82,33 @@ def test_full_size_frame_against_the_oracle(built, name, rgb_close, alpha_equal)
     elif name == "C":
         assert exact >= 0.9999
     assert ctx.ray_count() == 4 * cam.width * cam.height == ref.traced_rays
+
+
+def test_config_e_with_several_samples_per_light_type(built):
+    """Config E at its full 3840x2160 with LightSampling(spot 3, direct 2): five sample slots per segment through the deferred
+    shadow kernel and its sorted order, against the oracle (two passes: the first counted)."""
+    flat, cam, depth = scene("E")
+    cfg = RenderConfig(LightSampling(3, 2), Tracing(depth, 2)).struct()
+    ctx = Context(0)
+    ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(cfg)
+    first = ctx.render_counted(1)
+    ctx.render(1)
+    ref = oracle.OracleRenderer(flat, cam, cfg)
+    ref_first = ref.render(1, counted=True)
+    ref.render(1)
+    assert np.array_equal(ctx.read_depth(), ref.depth)
+    for k in ("segments", "hits", "light_samples", "texel_fetches", "finished"):
+        assert first[k] == ref_first[k], k
+    assert first["light_samples"] == 5 * first["hits"]
+    for total, shadow in (("box_tests", "shadow_box_tests"), ("tri_tests", "shadow_tri_tests")):
+        assert first[total] - first[shadow] == ref_first[total] - ref_first[shadow], total
+    for k in ("shadow_rays", "shadow_box_tests", "shadow_tri_tests"):
+        assert abs(first[k] - ref_first[k]) <= 1e-5 * max(ref_first[k], 1), k
+    acc, racc = ctx.read_accum(), ref.accum
+    close = (np.abs(acc[..., :3] - racc[..., :3]) <= 1e-3 * np.maximum(np.abs(racc[..., :3]), 1.0)).all(-1).mean()
+    same_alpha = (acc[..., 3] == racc[..., 3]).mean()
+    print(f"config E, samples (3, 2): rgb within 1e-3 {close:.6f}, alpha equal {same_alpha:.6f}")
+    assert close >= 0.997 and same_alpha >= 0.9997
 
 
 @pytest.mark.parametrize("name", ["B", "D"])

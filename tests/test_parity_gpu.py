@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 REL, FRACTION = 1e-3, 0.01
 # scenes with lights (next-event estimation behind expf / cosf / acosf: a sample at the `radiance < 1e-4` threshold or a shadow ray
 # grazing an edge differs): measured on MI355X minus 0.2 points, see the printed reports
-LIT_ALPHA, LIT_RGB = 0.98, 0.97
+LIT_ALPHA, LIT_RGB = 0.997, 0.993
 
 
 def _run_both(world, max_depth, passes, mode=-1, spot=1, direct=1, seed=20240501):
@@ -563,3 +563,33 @@ def test_exact_ties_pick_the_triangle_the_reference_meets_first(built, monkeypat
     # both copies win somewhere (the shuffle decides which comes first in a leaf): red-diffuse and blue-glossy pixels are in the picture
     rgb = ref.accum[..., :3]
     assert (rgb[..., 0] > 3 * rgb[..., 2]).sum() > 30 and (rgb[..., 2] > 1.5 * rgb[..., 0]).sum() > 30
+
+
+def test_engine_frames_replay_the_captured_graph(built):
+    """Engine.renderWorld calls hiprz_set_config before every frame; with an unchanged config the second steady-state frame must
+    replay the graph the first one captured (split pipeline) — and a changed config must re-capture."""
+    from rayzath_amd.engine import Engine
+    world = scenes.cornell_sphere(160, 96, resolution=24)     # not staged in LDS by default? force the split pipeline below
+    eng = Engine(0)
+    eng.context.set_pipeline(1)
+    cfg = RenderConfig(LightSampling(1, 1), Tracing(6, 4))
+    eng.renderWorld(world, cfg)                   # first pass + 3 cumulative: eager
+    assert eng.context.graph_captures() == 0
+    eng.renderWorld(world, cfg)
+    assert eng.context.graph_captures() == 1
+    for _ in range(3):
+        eng.renderWorld(world, cfg)
+    assert eng.context.graph_captures() == 1      # replayed, not re-captured
+    eng.renderWorld(world, RenderConfig(LightSampling(1, 1), Tracing(5, 4)))
+    assert eng.context.graph_captures() == 2      # max depth changed: kernel arguments differ
+    # the frames themselves: the same passes through a fresh context, eagerly
+    flat, cam = flatten(world), camera_struct(world.camera)
+    ref = Context(0)
+    ref.set_pipeline(1), ref.set_graph(False)
+    ref.upload_scene(flat), ref.upload_camera(cam)
+    ref.set_config(cfg.struct())
+    for _ in range(5):
+        ref.render(4)
+    ref.set_config(RenderConfig(LightSampling(1, 1), Tracing(5, 4)).struct())
+    ref.render(4)
+    assert np.array_equal(eng.context.read_accum(), ref.read_accum())

@@ -54,9 +54,10 @@ def test_shading_inputs_against_the_oracle(built, packaging, lights, samples):
         assert abs(first["shadow_rays"] - ref_first["shadow_rays"]) <= 2
     else:
         assert first["shadow_rays"] == 0 == first["light_samples"]
-    # first pass: the accumulator holds the emission met by the primary ray (emission maps, sky) — no sampling routine involved
+    # first pass: without lights the accumulator holds the emission met by the primary ray (emission maps, sky) and nothing else
+    # — no sampling routine involved; with lights the first hit's next-event estimation (expf, cosf, acosf) adds ulps
     acc, racc = ctx.read_accum(), ref.accum
-    primary_exact = (acc == racc).all(-1).mean()
+    primary_exact = (acc == racc).all(-1).mean() if not lights else _close(acc[..., :3], racc[..., :3]).mean()
     assert np.array_equal(acc[..., 3], racc[..., 3])
 
     ctx.render(7), ref.render(7)
@@ -77,7 +78,9 @@ def test_shading_inputs_against_the_oracle(built, packaging, lights, samples):
 
 
 # measured on MI355X (round 2) minus 0.2 points; see the printed reports
-THRESHOLDS = dict(primary_exact=0.99, alpha_equal=0.99, rgb_close_lit=0.97, rgb_close_dark=0.98, rgba8=0.98)
+# round 2, every packaging: alpha / material / depth equal 1.0, radiance within 1e-3 on 1.0 of the pixels (0.94 bit-exact with
+# lights, 1.0 bit-exact without), first pass 1.0
+THRESHOLDS = dict(primary_exact=0.998, alpha_equal=0.998, rgb_close_lit=0.998, rgb_close_dark=0.998, rgba8=0.998)
 
 
 def test_all_packagings_give_the_same_frame(built):
