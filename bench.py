@@ -66,8 +66,9 @@ def cpu_baseline(flat, cam, cfg, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=40, help="steps per timed repeat (each step = 8 passes: >= 64 passes per repeat from 8 steps on)")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are repeated this many times; the line reports the median repeat")
     ap.add_argument("--config", default="B", help="scene preset of rayzath_amd/scenes.py (B = the quoted config)")
     ap.add_argument("--traversal", type=int, default=-1, help="-1 per-scene choice (default), 1 nested walk with LDS stack, 2 workgroup-binned, 3 skip links (front to back, cooperative triangle phase)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather on the render stream instead of overlapping it with the next step's rendering")
@@ -159,47 +160,79 @@ def main():
         step()
     fence()
     ctx.kernel_time_ms()  # drop the warm-up launches from the event log
-    alpha_before = None
-    if rank == 0 and world == 1:
-        alpha_before = float(ctx.read_accum()[..., 3].sum())
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i == args.steps - 1:
-            ctx.time_kernels(True)  # the last timed step also records per-kernel events (eager launches instead of the graph)
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
 
-    kernel_ms, launches = ctx.kernel_time_ms()
-    breakdown = ctx.kernel_breakdown_ms()  # trace / shade kernel times of the last timed step
+    # ---- the timed region: EXACTLY `steps` steps between two fences, repeated `repeats` times; the line reports the median
+    # repeat ("median of 5").  Nothing but step() runs between the fences.
+    alpha_before = float(ctx.read_accum()[..., 3].sum()) if rank == 0 and world == 1 else None
+    passes_before = ctx.pass_count()
+    samples = []
+    t_all0 = time.perf_counter()
+    for _ in range(max(args.repeats, 1)):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        samples.append(float(t.item()))
+    timed_wall = time.perf_counter() - t_all0
+    elapsed = sorted(samples)[len(samples) // 2]
+    kernel_ms, launches = ctx.kernel_time_ms()   # hip events around every render batch of the timed repeats
+    alpha_after = float(ctx.read_accum()[..., 3].sum()) if alpha_before is not None else None
+    passes_timed = ctx.pass_count() - passes_before
+
+    # ---- outside the timed region: per-kernel events (eager launches), host readback, work counters
+    ctx.time_kernels(True)
+    trace_ms = shade_ms = 0.0
+    timed_passes = 0
+    for _ in range(3):
+        ctx.render(RPP)
+        b = ctx.kernel_breakdown_ms()
+        trace_ms, shade_ms, timed_passes = trace_ms + b[0], shade_ms + b[1], timed_passes + b[2]
     ctx.time_kernels(False)
+    breakdown = (trace_ms, shade_ms, timed_passes)
+    ctx.kernel_time_ms()
+    end_to_end = None
+    if world == 1:  # what the reference's renderWorld hands back per call: the tone-mapped frame in host memory
+        ctx.render(RPP), ctx.tonemap(), ctx.read_rgba8()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.render(RPP)
+            ctx.tonemap()
+            ctx.read_rgba8()
+        fence()
+        e2e = time.perf_counter() - t0
+        end_to_end = {"value": args.steps * RPP * W * H / e2e / 1e6, "unit": "Mrays/s", "ms_per_step": e2e / args.steps * 1e3,
+                      "includes": "render + tone map + hiprz_read_rgba8 into host memory (8.3 MB per step over PCIe, synchronous)"}
+        ctx.kernel_time_ms()
     rays = args.steps * RPP * W * H
     result = None
     if rank == 0:
         spp_per_s = None
-        if alpha_before is not None:
-            spp_per_s = (float(ctx.read_accum()[..., 3].sum()) - alpha_before) / (W * H) / elapsed
-        # work counters of the same kernels, same state, outside the timed region
+        if alpha_before is not None:   # finished paths per pixel per second over ALL the timed repeats
+            spp_per_s = (alpha_after - alpha_before) / (W * H) / sum(samples)
+        # work counters of the same kernels, same state
         counters = ctx.render_counted(RPP)
         ctx.kernel_time_ms()
         bytes_per_pass = algorithmic_bytes(counters) / RPP
         avg_pass_s = kernel_ms / 1e3 / max(launches, 1)
         pipeline = ctx.pipeline()
         split = pipeline == 1
-        traversal_kernel = None
+        walk_order = args.walk_order if args.walk_order >= 0 else 1
+        front_to_back = split and ctx.traversal_mode() == 3 and walk_order != 0
+        trace_bytes = lambda c: (60 * c["segments"] + 32 * (c["box_tests"] - c["shadow_box_tests"]) + 36 * (c["tri_tests"] - c["shadow_tri_tests"])) / RPP
+        traversal_kernel = reference_algorithm = None
         if pipeline == 2 and breakdown[2]:
             # dominant (only) kernel: the resident batch kernel — one launch takes every tile through the RPP passes of the
-            # step.  Algorithmic bytes: SURVEY.md §8d's per-segment figure x the segments of the launch.
+            # step.  Algorithmic bytes: SURVEY.md §8d's per-segment figure x the segments of the launch.  It walks in the
+            # reference's order: executed work == the reference algorithm's work.
             kernel_name = "rz_batch_kernel (resident: all passes of a step)"
-            kernel_s = breakdown[0] / 1e3
+            kernel_s = breakdown[0] / 1e3 / (breakdown[2] / RPP)
             kernel_bytes = algorithmic_bytes(counters)
-            # the BVH-traversal kernel on its own (north_star's 30 % target): the same step through the split pipeline,
-            # outside the timed region
+            # the BVH-traversal kernel on its own (north_star's 30 % target): the same step through the split pipeline
             ctx.set_pipeline(1)
             ctx.render(RPP)
             ctx.time_kernels(True)
@@ -208,8 +241,7 @@ def main():
             ctx.time_kernels(False)
             ctx.set_pipeline(args.pipeline)
             if tb[2]:
-                t_bytes = (60 * counters["segments"] + 32 * (counters["box_tests"] - counters["shadow_box_tests"])
-                           + 36 * (counters["tri_tests"] - counters["shadow_tri_tests"])) / RPP
+                t_bytes = trace_bytes(counters)
                 t_s = tb[0] / 1e3 / tb[2]
                 traversal_kernel = {"kernel": "rz_trace_kernel (closest-hit walk, split pipeline)", "avg_launch_us": t_s * 1e6,
                                     "algorithmic_bytes_per_launch": t_bytes, "achieved": t_bytes / t_s / 1e9,
@@ -217,27 +249,29 @@ def main():
         elif split and breakdown[2]:
             # dominant kernel = the BVH-traversal kernel.  Its algorithmic bytes: the ray it reads (40 B of path state) and
             # the hit record it writes (20 B) per segment + 32 B per box test + 36 B per triangle test of the closest-hit
-            # walk (shadow-ray tests run in the shade kernel and are not counted here).
-            mode3 = "rz_trace_coop_kernel" if (args.walk_order if args.walk_order >= 0 else 1) != 0 else "rz_trace_skip_kernel"
+            # walk (shadow-ray tests run in their own kernel and are not counted here).
+            mode3 = "rz_trace_coop_kernel" if front_to_back else "rz_trace_skip_kernel"
             kernel_name = {3: mode3}.get(ctx.traversal_mode(), "rz_trace_kernel") + " (closest-hit walk)"
             kernel_s = breakdown[0] / 1e3 / breakdown[2]
-            kernel_bytes = (60 * counters["segments"] + 32 * (counters["box_tests"] - counters["shadow_box_tests"])
-                            + 36 * (counters["tri_tests"] - counters["shadow_tri_tests"])) / RPP
+            kernel_bytes = trace_bytes(counters)
+            if front_to_back:
+                # `counters` walked in the reference's child order (they equal the CPU kernel's).  The timed kernel walks front to
+                # back and reaches the same hits with fewer tests: the roofline is priced on the tests it EXECUTED; the reference
+                # algorithm's figure is kept beside it as context.
+                ctx.set_walk_order(2)
+                ex = ctx.render_counted(RPP)
+                ctx.set_walk_order(walk_order)
+                ctx.kernel_time_ms()
+                ref_bytes = kernel_bytes
+                kernel_bytes = trace_bytes(ex)
+                reference_algorithm = {"note": "work of the reference's first-child-then-second walk on the same rays, divided by the timed kernel's duration",
+                                       "box_tests_per_segment": counters["box_tests"] / max(counters["segments"], 1),
+                                       "tri_tests_per_segment": counters["tri_tests"] / max(counters["segments"], 1),
+                                       "kernel_bytes_per_launch": ref_bytes, "achieved": ref_bytes / kernel_s / 1e9, "frac": ref_bytes / kernel_s / 1e9 / PEAK_HBM_GBS}
+                counters = ex
         else:
             kernel_name, kernel_s, kernel_bytes = "rz_pass_kernel (fused pass)", avg_pass_s, bytes_per_pass
         achieved = kernel_bytes / kernel_s / 1e9
-        # The algorithmic bytes above are the work of the REFERENCE's algorithm (counted renders walk in its child order).  The
-        # front-to-back mesh walk finds the same hits with fewer tests; what the timed kernels actually executed is reported beside it.
-        executed = None
-        walk_order = args.walk_order if args.walk_order >= 0 else 1
-        if split and ctx.traversal_mode() == 3 and walk_order != 0:
-            ctx.set_walk_order(2)
-            ex = ctx.render_counted(RPP)
-            ctx.set_walk_order(walk_order)
-            ctx.kernel_time_ms()
-            ex_bytes = (60 * ex["segments"] + 32 * (ex["box_tests"] - ex["shadow_box_tests"]) + 36 * (ex["tri_tests"] - ex["shadow_tri_tests"])) / RPP
-            executed = {"box_tests_per_segment": ex["box_tests"] / max(ex["segments"], 1), "tri_tests_per_segment": ex["tri_tests"] / max(ex["segments"], 1),
-                        "kernel_bytes_per_launch": ex_bytes, "achieved": ex_bytes / kernel_s / 1e9, "frac": ex_bytes / kernel_s / 1e9 / PEAK_HBM_GBS}
         traffic = None
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
         if os.path.exists(tpath) and world == 1:
@@ -252,19 +286,24 @@ def main():
                        "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
                        "traversal": {1: "lds-stack", 2: "workgroup-binned", 3: "skip-links"}[ctx.traversal_mode()],
                        "pipeline": {0: "fused (one kernel per pass)", 1: "trace+shade (two kernels per pass)", 2: "resident (one kernel per step)"}[pipeline]},
+            "timing": {"protocol": f"{len(samples)} repeats of exactly {args.steps} steps ({args.steps * RPP} passes) between barrier + synchronize fences; value = median repeat",
+                       "repeat_seconds": samples, "passes_timed": passes_timed, "timed_wall_seconds": timed_wall},
             "spp_per_s": spp_per_s,
+            "end_to_end": end_to_end,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": traffic, "kernel": kernel_name, "avg_launch_us": kernel_s * 1e6,
                          "algorithmic_bytes_per_launch": kernel_bytes,
+                         "priced_on": "tests executed by the timed kernel" + (" (front-to-back walk)" if front_to_back else " (= the reference algorithm's: same visiting order)"),
                          "segments_per_launch": counters["segments"] / (1 if pipeline == 2 else RPP),
                          "traversal_kernel": traversal_kernel,
                          "shade_kernel_avg_launch_us": breakdown[1] / breakdown[2] * 1e3 if split and breakdown[2] else None,
                          "whole_pass": {"avg_us": avg_pass_s * 1e6, "algorithmic_bytes": bytes_per_pass,
-                                        "achieved": bytes_per_pass / avg_pass_s / 1e9, "frac": bytes_per_pass / avg_pass_s / 1e9 / PEAK_HBM_GBS},
+                                        "achieved": bytes_per_pass / avg_pass_s / 1e9, "frac": bytes_per_pass / avg_pass_s / 1e9 / PEAK_HBM_GBS,
+                                        "note": "all kernels of a pass; bytes of the reference algorithm (closest-hit + shadow rays + shading)"},
                          "box_tests_per_segment": counters["box_tests"] / max(counters["segments"], 1),
                          "tri_tests_per_segment": counters["tri_tests"] / max(counters["segments"], 1),
                          "mesh_walk_order": None if not (split and ctx.traversal_mode() == 3) else ("front to back" if walk_order else "reference child order"),
-                         "executed": executed},
+                         "reference_algorithm": reference_algorithm},
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(flat, cam, cfg)

@@ -936,6 +936,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     c->n_textures = sc->n_textures;
     // mesh walk rounds of at most 4 node steps and 8 triangles per lane (measured: D 3 163 -> 2 891 us, C 935 -> 892 us)
     d.walk_k = 4u, d.walk_l = 8u;
+    d.walk_h = 65u;  // never: ending the node phase early for a full triangle step measured no gain (D 1 010 vs 999 us)
     // ray reordering key: without lights only the closest-hit walk follows the sorted order and the interleaved origin/direction
     // code groups best (config C: trace kernel 583 -> 503 us); with lights the deferred shadow rays follow it too and they fan out
     // from the origin cell, so the origin leads (config E: 86.5 ms per step against 92.6)
@@ -945,6 +946,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     if (const char* v = std::getenv("HIPRZ_SORT_KEY")) d.sort_variant = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_K")) d.walk_k = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_L")) d.walk_l = uint32_t(std::atoi(v));
+    if (const char* v = std::getenv("HIPRZ_WALK_H")) d.walk_h = uint32_t(std::atoi(v));
     d.n_spot_lights = sc->n_spot_lights;
     d.n_direct_lights = sc->n_direct_lights;
     // Stage the blob in LDS when three workgroups per CU (the kernel's register-limited residency)
@@ -1297,31 +1299,6 @@ int hiprz_selftest(hiprz_ctx* c, uint32_t cases_per_thread, uint32_t seed, uint6
     *mismatches = v[0], *tested = v[1];
     return HIPRZ_OK;
 }
-
-#ifdef RZ_BOXPATH_STATS
-int hiprz_read_boxpath(unsigned long long out[4]) {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(hiprz::rz_boxpath), 32);
-    unsigned long long zero[4] = {0};
-    hipMemcpyToSymbol(HIP_SYMBOL(hiprz::rz_boxpath), zero, 32);
-    return 0;
-}
-#endif
-#ifdef RZ_PHASE_STATS
-extern "C" int hiprz_read_phase_stats(unsigned long long out[16]) {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(hiprz::rz_phase), 128);
-    unsigned long long zero[16] = {0};
-    hipMemcpyToSymbol(HIP_SYMBOL(hiprz::rz_phase), zero, 128);
-    return 0;
-}
-#endif
-#ifdef RZ_STAMP
-int hiprz_read_stamps(unsigned long long out[8]) {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(hiprz::rz_stamp_sums), 64);
-    unsigned long long zero[8] = {0};
-    hipMemcpyToSymbol(HIP_SYMBOL(hiprz::rz_stamp_sums), zero, 64);
-    return 0;
-}
-#endif
 
 int hiprz_timings(hiprz_ctx* c, char* buf, size_t len) {
     if (!c || !buf || len == 0) return HIPRZ_ERR_INVALID;

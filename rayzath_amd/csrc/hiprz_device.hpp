@@ -95,6 +95,7 @@ struct DScene {
     uint32_t top_count;            // MODE 3: the first top_count nodes (+ their links) are staged in LDS by every workgroup
     const uint32_t* node_skip;     // link to the node that follows a node's subtree (same numbering as `nodes`)
     uint32_t walk_k, walk_l;       // MODE 3 mesh walk: node steps / triangle tests per lane per round (0 = unbounded)
+    uint32_t walk_h;               // cooperative walks: the node phase of a round ends as soon as this many lanes hold a leaf
     // front-to-back mesh walk (hiprz_set_walk_order): 64-B records = node (32 B) + its skip link under each of the 8
     // ray-direction octants
     const float4* nodes64;
@@ -374,7 +375,7 @@ RZ_DEV bool zero_or_exponent_in(float x, int lo, int hi) {
     return (__float_as_uint(x) & 0x7FFFFFFFu) == 0u || exponent_in(x, lo, hi);
 }
 #ifdef RZ_PHASE_STATS  // diagnostic build: wave-level executions and active lanes of the MODE 3 walk's steps (tools/phase_stats.py)
-__device__ unsigned long long rz_phase[16];
+static __device__ unsigned long long rz_phase[16];  // one copy per translation unit: read through that unit's hiprz_read_phase_stats
 #define RZ_PHASE(k)                                                                                        \
     do {                                                                                                   \
         const unsigned long long rz_a = __ballot(1);                                                       \
@@ -955,49 +956,123 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
 // After front to back the thin phase of the walk is the triangle test: a lane that holds a leaf tests its (up to 8) triangles one
 // after the other while the lanes without a leaf wait — config D: 133 wave-level triangle steps per wave at 7.9 active lanes.
 // Here every loop of the walk is wave-uniform (conditions are ballots, lanes carry predicates), so ALL 64 lanes reach the triangle
-// phase, and the (ray, triangle) pairs of the lanes that hold leaves are dealt out over the whole wave:
-//   counts -> wave prefix sum -> the holders write their lane id into the item list (LDS, one byte per item) -> every lane takes
-//   one item, fetches its holder's mesh-space ray with ds_bpermute (no memory), tests the triangle, and the closest hit of a holder
-//   is found with a 64-bit LDS atomic min on (bits(t) << 32 | triangle index) — t > near >= 0, so its bit pattern orders like the
-//   number, and the index in the low word is the reference's "first found wins" — the winning lane leaves the barycentrics in LDS.
-// A leaf's triangles tested against the range the lane held when it reached the leaf, then reduced by (t, index), give what testing
-// them one by one in index order gives (each accepted t is strictly smaller, or equal with a lower index than a hit of another
-// leaf): same boxes, same triangles, same hits as a per-lane front-to-back walk with tri_hit_ordered.  The caller brings all 64 lanes (`active` = has a
-// ray).  LDS per wave: CoopLds::kBytes.
+// phase, and the (ray, triangle) pairs of the lanes that hold leaves are dealt out over the whole wave in groups of 8 lanes:
+//   a holder's (up to 8) triangles form one or two ENTRIES of at most 4; entry positions come from two ballots + mbcnt (no scan), and
+//   the holder writes a 48-byte record per entry — mesh-space ray, range, first triangle, count — to LDS; the four lanes of quad e of
+//   a step read record e (three ds_read_b128, broadcast within the quad) and test triangle j = lane & 3 of that entry; the quad's
+//   closest hit is a 2-step DPP minimum over bits(t) (t > near >= 0, so the bit pattern orders like the number), the lowest lane
+//   holding the minimum — the lowest triangle index, i.e. the reference's "first found wins" — writes (t, triangle, barycentrics,
+//   side) to the entry's result slot, and the holder takes the better of its entries.  No atomics, one hand-over each way.
+// The node phase of a round ends after walk_k steps, or as soon as walk_h lanes hold a leaf (a full step of 64 slots).  A leaf's triangles tested against the range the lane held when it reached the leaf, then reduced by
+// (t, index), give what testing them one by one in index order gives (each accepted t is strictly smaller, or equal with a lower
+// index than a hit of another leaf): the same hits as a per-lane front-to-back walk with tri_hit_ordered.  The caller brings all
+// 64 lanes (`active` = has a ray).  LDS per wave: CoopLds::kBytes.
 #define RZ_LDS __attribute__((address_space(3)))
-struct CoopLds {  // LDS-qualified pointers: ds_read / ds_write / ds_min_u64, not flat accesses
-    RZ_LDS unsigned char* owner;       // [512] item -> holder lane
-    RZ_LDS unsigned long long* key;    // [64]  per holder: min over its items of bits(t) << 32 | triangle
-    RZ_LDS float* res;                 // [3][64] winner's b1, b2, external
-    static constexpr uint32_t kItems = 512u, kBytes = 512u + 512u + 768u;
-    RZ_DEV explicit CoopLds(unsigned char* base)
-        : owner((RZ_LDS unsigned char*)base), key((RZ_LDS unsigned long long*)(base + 512)), res((RZ_LDS float*)(base + 1024)) {}
+typedef float f4 __attribute__((ext_vector_type(4)));  // a native vector: loads / stores through address-space-qualified pointers
+RZ_DEV f4 F4(float x, float y, float z, float w) { return f4{x, y, z, w}; }
+struct CoopLds {  // LDS-qualified pointers: ds_read / ds_write, not flat accesses
+    RZ_LDS f4* rec;       // [3][128] by entry: (o.xyz, near), (d.xyz, far), bits(first triangle, count <= 4, held triangle + 1 or 0, -)
+    RZ_LDS f4* res;       // [128]    by entry: bits(t) or ~0 = no hit, bits(triangle | external << 31), b1, b2
+    static constexpr uint32_t kEntries = 128u, kBytes = 4u * kEntries * 16u;
+    RZ_DEV explicit CoopLds(unsigned char* base) : rec((RZ_LDS f4*)base), res((RZ_LDS f4*)(base + 3u * kEntries * 16u)) {}
 };
-RZ_DEV void lds_min_u64(RZ_LDS unsigned long long* p, unsigned long long v) { __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// Hand-over points of the cooperative phase.  One wave per workgroup, so the barrier costs little; the fence-only variant
-// (RZ_COOP_BARRIER 0, relying on the LDS unit executing a wave's instructions in issue order) measured the same (D 1 030 vs 1 037 us)
-// and is not used.
-#ifndef RZ_COOP_BARRIER
-#define RZ_COOP_BARRIER 1
-#endif
+// Hand-over points of the cooperative phase: the LDS unit executes a wave's instructions in issue order, so a fence that keeps the
+// compiler from moving LDS accesses across it is all one wave needs (the workgroup IS one wave).
 RZ_DEV void rz_wave_sync() {
-#if RZ_COOP_BARRIER
-    __syncthreads();
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#endif
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
-RZ_DEV float shfl_f(float v, uint32_t src) { return __shfl(v, int(src)); }
+RZ_DEV uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// number of set bits of `mask` below this lane
+RZ_DEV uint32_t rank_in(unsigned long long mask) { return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u)); }
+// minimum of an unsigned value over each quad (aligned group of 4 lanes), in every lane of the quad: two quad_perm exchanges
+RZ_DEV uint32_t quad_min(uint32_t v) {
+    uint32_t o = uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0xB1, 0xF, 0xF, false));  // quad_perm:[1,0,3,2]
+    v = o < v ? o : v;
+    o = uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x4E, 0xF, 0xF, false));           // quad_perm:[2,3,0,1]
+    return o < v ? o : v;
+}
+// How the triangles of the lanes that hold a leaf are dealt out: a holder of c <= 4 triangles fills ONE entry (a quad of lanes), a
+// holder of 5..8 two — positions come from two ballots (no scan): entries before mine = holders before me + two-entry holders before me.
+struct CoopDeal {
+    uint32_t n_entries, pos;
+    bool big;
+};
+RZ_DEV CoopDeal coop_deal(bool holding, uint32_t c) {
+    const unsigned long long hmask = __ballot(holding), bmask = __ballot(holding && c > 4u);
+    return CoopDeal{uint32_t(__popcll(hmask)) + uint32_t(__popcll(bmask)), rank_in(hmask) + rank_in(bmask), c > 4u};
+}
+// One cooperative triangle step for the closest-hit walk.  Every lane calls it; `holding` lanes own a leaf [tj, tj + c), c <= 8.
+template <bool COUNT>
+RZ_DEV void coop_closest_triangles(const DScene& s, const CoopLds& lds, bool holding, uint32_t c, v3 lr_o, v3 lr_d, float lr_near, uint32_t tj,
+                                   bool& found, Hit& hit, float& far_, Counters& cnt) {
+    const uint32_t lane = lane_id();
+    const CoopDeal deal = coop_deal(holding, c);
+    if (holding) {
+        const f4 r0 = F4(lr_o.x, lr_o.y, lr_o.z, lr_near), r1 = F4(lr_d.x, lr_d.y, lr_d.z, far_);
+        const uint32_t held = found ? hit.triangle + 1u : 0u;
+        lds.rec[deal.pos] = r0, lds.rec[CoopLds::kEntries + deal.pos] = r1;
+        lds.rec[2u * CoopLds::kEntries + deal.pos] = F4(__uint_as_float(tj), __uint_as_float(c < 4u ? c : 4u), __uint_as_float(held), 0.0f);
+        lds.res[deal.pos] = F4(__uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f, 0.0f);
+        if (deal.big) {
+            lds.rec[deal.pos + 1u] = r0, lds.rec[CoopLds::kEntries + deal.pos + 1u] = r1;
+            lds.rec[2u * CoopLds::kEntries + deal.pos + 1u] = F4(__uint_as_float(tj + 4u), __uint_as_float(c - 4u), __uint_as_float(held), 0.0f);
+            lds.res[deal.pos + 1u] = F4(__uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f, 0.0f);
+        }
+    }
+    rz_wave_sync();
+    for (uint32_t base = 0u; base < deal.n_entries * 4u; base += 64u) {  // wave-uniform
+        const uint32_t e = (base + lane) >> 2, j = lane & 3u;
+        uint32_t tbits = 0xFFFFFFFFu, tri = 0u;
+        float b1 = 0.0f, b2 = 0.0f, det = 0.0f;
+        if (e < deal.n_entries) {
+            const f4 r2 = lds.rec[2u * CoopLds::kEntries + e];
+            if (j < __float_as_uint(r2.y)) {
+                const f4 r0 = lds.rec[e], r1 = lds.rec[CoopLds::kEntries + e];
+                WalkRay hr;
+                hr.o = V3(r0.x, r0.y, r0.z), hr.d = V3(r1.x, r1.y, r1.z), hr.near_ = r0.w, hr.far_ = r1.w;
+                tri = __float_as_uint(r2.x) + j;
+                const float4 a = s.tris[3 * tri], b = s.tris[3 * tri + 1], cc = s.tris[3 * tri + 2];
+                float t;
+                RZ_PHASE(4);
+                RZ_COUNT(tri_tests);
+                // a hit at exactly the held distance replaces the held one when the reference would have met it first: lower index
+                if (tri_hit_ordered(xyz(a), xyz(b), xyz(cc), hr, tri + 1u < __float_as_uint(r2.z), t, b1, b2, det)) tbits = __float_as_uint(t);
+            }
+        }
+        const uint32_t tmin = quad_min(tbits);
+        const bool candidate = tbits != 0xFFFFFFFFu && tbits == tmin;
+        const unsigned long long winners = __ballot(candidate);
+        const uint32_t mine = uint32_t(winners >> (lane & 60u)) & 0xFu;   // the candidates of this lane's quad
+        if (candidate && (mine & ((1u << j) - 1u)) == 0u)                  // the lowest lane = the lowest triangle index
+            lds.res[e] = F4(__uint_as_float(tbits), __uint_as_float(tri | (det > 0.0f ? 0x80000000u : 0u)), b1, b2);
+    }
+    rz_wave_sync();
+    if (holding) {
+        f4 best = lds.res[deal.pos];
+        if (deal.big) {  // the second entry holds the higher triangle indices: it wins only with a strictly smaller t
+            const f4 other = lds.res[deal.pos + 1u];
+            if (__float_as_uint(other.x) < __float_as_uint(best.x)) best = other;
+        }
+        if (__float_as_uint(best.x) != 0xFFFFFFFFu) {
+            far_ = best.x;
+            hit.triangle = __float_as_uint(best.y) & 0x7FFFFFFFu;
+            hit.external = (__float_as_uint(best.y) & 0x80000000u) != 0u;
+            hit.bx = best.z, hit.by = best.w;
+            found = true;
+        }
+    }
+    rz_wave_sync();  // the next phase rewrites rec / res
+}
+
 template <bool COUNT, bool RCP>
 RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ray& ray, Hit& hit, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
-    const uint32_t lane = threadIdx.x & 63u;
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
     prepare<RCP>(g, scene_fast);
-    const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? (s.walk_l < 8u ? s.walk_l : 8u) : 8u;
+    const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? (s.walk_l < 8u ? s.walk_l : 8u) : 8u, hmin = s.walk_h;
     uint32_t n = active ? s.tlas_root : RZ_END, guard = 0u;
     bool root_missed = false;
     while (__any(n != RZ_END)) {
@@ -1045,8 +1120,9 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
             uint32_t tj = 0u, tj_end = 0u;  // the held leaf's remaining triangles
             while (__any(tj != tj_end || m != RZ_END)) {
                 RZ_PHASE(5);
-                // node phase: lanes without a leaf step (at most kmax steps per round), the others wait
+                // node phase: lanes without a leaf step, the others wait — until a full triangle step's worth of lanes hold a leaf
                 for (uint32_t k = 0u; k < kmax && __any(tj == tj_end && m != RZ_END); ++k) {
+                    if (k != 0u && uint32_t(__popcll(__ballot(tj != tj_end))) >= hmin) break;
                     if (tj == tj_end && m != RZ_END) {
                         RZ_GUARD(guard);
                         float4 m0, m1;
@@ -1065,53 +1141,8 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
                 if (!__any(tj != tj_end)) continue;
                 // triangle phase, all 64 lanes
                 const uint32_t c = tj_end - tj < lmax ? tj_end - tj : lmax;
-                uint32_t incl = c;
-                for (uint32_t d = 1u; d < 64u; d <<= 1) {
-                    const uint32_t v = __shfl_up(incl, d);
-                    if (lane >= d) incl += v;
-                }
-                const uint32_t off = incl - c, total = __shfl(incl, 63);
-                for (uint32_t j = 0u; j < c; ++j) lds.owner[off + j] = (unsigned char)lane;
-                lds.key[lane] = ~0ull;
-                rz_wave_sync();
-                for (uint32_t base = 0u; base < total; base += 64u) {
-                    const uint32_t item = base + lane;
-                    const bool valid = item < total;
-                    const uint32_t h = valid ? uint32_t(lds.owner[item]) : lane;
-                    WalkRay hr;
-                    hr.o = V3(shfl_f(lr.o.x, h), shfl_f(lr.o.y, h), shfl_f(lr.o.z, h));
-                    hr.d = V3(shfl_f(lr.d.x, h), shfl_f(lr.d.y, h), shfl_f(lr.d.z, h));
-                    hr.near_ = shfl_f(lr.near_, h), hr.far_ = shfl_f(lr.far_, h);
-                    const uint32_t htj = __shfl(tj, int(h)), hoff = __shfl(off, int(h)), hbest = __shfl(hit.triangle, int(h));
-                    const bool hfound = __shfl(int(found), int(h)) != 0;
-                    unsigned long long mykey = ~0ull;
-                    float b1 = 0.0f, b2 = 0.0f, det = 0.0f;
-                    if (valid) {
-                        const uint32_t tri = htj + (item - hoff);
-                        const float4 a = s.tris[3 * tri], b = s.tris[3 * tri + 1], cc = s.tris[3 * tri + 2];
-                        float t;
-                        RZ_PHASE(4);
-                        RZ_COUNT(tri_tests);
-                        if (tri_hit_ordered(xyz(a), xyz(b), xyz(cc), hr, hfound && tri < hbest, t, b1, b2, det)) {
-                            mykey = ((unsigned long long)__float_as_uint(t) << 32) | tri;
-                            lds_min_u64(&lds.key[h], mykey);
-                        }
-                    }
-                    rz_wave_sync();
-                    if (mykey != ~0ull && lds.key[h] == mykey) lds.res[h] = b1, lds.res[64 + h] = b2, lds.res[128 + h] = det > 0.0f ? 1.0f : 0.0f;
-                }
-                rz_wave_sync();
-                if (c != 0u) {
-                    const unsigned long long best = lds.key[lane];
-                    if (best != ~0ull) {
-                        lr.far_ = __uint_as_float(uint32_t(best >> 32));
-                        hit.triangle = uint32_t(best);
-                        hit.bx = lds.res[lane], hit.by = lds.res[64 + lane], hit.external = lds.res[128 + lane] != 0.0f;
-                        found = true;
-                    }
-                    tj += c;
-                }
-                rz_wave_sync();  // the next round rewrites owner / key
+                coop_closest_triangles<COUNT>(s, lds, c != 0u, c, lr.o, lr.d, lr.near_, tj, found, hit, lr.far_, cnt);
+                tj += c;
             }
             if (found) {
                 hit.instance = int32_t(inst);
@@ -1203,16 +1234,17 @@ RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, 
 }
 
 // anyIntersection with the cooperative triangle phase of closest_hit_coop: all 64 lanes walk together (`active` = has a shadow
-// ray), the triangles of the lanes that hold a leaf are dealt out over the wave, and a holder is occluded as soon as ANY of its items
-// hits (an LDS flag instead of the atomic min).  A shadow ray's range is fixed, so the answer does not depend on the order of the tests.
+// ray), the triangles of the lanes that hold a leaf are dealt out over the wave in groups of 8, and a holder is occluded as soon as
+// ANY of its items hits (a ballot per group instead of the minimum).  A shadow ray's range is fixed, so the answer does not depend
+// on the order of the tests.
 template <bool COUNT, bool RCP>
 RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, const Ray& ray, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
-    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t lane = lane_id();
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
     prepare<RCP>(g, scene_fast);
-    const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? (s.walk_l < 8u ? s.walk_l : 8u) : 8u;
+    const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? (s.walk_l < 8u ? s.walk_l : 8u) : 8u, hmin = s.walk_h;
     uint32_t n = active ? s.tlas_root : RZ_END, guard = 0u;
     bool occluded = false;
     while (__any(n != RZ_END)) {
@@ -1257,6 +1289,7 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
             uint32_t tj = 0u, tj_end = 0u;
             while (__any(tj != tj_end || m != RZ_END)) {
                 for (uint32_t k = 0u; k < kmax && __any(tj == tj_end && m != RZ_END); ++k) {
+                    if (k != 0u && uint32_t(__popcll(__ballot(tj != tj_end))) >= hmin) break;
                     if (tj == tj_end && m != RZ_END) {
                         RZ_GUARD(guard);
                         float4 m0, m1;
@@ -1274,37 +1307,43 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
                 }
                 if (!__any(tj != tj_end)) continue;
                 const uint32_t c = tj_end - tj < lmax ? tj_end - tj : lmax;
-                uint32_t incl = c;
-                for (uint32_t d = 1u; d < 64u; d <<= 1) {
-                    const uint32_t v = __shfl_up(incl, d);
-                    if (lane >= d) incl += v;
-                }
-                const uint32_t off = incl - c, total = __shfl(incl, 63);
-                for (uint32_t j = 0u; j < c; ++j) lds.owner[off + j] = (unsigned char)lane;
-                lds.res[lane] = 0.0f;  // "one of my triangles was hit"
-                rz_wave_sync();
-                for (uint32_t base = 0u; base < total; base += 64u) {
-                    const uint32_t item = base + lane;
-                    const bool valid = item < total;
-                    const uint32_t h = valid ? uint32_t(lds.owner[item]) : lane;
-                    WalkRay hr;
-                    hr.o = V3(shfl_f(lr.o.x, h), shfl_f(lr.o.y, h), shfl_f(lr.o.z, h));
-                    hr.d = V3(shfl_f(lr.d.x, h), shfl_f(lr.d.y, h), shfl_f(lr.d.z, h));
-                    hr.near_ = shfl_f(lr.near_, h), hr.far_ = shfl_f(lr.far_, h);
-                    const uint32_t htj = __shfl(tj, int(h)), hoff = __shfl(off, int(h));
-                    if (valid) {
-                        const uint32_t tri = htj + (item - hoff);
-                        const float4 a = s.tris[3 * tri], b = s.tris[3 * tri + 1], cc = s.tris[3 * tri + 2];
-                        float t, b1, b2, det;
-                        RZ_COUNT(tri_tests);
-                        RZ_COUNT(shadow_tri_tests);
-                        if (tri_hit(xyz(a), xyz(b), xyz(cc), hr, t, b1, b2, det)) lds.res[h] = 1.0f;
+                const bool holding = c != 0u;
+                const CoopDeal deal = coop_deal(holding, c);
+                if (holding) {
+                    const f4 r0 = F4(lr.o.x, lr.o.y, lr.o.z, lr.near_), r1 = F4(lr.d.x, lr.d.y, lr.d.z, lr.far_);
+                    lds.rec[deal.pos] = r0, lds.rec[CoopLds::kEntries + deal.pos] = r1;
+                    lds.rec[2u * CoopLds::kEntries + deal.pos] = F4(__uint_as_float(tj), __uint_as_float(c < 4u ? c : 4u), 0.0f, 0.0f);
+                    lds.res[deal.pos] = F4(0.0f, 0.0f, 0.0f, 0.0f);  // .x != 0: one of the entry's triangles was hit
+                    if (deal.big) {
+                        lds.rec[deal.pos + 1u] = r0, lds.rec[CoopLds::kEntries + deal.pos + 1u] = r1;
+                        lds.rec[2u * CoopLds::kEntries + deal.pos + 1u] = F4(__uint_as_float(tj + 4u), __uint_as_float(c - 4u), 0.0f, 0.0f);
+                        lds.res[deal.pos + 1u] = F4(0.0f, 0.0f, 0.0f, 0.0f);
                     }
                 }
                 rz_wave_sync();
-                if (c != 0u) {
+                for (uint32_t base = 0u; base < deal.n_entries * 4u; base += 64u) {
+                    const uint32_t e = (base + lane) >> 2, j = lane & 3u;
+                    bool item_hit = false;
+                    if (e < deal.n_entries) {
+                        const f4 r2 = lds.rec[2u * CoopLds::kEntries + e];
+                        if (j < __float_as_uint(r2.y)) {
+                            const f4 r0 = lds.rec[e], r1 = lds.rec[CoopLds::kEntries + e];
+                            WalkRay hr;
+                            hr.o = V3(r0.x, r0.y, r0.z), hr.d = V3(r1.x, r1.y, r1.z), hr.near_ = r0.w, hr.far_ = r1.w;
+                            const uint32_t tri = __float_as_uint(r2.x) + j;
+                            const float4 a = s.tris[3 * tri], b = s.tris[3 * tri + 1], cc = s.tris[3 * tri + 2];
+                            float t, b1, b2, det;
+                            RZ_COUNT(tri_tests);
+                            RZ_COUNT(shadow_tri_tests);
+                            item_hit = tri_hit(xyz(a), xyz(b), xyz(cc), hr, t, b1, b2, det);
+                        }
+                    }
+                    if (item_hit) lds.res[e] = F4(1.0f, 0.0f, 0.0f, 0.0f);  // every writer of a slot writes the same value
+                }
+                rz_wave_sync();
+                if (holding) {
                     tj += c;
-                    if (lds.res[lane] != 0.0f) {  // occluded: this lane's walk is over (:465 "TODO: texture fetch" -> mask 0)
+                    if (lds.res[deal.pos].x != 0.0f || (deal.big && lds.res[deal.pos + 1u].x != 0.0f)) {  // occluded: this lane's walk is over (:465 "TODO: texture fetch" -> mask 0)
                         occluded = true;
                         tj = tj_end = 0u, m = RZ_END, i = end = 0u, n = RZ_END, link = RZ_END, descended = false;
                     }

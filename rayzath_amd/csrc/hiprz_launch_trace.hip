@@ -43,3 +43,12 @@ void launch_trace(hiprz_ctx* c, const DFrame& f, bool first, bool counted) {
 }
 
 }  // namespace hiprz
+
+#ifdef RZ_PHASE_STATS  // diagnostic build (tools/phase_stats.py): wave-level executions / active lanes of the walk's step kinds
+extern "C" int hiprz_read_phase_stats(unsigned long long out[16]) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(hiprz::rz_phase), 128);
+    unsigned long long zero[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(hiprz::rz_phase), zero, 128);
+    return 0;
+}
+#endif
