@@ -132,6 +132,13 @@ typedef struct hiprz_material {
 #define HIPRZ_TEX_RGBA8 0u /* Texture / NormalMap (Graphics::Color)   */
 #define HIPRZ_TEX_R8 1u    /* MetalnessMap / RoughnessMap (uint8_t)   */
 #define HIPRZ_TEX_R32F 2u  /* EmissionMap (float)                     */
+/* hiprz_texture.sampling (RayZath/render_parts.hpp:116-130 FilterMode / AddressMode; cuda_buffer.cuh:364-401) */
+#define HIPRZ_TEX_FILTER_POINT 0u
+#define HIPRZ_TEX_FILTER_LINEAR 1u
+#define HIPRZ_TEX_ADDRESS_WRAP (0u << 8)
+#define HIPRZ_TEX_ADDRESS_CLAMP (1u << 8)
+#define HIPRZ_TEX_ADDRESS_MIRROR (2u << 8)
+#define HIPRZ_TEX_ADDRESS_BORDER (3u << 8)
 
 /* One texture descriptor, 48 B (RayZath/render_parts.hpp:113-222).  Texels are
  * row-major, top row first, at texels + offset. cos/sin of the rotation are hoisted to
@@ -146,7 +153,8 @@ typedef struct hiprz_texture {
     float rotation;
     float cos_rotation;
     float sin_rotation;
-    uint32_t pad0;
+    uint32_t sampling; /* HIPRZ_TEX_FILTER_* | HIPRZ_TEX_ADDRESS_*: read only in CUDA-compat mode (HIPRZ_COMPAT_FILTERING); the CPU
+                          kernel point-samples with wrap-around whatever the scene file says (render_parts.hpp:209-221) */
 } hiprz_texture;
 
 /* Spot light, 48 B (RayZath/spot_light.hpp). cos_angle = cosf(angle) hoisted to the host. */
@@ -282,6 +290,19 @@ int hiprz_set_traversal_mode(hiprz_ctx* ctx, int mode);
  * algorithm (what the roofline's algorithmic bytes are made of); 2 = front to back there too: counters = tests executed. */
 int hiprz_set_walk_order(hiprz_ctx* ctx, int order);
 int hiprz_traversal_mode(hiprz_ctx* ctx, int* effective_mode_out); /* valid after hiprz_upload_scene */
+
+/* Behaviours of the reference's CUDA engine that its CPU engine — the parity oracle — does not have.  mode = 0
+ * (default): the CPU kernel, bit-comparable with the oracle.  Any HIPRZ_COMPAT_* flag routes the passes through one fused kernel
+ * (no LDS staging, no ray reordering) that adds the selected behaviours; they are validated against their analytic expectations,
+ * not against the oracle.  Changing the mode restarts accumulation. */
+#define HIPRZ_COMPAT_BEER_LAMBERT 1u  /* ray.color *= opacityColor(medium) * pow(its alpha, distance): cuda_render_kernel.cu:174-176   */
+#define HIPRZ_COMPAT_SCATTERING 2u    /* medium scattering, Material::applyScattering: cuda_material.cuh:141-159, cuda_world.cuh:91-100 */
+#define HIPRZ_COMPAT_SHADOW_COLOR 4u  /* shadow rays pass through triangles, mask *= opacityColor(uv): cuda_instance.cuh:92-164         */
+#define HIPRZ_COMPAT_TEXTURE_MULT 8u  /* texture x colour, emission map x emission: cuda_material.cuh:75-123                           */
+#define HIPRZ_COMPAT_FILTERING 16u    /* hiprz_texture.sampling honoured (linear filter, clamp / mirror / border): cuda_buffer.cuh:364-438 */
+#define HIPRZ_MODE_CPU 0u
+#define HIPRZ_MODE_CUDA_COMPAT 31u
+int hiprz_set_mode(hiprz_ctx* ctx, uint32_t compat_flags);
 
 /* Stage the scene's geometry + shading records into LDS in every workgroup (ds_read instead of
  * dependent global loads): -1 = automatic (when the records fit three workgroups per CU), 0 = never,

@@ -35,7 +35,7 @@ material_dtype = np.dtype([("color", "u1", 4), ("metalness", "<f4"), ("roughness
                            ("metalness_map", "<i4"), ("roughness_map", "<i4"), ("emission_map", "<i4"), ("pad0", "<u4")])
 texture_dtype = np.dtype([("kind", "<u4"), ("width", "<u4"), ("height", "<u4"), ("offset", "<u4"), ("scale", "<f4", 2),
                           ("translation", "<f4", 2), ("rotation", "<f4"), ("cos_rotation", "<f4"),
-                          ("sin_rotation", "<f4"), ("pad0", "<u4")])
+                          ("sin_rotation", "<f4"), ("sampling", "<u4")])
 spot_light_dtype = np.dtype([("position", "<f4", 3), ("size", "<f4"), ("direction", "<f4", 3), ("emission", "<f4"),
                              ("color", "u1", 4), ("angle", "<f4"), ("cos_angle", "<f4"), ("pad0", "<u4")])
 direct_light_dtype = np.dtype([("direction", "<f4", 3), ("emission", "<f4"), ("color", "u1", 4), ("angular_size", "<f4"),
@@ -110,6 +110,7 @@ ENTRY_POINTS = {
     "hiprz_set_shard": (C.c_int, [P, U32, U32]),
     "hiprz_set_traversal_mode": (C.c_int, [P, C.c_int]),
     "hiprz_set_walk_order": (C.c_int, [P, C.c_int]),
+    "hiprz_set_mode": (C.c_int, [P, U32]),
     "hiprz_set_lds_scene": (C.c_int, [P, C.c_int]),
     "hiprz_set_pipeline": (C.c_int, [P, C.c_int]),
     "hiprz_traversal_mode": (C.c_int, [P, C.POINTER(C.c_int)]),

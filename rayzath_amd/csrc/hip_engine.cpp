@@ -82,6 +82,7 @@ FlatScene flatten(const World& world) {
         rec.scale[0] = t->scale[0], rec.scale[1] = t->scale[1];
         rec.translation[0] = t->translation[0], rec.translation[1] = t->translation[1];
         rec.rotation = t->rotation, rec.cos_rotation = std::cos(t->rotation), rec.sin_rotation = std::sin(t->rotation);
+        rec.sampling = t->sampling;
         f.texels.insert(f.texels.end(), t->bitmap.begin(), t->bitmap.end());
         f.textures.push_back(rec);
         return tex_index[t.get()] = int32_t(f.textures.size() - 1);

@@ -54,6 +54,7 @@ struct TextureBuffer {  // render_parts.hpp:113-222
     uint32_t kind = HIPRZ_TEX_RGBA8, width = 0, height = 0;
     std::vector<uint8_t> bitmap;  // row-major, top row first
     float scale[2] = {1, 1}, rotation = 0, translation[2] = {0, 0};
+    uint32_t sampling = HIPRZ_TEX_FILTER_POINT | HIPRZ_TEX_ADDRESS_WRAP;  // "filter mode" / "address mode" of the scene file: CUDA-compat mode only
 };
 
 struct Material {  // material.hpp:119-160; setters clamp as material.cpp:32-61

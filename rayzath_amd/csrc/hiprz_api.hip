@@ -294,7 +294,7 @@ DFrame make_frame(hiprz_ctx* c, bool counted) {
 }
 
 DConfig make_config(const hiprz_ctx* c) {
-    return DConfig{c->config.max_depth, c->config.spot_samples, c->config.direct_samples, c->config.seed};
+    return DConfig{c->config.max_depth, c->config.spot_samples, c->config.direct_samples, c->config.seed, c->mode_flags};
 }
 
 // The binned walk pays off when a mesh visit is short and uniform (every mesh tree is a single leaf, e.g. the
@@ -316,7 +316,8 @@ bool defer_shadows(const hiprz_ctx* c) {
 
 void resolve_pipeline(hiprz_ctx* c) {
     const int before = c->pipeline;
-    if (c->pipeline_setting >= 0) c->pipeline = c->pipeline_setting;
+    if (c->mode_flags != 0u) c->pipeline = 0;  // CUDA-compat mode: the fused compat kernel
+    else if (c->pipeline_setting >= 0) c->pipeline = c->pipeline_setting;
     else {
         // resident needs blob + walk workspace + 8 KiB of parked state per workgroup, four workgroups per CU
         const size_t lds = size_t(c->dscene.hot_bytes) + size_t(c->stack_entries) * 1024u + BinnedLds::kFixedBytes + 8u * 1024u;
@@ -1020,6 +1021,18 @@ int hiprz_set_traversal_mode(hiprz_ctx* c, int mode) {
     if (mode < -1 || mode == 0 || mode > 3) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: -1 = per scene, 1 = LDS stack, 2 = workgroup-binned, 3 = skip links (single-wave workgroups)");
     assign_setting(c, c->traversal_mode, mode);
     resolve_pipeline(c);
+    return HIPRZ_OK;
+}
+
+int hiprz_set_mode(hiprz_ctx* c, uint32_t compat_flags) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (compat_flags & ~HIPRZ_MODE_CUDA_COMPAT) return fail(c, HIPRZ_ERR_INVALID, "set_mode: unknown HIPRZ_COMPAT_* flag");
+    if (compat_flags != c->mode_flags) {
+        c->mode_flags = compat_flags;
+        c->graph_valid = false;
+        c->reset_pending = true;  // another integrator: what has been accumulated does not mix with it
+        resolve_pipeline(c);
+    }
     return HIPRZ_OK;
 }
 

@@ -125,6 +125,7 @@ struct DCamera {
 
 struct DConfig {
     uint32_t max_depth, spot_samples, direct_samples, seed;
+    uint32_t flags;  // HIPRZ_COMPAT_* (hiprz_set_mode); 0 = the CPU kernel's behaviour.  Only the compat instantiations read it.
 };
 
 // Per-pixel persistent state (CameraContext, cpu_engine_kernel.hpp:29-51), tile-major:
@@ -1375,6 +1376,13 @@ RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit
 // MODE 6 ("plain"): no lights AND no maps of any kind in the scene — texture fetches, normal mapping and the sky's texture
 // coordinates are compiled out as well.
 #define RZ_SHADOW_PLAIN 6
+// MODE 8 ("compat"): the CUDA engine's behaviours selected by DConfig::flags (hiprz_compat.hpp): shadow rays inline on skip links,
+// opaque as in the CPU kernel or — HIPRZ_COMPAT_SHADOW_COLOR — through triangles with a coloured mask.
+#define RZ_SHADOW_COMPAT 8
+template <bool COUNT>
+RZ_DEV col4 compat_shadow_mask(const DScene& s, const Ray& ray, bool filtering, Counters& cnt);  // hiprz_compat.hpp
+template <bool COUNT>
+RZ_DEV col4 compat_fetch(const DScene& s, int32_t tex, float u, float v, Counters& cnt);            // hiprz_compat.hpp
 struct ShadowCtx {
     uint32_t* lds_column;
     TopCache top;
@@ -1471,7 +1479,7 @@ struct Surface {
 
 // analyzeIntersection: cpu_engine_kernel.cpp:354-395; mesh_component.cpp:115-167
 template <bool COUNT, bool TEX = true>
-RZ_DEV void analyze_intersection(const DScene& s, const Hit& hit, Surface& sf, Material& m, Counters& cnt) {
+RZ_DEV void analyze_intersection(const DScene& s, const Hit& hit, Surface& sf, Material& m, Counters& cnt, bool compat_filtering = false) {
     const uint32_t inst = uint32_t(hit.instance);
     const float4 i1 = s.instances[7 * inst + 1], i2 = s.instances[7 * inst + 2],
                  i3 = s.instances[7 * inst + 3], i4 = s.instances[7 * inst + 4];
@@ -1507,7 +1515,7 @@ RZ_DEV void analyze_intersection(const DScene& s, const Hit& hit, Surface& sf, M
         sf.mapped_normal = face_normal;
     }
     if (TEX && m.normal_map >= 0 && has_texcrds) {  // Triangle::mapNormal, mesh_component.cpp:132-167
-        const col4 map_color = fetch_rgba8<COUNT>(s, m.normal_map, sf.u, sf.v, cnt);
+        const col4 map_color = compat_filtering ? compat_fetch<COUNT>(s, m.normal_map, sf.u, sf.v, cnt) : fetch_rgba8<COUNT>(s, m.normal_map, sf.u, sf.v, cnt);
         // v2 and v3 ride in the padding of the device attribute record (the triangle record holds edges)
         const v3 v1 = xyz(ta), v2 = V3(at[0].w, at[1].w, at[2].w), vv3 = V3(at[3].w, uv3.z, uv3.w);
         const v3 edge1 = (v2 - v1) * scale;
@@ -1716,8 +1724,10 @@ RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const Shado
             if constexpr (MODE == RZ_SHADOW_DEFER) {
                 defer_sample(lds_column, i, sr, term);
             } else {
-                const float V = any_hit<MODE, COUNT>(s, lds_column, sr, cnt);
-                const col4 V_PL = splat(V);
+                col4 V_PL;
+                if constexpr (MODE == RZ_SHADOW_COMPAT)
+                    V_PL = (cfg.flags & HIPRZ_COMPAT_SHADOW_COLOR) ? compat_shadow_mask<COUNT>(s, sr, (cfg.flags & HIPRZ_COMPAT_FILTERING) != 0u, cnt) : splat(any_hit<3, COUNT>(s, lds_column, sr, cnt));
+                else V_PL = splat(any_hit<MODE, COUNT>(s, lds_column, sr, cnt));
                 direct_total = direct_total + (term * V_PL) * V_PL.a;
             }
         }
@@ -1773,8 +1783,10 @@ RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const Shado
             if constexpr (MODE == RZ_SHADOW_DEFER) {
                 defer_sample(lds_column, cfg.direct_samples + i, sr, term);
             } else {
-                const float V = any_hit<MODE, COUNT>(s, lds_column, sr, cnt);
-                const col4 V_PL = splat(V);
+                col4 V_PL;
+                if constexpr (MODE == RZ_SHADOW_COMPAT)
+                    V_PL = (cfg.flags & HIPRZ_COMPAT_SHADOW_COLOR) ? compat_shadow_mask<COUNT>(s, sr, (cfg.flags & HIPRZ_COMPAT_FILTERING) != 0u, cnt) : splat(any_hit<3, COUNT>(s, lds_column, sr, cnt));
+                else V_PL = splat(any_hit<MODE, COUNT>(s, lds_column, sr, cnt));
                 spot_total = spot_total + (term * V_PL) * V_PL.a;
             }
         }

@@ -8,6 +8,7 @@
 
 #include "hiprz.h"
 #include "hiprz_device.hpp"
+#include "hiprz_compat.hpp"
 
 namespace hiprz {
 
@@ -82,13 +83,17 @@ RZ_DEV int trace_path(const DScene& s, unsigned char* workspace, uint32_t* lds_c
 // antialiased camera ray when the path ended).  ps.ray.far_ must hold the hit distance.
 template <bool COUNT, int SHADOW = 1>
 RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cfg, const PixelId& p, PathState& ps, uint32_t pass,
-                          int found, const Hit& hit, const ShadowCtx& lds_column, Counters& cnt, col4& final_color, bool& path_continues) {
+                          int found, const Hit& hit, const ShadowCtx& lds_column, Counters& cnt, col4& final_color, bool& path_continues,
+                          Rng* shared_rng = nullptr) {
+    constexpr bool COMPAT = SHADOW == RZ_SHADOW_COMPAT;  // the CUDA engine's behaviours by cfg.flags; `found == 3`: the medium scattered the ray
     Ray& ray = ps.ray;
     col4& ray_color = ps.color;
     uint32_t& ray_material = ps.material;
     uint32_t& depth = ps.depth;
     const uint32_t pixel_idx = p.y * cam.width + p.x;
-    Rng rng(float(p.x) / float(cam.width), float(p.y) / float(cam.height), seed_value(cfg.seed, pass, (pixel_idx + depth) & 255u));
+    Rng own_rng(float(p.x) / float(cam.width), float(p.y) / float(cam.height), seed_value(cfg.seed, pass, (pixel_idx + depth) & 255u));
+    Rng& rng = COMPAT ? *shared_rng : own_rng;  // compat: the kernel drew the scattering distance from this stream before the walk
+    const bool filtering = COMPAT && (cfg.flags & HIPRZ_COMPAT_FILTERING) != 0u;
 
     final_color = splat(0.0f);
     Surface sf;
@@ -101,7 +106,11 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
     constexpr bool TEX = SHADOW != RZ_SHADOW_PLAIN;  // PLAIN: the scene has no maps at all (every map index is -1)
     Material m;
     if (found == 2) {
-        analyze_intersection<COUNT, TEX>(s, hit, sf, m, cnt);
+        analyze_intersection<COUNT, TEX>(s, hit, sf, m, cnt, filtering);
+    } else if (COMPAT && found == 3) {  // Material::applyScattering: the medium itself is the surface, its normal the ray's direction
+        m = load_material(s, ray_material);
+        sf.surface_material = sf.behind_material = ray_material;
+        sf.normal = sf.mapped_normal = ray.d;
     } else {
         m = load_material(s, HIPRZ_MATERIAL_WORLD);
         if (TEX && found == 1) {  // texcrd of the sky sphere (cpu_engine_kernel.cpp:292-295); only a map reads it
@@ -111,20 +120,31 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
     }
     sf.surface_scattering = m.scattering;
     // fetchColor / fetchEmission (:505-512, 523-528)
-    sf.color = from_u8(m.color);
-    if (TEX && m.texture >= 0) sf.color = fetch_rgba8<COUNT>(s, m.texture, sf.u, sf.v, cnt);
-    sf.color.a = 1.0f - sf.color.a;
-    sf.emission = TEX && m.emission_map >= 0 ? fetch_r32f<COUNT>(s, m.emission_map, sf.u, sf.v, cnt) : m.emission;
+    if (COMPAT && (cfg.flags & HIPRZ_COMPAT_TEXTURE_MULT)) {  // cuda_material.cuh:86-95, 118-123: maps multiply
+        sf.color = compat_opacity_color<COUNT>(s, m, sf.u, sf.v, true, filtering, cnt);
+        sf.emission = m.emission;
+        if (m.emission_map >= 0) sf.emission *= filtering ? compat_fetch<COUNT>(s, m.emission_map, sf.u, sf.v, cnt).r : fetch_r32f<COUNT>(s, m.emission_map, sf.u, sf.v, cnt);
+    } else {
+        sf.color = from_u8(m.color);
+        if (TEX && m.texture >= 0) sf.color = filtering ? compat_fetch<COUNT>(s, m.texture, sf.u, sf.v, cnt) : fetch_rgba8<COUNT>(s, m.texture, sf.u, sf.v, cnt);
+        sf.color.a = 1.0f - sf.color.a;
+        sf.emission = TEX && m.emission_map >= 0 ? (filtering ? compat_fetch<COUNT>(s, m.emission_map, sf.u, sf.v, cnt).r : fetch_r32f<COUNT>(s, m.emission_map, sf.u, sf.v, cnt)) : m.emission;
+    }
+    if (COMPAT && (cfg.flags & HIPRZ_COMPAT_BEER_LAMBERT)) {  // Beer's law in the medium the segment crossed: cuda_render_kernel.cu:158-176
+        col4 medium = from_u8(load_material(s, ray_material).color);
+        medium.a = 1.0f - medium.a;
+        ray_color = ray_color * (medium * RZ_POWF(medium.a, ray.far_));
+    }
     if (sf.emission > 0.0f) final_color = final_color + (ray_color * sf.color) * sf.emission;
 
     v3 point = V3(0.0f, 0.0f, 0.0f), next_direction = V3(0.0f, 0.0f, 0.0f);
-    if (found != 2) {
+    if (found != 2 && !(COMPAT && found == 3)) {
         depth = 255u;  // TracingState::endPath
     } else {
         RZ_COUNT(hits);
         depth += 1u;
-        sf.metalness = TEX && m.metalness_map >= 0 ? fetch_r8<COUNT>(s, m.metalness_map, sf.u, sf.v, cnt) : m.metalness;
-        sf.roughness = TEX && m.roughness_map >= 0 ? fetch_r8<COUNT>(s, m.roughness_map, sf.u, sf.v, cnt) : m.roughness;
+        sf.metalness = TEX && m.metalness_map >= 0 ? (filtering ? compat_fetch<COUNT>(s, m.metalness_map, sf.u, sf.v, cnt).r : fetch_r8<COUNT>(s, m.metalness_map, sf.u, sf.v, cnt)) : m.metalness;
+        sf.roughness = TEX && m.roughness_map >= 0 ? (filtering ? compat_fetch<COUNT>(s, m.roughness_map, sf.u, sf.v, cnt).r : fetch_r8<COUNT>(s, m.roughness_map, sf.u, sf.v, cnt)) : m.roughness;
         sf.fresnel = fresnel_specular_ratio(sf.mapped_normal, ray.d, material_ior(s, ray_material), material_ior(s, sf.behind_material),
                                             sf.refr_x, sf.refr_y);
         sf.reflectance = lerpf(sf.fresnel, 1.0f, sf.metalness);
@@ -161,11 +181,11 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
 // shade_segment + accumulation + next-segment state to HBM (renderFirstPass / renderCumulativePass after traceRay)
 template <bool FIRST, bool COUNT, int SHADOW = 1>
 RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& cfg, const DFrame& f, const PixelId& p, PathState& ps,
-                            int found, const Hit& hit, const ShadowCtx& lds_column, Counters& cnt) {
+                            int found, const Hit& hit, const ShadowCtx& lds_column, Counters& cnt, Rng* shared_rng = nullptr) {
     const float hit_distance = ps.ray.far_;
     col4 final_color;
     bool path_continues;
-    shade_segment<COUNT, SHADOW>(s, cam, cfg, p, ps, FIRST ? 0u : *f.pass, found, hit, lds_column, cnt, final_color, path_continues);
+    shade_segment<COUNT, SHADOW>(s, cam, cfg, p, ps, FIRST ? 0u : *f.pass, found, hit, lds_column, cnt, final_color, path_continues, shared_rng);
     const Ray& ray = ps.ray;
     const col4& ray_color = ps.color;
     const uint32_t ray_material = ps.material, depth = ps.depth;
@@ -577,5 +597,35 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_coop_kernel(const DScene s
     flush_counters<COUNT>(f, 0u, cnt);
 }
 
+
+// ---- CUDA-compat mode (hiprz_set_mode, hiprz_compat.hpp): one fused kernel per pass, scene in global memory ----
+// Order of the random draws as in the CUDA engine: the medium's scattering distance first (cuda_material.cuh:146-148), then
+// whatever the shading draws.
+template <bool FIRST, bool COUNT>
+__global__ void __launch_bounds__(256) rz_compat_pass_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f) {
+    const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
+    Counters cnt;
+    if (p.active) {
+        PathState ps;
+        load_path<FIRST>(f, cam, p, ps);
+        const uint32_t pass = FIRST ? 0u : *f.pass, pixel_idx = p.y * cam.width + p.x;
+        Rng rng(float(p.x) / float(cam.width), float(p.y) / float(cam.height), seed_value(cfg.seed, pass, (pixel_idx + ps.depth) & 255u));
+        bool scattered = false;
+        if (cfg.flags & HIPRZ_COMPAT_SCATTERING) {  // Material::applyScattering of the medium the ray travels in
+            const float sigma = material_scattering(s, ps.material);
+            if (sigma > 1.0e-4f) {
+                const float distance = (-logf(rng.unsignedUniform() + 1.0e-4f)) / sigma;
+                if (distance < ps.ray.far_) ps.ray.far_ = distance, scattered = true;
+            }
+        }
+        Hit hit;
+        hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
+        int found = 0;
+        if (s.n_instances != 0u) found = closest_hit_skip<COUNT, false>(s, TopCache{nullptr, nullptr, 0u}, ps.ray, hit, cnt);
+        if (scattered && found != 2) found = 3;
+        shade_and_store<FIRST, COUNT, RZ_SHADOW_COMPAT>(s, cam, cfg, f, p, ps, found, hit, ShadowCtx{nullptr, TopCache{nullptr, nullptr, 0u}}, cnt, &rng);
+    }
+    flush_counters<COUNT>(f, p.active ? 1u : 0u, cnt);
+}
 
 }  // namespace hiprz

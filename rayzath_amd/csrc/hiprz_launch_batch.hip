@@ -10,6 +10,10 @@ template <bool FIRST, bool COUNT>
 void launch_fused_t(hiprz_ctx* c, const DFrame& f) {
     const PassGeometry g = pass_geometry(c);
     const DConfig cfg = make_config(c);
+    if (c->mode_flags != 0u) {  // CUDA-compat mode: its own fused kernel on the global scene
+        hipLaunchKernelGGL((rz_compat_pass_kernel<FIRST, COUNT>), g.grid, g.block, 0, c->stream, c->dscene, c->dcamera, cfg, f);
+        return;
+    }
     // the fused kernel's shadow rays use the stack walk: its columns must exist in every mode
     const size_t lds = g.mode == 2 ? g.walk_lds + 4096u : g.walk_lds;  // mode 2: + the parked path state
     if (g.mode == 2) {

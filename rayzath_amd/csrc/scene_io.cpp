@@ -687,7 +687,11 @@ struct SceneLoader {
             if (key == "scale") to_vec2(value, t->scale);
             else if (key == "rotation" && value.is_number()) t->rotation = as_float(value);
             else if (key == "translation") to_vec2(value, t->translation);
-            // "filter mode" / "address mode": the CPU kernel point-samples with wrap-around whatever they say (render_parts.hpp:209-221)
+            // "filter mode" / "address mode" (json_loader.cpp:120-150): kept in the record; only the CUDA-compat mode reads them — the CPU
+            // kernel point-samples with wrap-around whatever they say (render_parts.hpp:209-221)
+            else if (key == "filter mode" && value.is_string()) t->sampling = (t->sampling & ~0xFFu) | (value.str == "linear" ? HIPRZ_TEX_FILTER_LINEAR : HIPRZ_TEX_FILTER_POINT);
+            else if (key == "address mode" && value.is_string())
+                t->sampling = (t->sampling & 0xFFu) | (value.str == "clamp" ? HIPRZ_TEX_ADDRESS_CLAMP : value.str == "mirror" ? HIPRZ_TEX_ADDRESS_MIRROR : value.str == "border" ? HIPRZ_TEX_ADDRESS_BORDER : HIPRZ_TEX_ADDRESS_WRAP);
         }
         if (const Json* n = j.find("name"); n && n->is_string()) maps[which][n->str] = t;
         return t;
@@ -1056,6 +1060,14 @@ std::string color(const Color& c) {
 // <scene dir>/maps/<kind>/ — RGBA PNG for textures and normal maps, grey PNG for metalness / roughness, Radiance .hdr for emission.
 // Deliberate difference: a normal map is written with its green channel negated back, so that the file holds what was loaded
 // (the reference writes the in-memory bitmap, whose green the loader negated: every save / load cycle flips it there).
+static const char* address_mode_name(uint32_t sampling) {
+    switch (sampling & 0xFF00u) {
+        case HIPRZ_TEX_ADDRESS_CLAMP: return "clamp";
+        case HIPRZ_TEX_ADDRESS_MIRROR: return "mirror";
+        case HIPRZ_TEX_ADDRESS_BORDER: return "border";
+        default: return "wrap";
+    }
+}
 struct SavedMaps {
     static constexpr const char* kJsonKeys[5] = {"Texture", "NormalMap", "MetalnessMap", "RoughnessMap", "EmissionMap"};
     static constexpr const char* kDirs[5] = {"texture", "normal", "metalness", "roughness", "emission"};
@@ -1125,7 +1137,7 @@ void saveScene(const std::string& path, const World& world) {
         out << "\n  \"" << SavedMaps::kJsonKeys[k] << "\": [";
         for (size_t i = 0; i < maps.list[k].size(); ++i) {
             const TextureBuffer& t = *maps.list[k][i];
-            out << (i ? ",\n   " : "\n   ") << "{\"name\": \"" << maps.name[k][&t] << "\", \"filter mode\": \"point\", \"address mode\": \"wrap\", \"scale\": [" << num(t.scale[0]) << ", "
+            out << (i ? ",\n   " : "\n   ") << "{\"name\": \"" << maps.name[k][&t] << "\", \"filter mode\": \"" << ((t.sampling & 0xFFu) == HIPRZ_TEX_FILTER_LINEAR ? "linear" : "point") << "\", \"address mode\": \"" << address_mode_name(t.sampling) << "\", \"scale\": [" << num(t.scale[0]) << ", "
                 << num(t.scale[1]) << "], \"rotation\": " << num(t.rotation) << ", \"translation\": [" << num(t.translation[0]) << ", " << num(t.translation[1]) << "], \"file\": \""
                 << maps.file[k][&t] << "\"}";
         }

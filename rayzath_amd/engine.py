@@ -36,6 +36,9 @@ class RenderConfig:
                            self.light_sampling.direct_light, self.seed & 0xFFFFFFFF)
 
 
+COMPAT_BEER_LAMBERT, COMPAT_SCATTERING, COMPAT_SHADOW_COLOR, COMPAT_TEXTURE_MULT, COMPAT_FILTERING = 1, 2, 4, 8, 16  # hiprz_set_mode
+
+
 class Context:
     """Owns one hiprz_ctx (one GPU, one stream)."""
 
@@ -82,6 +85,10 @@ class Context:
     def set_walk_order(self, order):
         """0 = mesh children in the reference's order (counters equal the CPU kernel's), 1 = front to back (default)."""
         self._check(self.lib.hiprz_set_walk_order(self._ctx, order))
+
+    def set_mode(self, compat_flags):
+        """0 = the CPU kernel (default, parity-checked); COMPAT_* flags add behaviours of the reference's CUDA engine (include/hiprz.h)."""
+        self._check(self.lib.hiprz_set_mode(self._ctx, compat_flags))
 
     def set_pipeline(self, pipeline):
         self._check(self.lib.hiprz_set_pipeline(self._ctx, pipeline))

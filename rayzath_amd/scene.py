@@ -31,7 +31,10 @@ def _f3(v):
 class TextureBuffer:
     """RayZath/render_parts.hpp:113-222. bitmap: (H,W,4) u8 | (H,W) u8 | (H,W) f32, top row first."""
 
-    def __init__(self, bitmap, scale=(1.0, 1.0), rotation=0.0, translation=(0.0, 0.0)):
+    FILTERS = {"point": 0, "linear": 1}
+    ADDRESS_MODES = {"wrap": 0, "clamp": 1, "mirror": 2, "border": 3}
+
+    def __init__(self, bitmap, scale=(1.0, 1.0), rotation=0.0, translation=(0.0, 0.0), filter_mode="point", address_mode="wrap"):
         bitmap = np.ascontiguousarray(bitmap)
         if bitmap.dtype == np.uint8 and bitmap.ndim == 3 and bitmap.shape[2] == 4:
             self.kind = _abi.TEX_RGBA8
@@ -45,6 +48,8 @@ class TextureBuffer:
         self.scale = (F32(scale[0]), F32(scale[1]))
         self.rotation = F32(rotation)
         self.translation = (F32(translation[0]), F32(translation[1]))
+        # read only in CUDA-compat mode (hiprz_set_mode): the CPU kernel point-samples with wrap-around (render_parts.hpp:209-221)
+        self.filter_mode, self.address_mode = filter_mode, address_mode
 
 
 class Material:
@@ -398,6 +403,7 @@ def flatten(world, backend=None):
             rec["offset"] = len(pool)
             rec["scale"], rec["translation"], rec["rotation"] = t.scale, t.translation, t.rotation
             rec["cos_rotation"], rec["sin_rotation"] = _cosf(F32(t.rotation)), _sinf(F32(t.rotation))
+            rec["sampling"] = TextureBuffer.FILTERS[t.filter_mode] | (TextureBuffer.ADDRESS_MODES[t.address_mode] << 8)
             pool.extend(t.bitmap.tobytes())
             tex_index[id(t)] = len(tex_records)
             tex_records.append(rec)

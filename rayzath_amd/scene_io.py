@@ -258,7 +258,7 @@ def save_scene_json(world, path):
         objects["Instance"].append(e)
     for k, (_, _, json_key) in enumerate(_MAP_SLOTS):
         if map_order[k]:
-            objects[json_key] = [{"name": map_names[k][id(t)][0], "filter mode": "point", "address mode": "wrap", "scale": [_f(t.scale[0]), _f(t.scale[1])],
+            objects[json_key] = [{"name": map_names[k][id(t)][0], "filter mode": t.filter_mode, "address mode": t.address_mode, "scale": [_f(t.scale[0]), _f(t.scale[1])],
                                   "rotation": _f(t.rotation), "translation": [_f(t.translation[0]), _f(t.translation[1])],
                                   "file": map_names[k][id(t)][1]} for t in map_order[k]]
     doc = {"Objects": objects, "Material": with_maps(_material(world.material), world.material),
