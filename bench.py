@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=-1, help="0 fused pass kernel, 1 trace + shade kernels, 2 resident batch kernel (-1: chosen per scene)")
     ap.add_argument("--ray-sort", type=int, default=-1, help="-1 auto, 0 off, 1 on")
     ap.add_argument("--walk-order", type=int, default=-1, help="mesh child order of the skip-link walk: 0 reference order, 1 front to back (-1: library default)")
+    ap.add_argument("--tree", type=int, default=0, help="0 the scene's (reference) mesh trees, 1 rebuilt with a binned SAH (hiprz_set_tree; same frames, fewer tests; not the default)")
     ap.add_argument("--no-xcd-swizzle", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-gather", action="store_true", help="check the gathered frame against an unsharded render (N > 1)")
@@ -121,6 +122,7 @@ def main():
         ctx.set_walk_order(args.walk_order)
     if args.no_xcd_swizzle:
         ctx.set_xcd_swizzle(False)
+    ctx.set_tree(args.tree)
     ctx.set_shard(rank, world)
     ctx.upload_scene(flat)
     ctx.upload_camera(cam)
@@ -285,6 +287,7 @@ def main():
                        "triangles": int(len(flat.tris)), "instances": int(len(flat.instances)),
                        "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
                        "traversal": {1: "lds-stack", 2: "workgroup-binned", 3: "skip-links"}[ctx.traversal_mode()],
+                       "mesh_trees": "binned SAH, rebuilt at upload" if args.tree else "reference builder (scene snapshot)",
                        "pipeline": {0: "fused (one kernel per pass)", 1: "trace+shade (two kernels per pass)", 2: "resident (one kernel per step)"}[pipeline]},
             "timing": {"protocol": f"{len(samples)} repeats of exactly {args.steps} steps ({args.steps * RPP} passes) between barrier + synchronize fences; value = median repeat",
                        "repeat_seconds": samples, "passes_timed": passes_timed, "timed_wall_seconds": timed_wall},

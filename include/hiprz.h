@@ -72,7 +72,7 @@ typedef struct hiprz_tri {
     float v2[3];
     uint32_t source_index; /* index of the triangle in its mesh before leaf reordering */
     float v3[3];
-    uint32_t pad0;
+    uint32_t pad0; /* ignored on upload (the device copy keeps the triangle's position in the reference's leaf order here) */
 } hiprz_tri;
 
 /* Shading record of one triangle, 96 B, read once per hit
@@ -303,6 +303,20 @@ int hiprz_traversal_mode(hiprz_ctx* ctx, int* effective_mode_out); /* valid afte
 #define HIPRZ_MODE_CPU 0u
 #define HIPRZ_MODE_CUDA_COMPAT 31u
 int hiprz_set_mode(hiprz_ctx* ctx, uint32_t compat_flags);
+
+/* Which mesh trees the walks use.  HIPRZ_TREE_REFERENCE (default): the trees of the uploaded snapshot — the reference's builder
+ * (bvh_tree_node.hpp:117-215), the anchor of the work counters.  HIPRZ_TREE_SAH: at upload every mesh tree is rebuilt over the same
+ * triangles with a binned surface-area heuristic (leaves of at most 8 triangles).  A tree decides which boxes and triangles a ray
+ * meets, not what it hits: frames are identical (equally distant triangles are ranked by their position in the reference's visiting
+ * order), while the tests per segment drop.  With a rebuilt tree every walk — counted ones too — runs front to back on skip links
+ * (the scene is not staged in LDS), and the work counters are those of the rebuilt tree.  Takes effect at the next hiprz_upload_scene. */
+#define HIPRZ_TREE_REFERENCE 0u
+#define HIPRZ_TREE_SAH 1u
+int hiprz_set_tree(hiprz_ctx* ctx, uint32_t tree);
+/* The rebuild itself (pure host): new node array (world tree copied, mesh trees rebuilt; at most max_nodes = n_nodes + 2 * n_tris +
+ * n_instances), tri_order_out[new index] = index in scene->tris, blas_roots_out[instance] = its mesh root in the new array. */
+int hiprz_rebuild_mesh_trees(const hiprz_scene* scene, uint32_t tree, hiprz_node* nodes_out, uint32_t max_nodes, uint32_t* n_nodes_out,
+                             uint32_t* tri_order_out, uint32_t* blas_roots_out, uint32_t* tlas_root_out);
 
 /* Stage the scene's geometry + shading records into LDS in every workgroup (ds_read instead of
  * dependent global loads): -1 = automatic (when the records fit three workgroups per CU), 0 = never,

@@ -301,6 +301,7 @@ DConfig make_config(const hiprz_ctx* c) {
 // Cornell configs: 329 vs 370 us per pass); with deep mesh trees a round lasts as long as its slowest item
 // and the nested walk is faster (config C: 1 668 vs 2 450 us).
 int effective_mode(const hiprz_ctx* c) {
+    if (c->scene_tree != HIPRZ_TREE_REFERENCE) return 3;  // rebuilt trees: the front-to-back cooperative walks only
     if (c->traversal_mode >= 0) return c->traversal_mode;
     // records do not fit LDS: skip-link walks in single-wave workgroups
     if (!c->lds_scene && c->pipeline == 1) return 3;
@@ -317,6 +318,7 @@ bool defer_shadows(const hiprz_ctx* c) {
 void resolve_pipeline(hiprz_ctx* c) {
     const int before = c->pipeline;
     if (c->mode_flags != 0u) c->pipeline = 0;  // CUDA-compat mode: the fused compat kernel
+    else if (c->scene_tree != HIPRZ_TREE_REFERENCE) c->pipeline = 1;
     else if (c->pipeline_setting >= 0) c->pipeline = c->pipeline_setting;
     else {
         // resident needs blob + walk workspace + 8 KiB of parked state per workgroup, four workgroups per CU
@@ -328,7 +330,7 @@ void resolve_pipeline(hiprz_ctx* c) {
 }
 
 bool use_lds_scene(const hiprz_ctx* c) {
-    if (c->lds_scene_override == 0) return false;
+    if (c->lds_scene_override == 0 || c->scene_tree != HIPRZ_TREE_REFERENCE) return false;
     if (c->lds_scene_override == 1) return size_t(c->dscene.hot_bytes) + size_t(c->stack_entries) * 1024u <= 160u * 1024u;
     return c->lds_scene;
 }
@@ -819,6 +821,37 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     StageTimer timer;
     SceneCheck chk;
     if (check_scene(sc, chk) != HIPRZ_OK) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: " + chk.error);
+    // opt-in mesh trees of better quality (hiprz_set_tree): the snapshot is rewritten — new nodes, triangles and their attributes in
+    // the new leaf order, every triangle remembering its position in the reference's order — and then takes the usual way
+    hiprz_scene rebuilt_scene;
+    std::vector<hiprz_node> rebuilt_nodes;
+    std::vector<hiprz_tri> rebuilt_tris;
+    std::vector<hiprz_tri_attr> rebuilt_attrs;
+    std::vector<hiprz_instance> rebuilt_instances;
+    if (c->tree_mode != HIPRZ_TREE_REFERENCE && sc->n_tris != 0u) {
+        const uint32_t max_nodes = sc->n_nodes + 2u * sc->n_tris + sc->n_instances + 1u;
+        rebuilt_nodes.resize(max_nodes);
+        std::vector<uint32_t> order(sc->n_tris), roots(sc->n_instances ? sc->n_instances : 1u);
+        uint32_t n_nodes = 0u, tlas_root = 0u;
+        if (hiprz_rebuild_mesh_trees(sc, c->tree_mode, rebuilt_nodes.data(), max_nodes, &n_nodes, order.data(), roots.data(), &tlas_root) != HIPRZ_OK)
+            return fail(c, HIPRZ_ERR_INVALID, "upload_scene: the mesh trees could not be rebuilt (leaves of a mesh must tile one range of triangles)");
+        rebuilt_nodes.resize(n_nodes);
+        rebuilt_tris.resize(sc->n_tris), rebuilt_attrs.resize(sc->n_tris);
+        for (uint32_t i = 0; i < sc->n_tris; ++i) {
+            rebuilt_tris[i] = sc->tris[order[i]];
+            rebuilt_tris[i].pad0 = order[i];
+            rebuilt_attrs[i] = sc->tri_attrs[order[i]];
+        }
+        rebuilt_instances.assign(sc->instances, sc->instances + sc->n_instances);
+        for (uint32_t i = 0; i < sc->n_instances; ++i) rebuilt_instances[i].blas_root = roots[i];
+        rebuilt_scene = *sc;
+        rebuilt_scene.n_nodes = n_nodes, rebuilt_scene.nodes = rebuilt_nodes.data(), rebuilt_scene.tlas_root = tlas_root;
+        rebuilt_scene.tris = rebuilt_tris.data(), rebuilt_scene.tri_attrs = rebuilt_attrs.data(), rebuilt_scene.instances = rebuilt_instances.data();
+        sc = &rebuilt_scene;
+        if (check_scene(sc, chk) != HIPRZ_OK) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: rebuilt trees: " + chk.error);
+        c->timings.set("rebuild mesh trees", timer.ms());
+    }
+    const bool own_trees = sc == &rebuilt_scene;
     const uint32_t world_depth = chk.world_depth, mesh_depth = chk.mesh_depth;
 
     DerivedTables derived;
@@ -881,6 +914,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     for (uint32_t i = 0; i < sc->n_tris; ++i) {
         hiprz_tri& t = dtris[i];
         hiprz_tri_attr& a = dattrs[i];
+        if (!own_trees) t.pad0 = i;  // position in the reference's leaf order: what equally distant hits are ranked by
         a.pad0 = t.v2[0], a.pad1 = t.v2[1], a.pad2 = t.v2[2], a.pad3 = t.v3[0], a.pad4[0] = t.v3[1], a.pad4[1] = t.v3[2];
         for (int k = 0; k < 3; ++k) {
             const float v2 = t.v2[k], v3 = t.v3[k];
@@ -953,6 +987,8 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     // Stage the blob in LDS when three workgroups per CU (the kernel's register-limited residency)
     // still fit into the CU's 160 KiB together with their traversal stacks.
     c->lds_scene = size_t(d.hot_bytes) + size_t(c->stack_entries) * 1024u + BinnedLds::kFixedBytes <= kLdsSceneLimit;
+    c->scene_tree = own_trees ? c->tree_mode : HIPRZ_TREE_REFERENCE;
+    if (own_trees) c->lds_scene = false;  // rebuilt trees are walked front to back on skip links only (ties by reference position)
     c->have_scene = true;
     resolve_pipeline(c);
     c->reset_pending = true;  // world changed => accumulation restarts (cpu_engine_renderer.cpp:108-112)
@@ -1033,6 +1069,13 @@ int hiprz_set_mode(hiprz_ctx* c, uint32_t compat_flags) {
         c->reset_pending = true;  // another integrator: what has been accumulated does not mix with it
         resolve_pipeline(c);
     }
+    return HIPRZ_OK;
+}
+
+int hiprz_set_tree(hiprz_ctx* c, uint32_t tree) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (tree > HIPRZ_TREE_SAH) return fail(c, HIPRZ_ERR_INVALID, "set_tree: HIPRZ_TREE_REFERENCE or HIPRZ_TREE_SAH");
+    c->tree_mode = tree;
     return HIPRZ_OK;
 }
 

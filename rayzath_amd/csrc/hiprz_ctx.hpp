@@ -134,6 +134,8 @@ struct hiprz_ctx {
     uint32_t passes = 0;
     uint64_t ray_count = 0;
     int traversal_mode = -1;  // -1 = choose per scene (effective_mode)
+    uint32_t tree_mode = 0;   // HIPRZ_TREE_* (hiprz_set_tree), applied by hiprz_upload_scene
+    uint32_t scene_tree = 0;  // ... of the scene that is uploaded now
     uint32_t mode_flags = 0;  // HIPRZ_COMPAT_* (hiprz_set_mode): non-zero routes every pass through rz_compat_pass_kernel
 
     // hipGraph of one batch of cumulative passes ([pass kernel, pass update] x n): replayed while nothing that

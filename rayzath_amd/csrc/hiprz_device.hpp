@@ -974,8 +974,10 @@ RZ_DEV f4 F4(float x, float y, float z, float w) { return f4{x, y, z, w}; }
 struct CoopLds {  // LDS-qualified pointers: ds_read / ds_write, not flat accesses
     RZ_LDS f4* rec;       // [3][128] by entry: (o.xyz, near), (d.xyz, far), bits(first triangle, count <= 4, held triangle + 1 or 0, -)
     RZ_LDS f4* res;       // [128]    by entry: bits(t) or ~0 = no hit, bits(triangle | external << 31), b1, b2
-    static constexpr uint32_t kEntries = 128u, kBytes = 4u * kEntries * 16u;
-    RZ_DEV explicit CoopLds(unsigned char* base) : rec((RZ_LDS f4*)base), res((RZ_LDS f4*)(base + 3u * kEntries * 16u)) {}
+    RZ_LDS uint32_t* ref; // [128]    by entry: the winner's position in the reference's leaf order
+    static constexpr uint32_t kEntries = 128u, kBytes = 4u * kEntries * 16u + kEntries * 4u;
+    RZ_DEV explicit CoopLds(unsigned char* base)
+        : rec((RZ_LDS f4*)base), res((RZ_LDS f4*)(base + 3u * kEntries * 16u)), ref((RZ_LDS uint32_t*)(base + 4u * kEntries * 16u)) {}
 };
 // Hand-over points of the cooperative phase: the LDS unit executes a wave's instructions in issue order, so a fence that keeps the
 // compiler from moving LDS accesses across it is all one wave needs (the workgroup IS one wave).
@@ -1007,12 +1009,12 @@ RZ_DEV CoopDeal coop_deal(bool holding, uint32_t c) {
 // One cooperative triangle step for the closest-hit walk.  Every lane calls it; `holding` lanes own a leaf [tj, tj + c), c <= 8.
 template <bool COUNT>
 RZ_DEV void coop_closest_triangles(const DScene& s, const CoopLds& lds, bool holding, uint32_t c, v3 lr_o, v3 lr_d, float lr_near, uint32_t tj,
-                                   bool& found, Hit& hit, float& far_, Counters& cnt) {
+                                   bool& found, uint32_t& held_ref, Hit& hit, float& far_, Counters& cnt) {
     const uint32_t lane = lane_id();
     const CoopDeal deal = coop_deal(holding, c);
     if (holding) {
         const f4 r0 = F4(lr_o.x, lr_o.y, lr_o.z, lr_near), r1 = F4(lr_d.x, lr_d.y, lr_d.z, far_);
-        const uint32_t held = found ? hit.triangle + 1u : 0u;
+        const uint32_t held = found ? held_ref + 1u : 0u;  // triangles are ranked by their position in the REFERENCE's leaf order
         lds.rec[deal.pos] = r0, lds.rec[CoopLds::kEntries + deal.pos] = r1;
         lds.rec[2u * CoopLds::kEntries + deal.pos] = F4(__uint_as_float(tj), __uint_as_float(c < 4u ? c : 4u), __uint_as_float(held), 0.0f);
         lds.res[deal.pos] = F4(__uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f, 0.0f);
@@ -1025,7 +1027,7 @@ RZ_DEV void coop_closest_triangles(const DScene& s, const CoopLds& lds, bool hol
     rz_wave_sync();
     for (uint32_t base = 0u; base < deal.n_entries * 4u; base += 64u) {  // wave-uniform
         const uint32_t e = (base + lane) >> 2, j = lane & 3u;
-        uint32_t tbits = 0xFFFFFFFFu, tri = 0u;
+        uint32_t tbits = 0xFFFFFFFFu, tri = 0u, refpos = 0xFFFFFFFFu;
         float b1 = 0.0f, b2 = 0.0f, det = 0.0f;
         if (e < deal.n_entries) {
             const f4 r2 = lds.rec[2u * CoopLds::kEntries + e];
@@ -1038,26 +1040,32 @@ RZ_DEV void coop_closest_triangles(const DScene& s, const CoopLds& lds, bool hol
                 float t;
                 RZ_PHASE(4);
                 RZ_COUNT(tri_tests);
-                // a hit at exactly the held distance replaces the held one when the reference would have met it first: lower index
-                if (tri_hit_ordered(xyz(a), xyz(b), xyz(cc), hr, tri + 1u < __float_as_uint(r2.z), t, b1, b2, det)) tbits = __float_as_uint(t);
+                refpos = __float_as_uint(cc.w);
+                // a hit at exactly the held distance replaces the held one when the reference would have met it first: lower position
+                if (tri_hit_ordered(xyz(a), xyz(b), xyz(cc), hr, refpos + 1u < __float_as_uint(r2.z), t, b1, b2, det)) tbits = __float_as_uint(t);
             }
         }
         const uint32_t tmin = quad_min(tbits);
         const bool candidate = tbits != 0xFFFFFFFFu && tbits == tmin;
-        const unsigned long long winners = __ballot(candidate);
-        const uint32_t mine = uint32_t(winners >> (lane & 60u)) & 0xFu;   // the candidates of this lane's quad
-        if (candidate && (mine & ((1u << j) - 1u)) == 0u)                  // the lowest lane = the lowest triangle index
+        const uint32_t first = quad_min(candidate ? refpos : 0xFFFFFFFFu);  // among equal distances: the one the reference meets first
+        if (candidate && refpos == first) {
             lds.res[e] = F4(__uint_as_float(tbits), __uint_as_float(tri | (det > 0.0f ? 0x80000000u : 0u)), b1, b2);
+            lds.ref[e] = refpos;
+        }
     }
     rz_wave_sync();
     if (holding) {
         f4 best = lds.res[deal.pos];
-        if (deal.big) {  // the second entry holds the higher triangle indices: it wins only with a strictly smaller t
+        uint32_t best_ref = lds.ref[deal.pos];
+        if (deal.big) {
             const f4 other = lds.res[deal.pos + 1u];
-            if (__float_as_uint(other.x) < __float_as_uint(best.x)) best = other;
+            const uint32_t other_ref = lds.ref[deal.pos + 1u];
+            if (__float_as_uint(other.x) < __float_as_uint(best.x) || (__float_as_uint(other.x) == __float_as_uint(best.x) && __float_as_uint(other.x) != 0xFFFFFFFFu && other_ref < best_ref))
+                best = other, best_ref = other_ref;
         }
         if (__float_as_uint(best.x) != 0xFFFFFFFFu) {
             far_ = best.x;
+            held_ref = best_ref;
             hit.triangle = __float_as_uint(best.y) & 0x7FFFFFFFu;
             hit.external = (__float_as_uint(best.y) & 0x80000000u) != 0u;
             hit.bx = best.z, hit.by = best.w;
@@ -1110,6 +1118,7 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
             lr.o = lr.d = lr.y = V3(0.0f, 0.0f, 0.0f), lr.near_ = lr.far_ = 0.0f, lr.fast = true;
             float len = 1.0f;
             bool found = false;
+            uint32_t held_ref = 0u;  // reference position of the held hit of THIS mesh
             uint32_t m = RZ_END, oct = 0u;
             if (enter) {
                 RZ_PHASE(2);
@@ -1142,7 +1151,7 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
                 if (!__any(tj != tj_end)) continue;
                 // triangle phase, all 64 lanes
                 const uint32_t c = tj_end - tj < lmax ? tj_end - tj : lmax;
-                coop_closest_triangles<COUNT>(s, lds, c != 0u, c, lr.o, lr.d, lr.near_, tj, found, hit, lr.far_, cnt);
+                coop_closest_triangles<COUNT>(s, lds, c != 0u, c, lr.o, lr.d, lr.near_, tj, found, held_ref, hit, lr.far_, cnt);
                 tj += c;
             }
             if (found) {

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -349,3 +350,229 @@ void hiprz_abi_sizes(uint32_t out[13]) {
 const char* hiprz_version(void) { return "hiprz 0.1 (gfx950)"; }
 
 }  // extern "C"
+
+// =======================================================================================
+// Opt-in mesh trees of better quality (hiprz_set_tree).  The reference's builder splits at the median centroid of
+// the axis of largest variance (bvh_tree_node.hpp:117-215); a surface-area-heuristic tree visits fewer boxes for the same hits.  The
+// tree only decides which boxes and triangles a ray meets, never what it hits, so frames stay the same — as long as ties between
+// equally distant triangles are resolved as the reference's visiting order would: every triangle keeps its position in the
+// reference's leaf order ("refpos") and the walks compare (t, refpos).
+// =======================================================================================
+namespace hiprz_trees {
+
+struct SahBuilder {
+    static constexpr int kBins = 16;
+    // measured on config D (trace kernel, us): leaf 4 / cost 1.2: 1 018; 8 / 2: 959; 8 / 4: 932; 8 / 8: 931; 16 / 4: 945; 16 / 8: 1 009; the
+    // reference trees: 1 022.  A node step runs at ~20 of 64 lanes, a triangle test in the cooperative phase at ~50, hence the high cost.
+    uint32_t kMaxLeaf = 8;     // two quad entries of the cooperative triangle phase
+    float kTraversal = 4.0f;   // cost of a node step relative to a triangle test
+    const hiprz_tri* tris;                      // the mesh's triangles (global array), vertices v1 v2 v3
+    std::vector<Box> bounds;
+    std::vector<float> cx, cy, cz;
+    std::vector<uint32_t> idx;                  // local triangle ids, permuted in place
+    std::vector<hiprz_node>& nodes;
+    uint32_t tri_base;                          // where this mesh's leaves start in the NEW triangle order
+
+    SahBuilder(const hiprz_tri* t, uint32_t n, std::vector<hiprz_node>& out, uint32_t base) : tris(t), nodes(out), tri_base(base) {
+        if (const char* e = std::getenv("HIPRZ_SAH_LEAF")) kMaxLeaf = uint32_t(std::atoi(e));
+        if (const char* e = std::getenv("HIPRZ_SAH_TRAV")) kTraversal = float(std::atof(e));
+        bounds.resize(n), cx.resize(n), cy.resize(n), cz.resize(n), idx.resize(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            Box b = box_of(t[i].v1, t[i].v2);
+            grow(b, t[i].v3);
+            bounds[i] = b;
+            cx[i] = centroid(b, 0), cy[i] = centroid(b, 1), cz[i] = centroid(b, 2);
+            idx[i] = i;
+        }
+    }
+    static float area(const Box& b) {
+        const float dx = b.mx[0] - b.mn[0], dy = b.mx[1] - b.mn[1], dz = b.mx[2] - b.mn[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+    const std::vector<float>& axis(int a) const { return a == 0 ? cx : a == 1 ? cy : cz; }
+
+    // returns the index of the mesh's root in `nodes`
+    uint32_t build() {
+        struct Item {
+            uint32_t node, first, count, depth;
+        };
+        const uint32_t root = uint32_t(nodes.size());
+        nodes.push_back(hiprz_node{});
+        std::vector<Item> stack{{root, 0u, uint32_t(idx.size()), 1u}};
+        while (!stack.empty()) {
+            const Item it = stack.back();
+            stack.pop_back();
+            Box box = bounds[idx[it.first]], cbox;
+            for (int a = 0; a < 3; ++a) cbox.mn[a] = cbox.mx[a] = axis(a)[idx[it.first]];
+            for (uint32_t k = 1; k < it.count; ++k) {
+                const uint32_t t = idx[it.first + k];
+                grow(box, bounds[t]);
+                const float c[3] = {cx[t], cy[t], cz[t]};
+                grow(cbox, c);
+            }
+            hiprz_node& node = nodes[it.node];
+            std::memcpy(node.bb_min, box.mn, 12), std::memcpy(node.bb_max, box.mx, 12);
+            auto make_leaf = [&]() {
+                std::sort(idx.begin() + it.first, idx.begin() + it.first + it.count);  // ascending refpos inside a leaf
+                nodes[it.node].begin = tri_base + it.first;
+                nodes[it.node].meta = HIPRZ_NODE_LEAF | it.count;
+            };
+            if (it.count <= 2u || it.depth >= 60u) {
+                make_leaf();
+                continue;
+            }
+            // binned SAH over the three axes
+            float best_cost = 3.4e38f;
+            int best_axis = -1, best_plane = 0;
+            for (int a = 0; a < 3; ++a) {
+                const float lo = cbox.mn[a], extent = cbox.mx[a] - cbox.mn[a];
+                if (!(extent > 0.0f)) continue;
+                const float scale = float(kBins) / extent;
+                Box bin_box[kBins];
+                uint32_t bin_count[kBins] = {0};
+                const std::vector<float>& c = axis(a);
+                for (uint32_t k = 0; k < it.count; ++k) {
+                    const uint32_t t = idx[it.first + k];
+                    int b = int((c[t] - lo) * scale);
+                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                    if (bin_count[b]++ == 0) bin_box[b] = bounds[t];
+                    else grow(bin_box[b], bounds[t]);
+                }
+                float right_area[kBins];
+                uint32_t right_count[kBins];
+                Box acc{};
+                uint32_t n = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    if (bin_count[b]) {
+                        if (n == 0) acc = bin_box[b];
+                        else grow(acc, bin_box[b]);
+                        n += bin_count[b];
+                    }
+                    right_area[b] = n ? area(acc) : 0.0f, right_count[b] = n;
+                }
+                n = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    if (bin_count[b]) {
+                        if (n == 0) acc = bin_box[b];
+                        else grow(acc, bin_box[b]);
+                        n += bin_count[b];
+                    }
+                    if (n == 0 || right_count[b + 1] == 0) continue;
+                    const float cost = area(acc) * float(n) + right_area[b + 1] * float(right_count[b + 1]);
+                    if (cost < best_cost) best_cost = cost, best_axis = a, best_plane = b + 1;
+                }
+            }
+            const float node_area = area(box);
+            const float split_cost = best_axis >= 0 && node_area > 0.0f ? kTraversal + best_cost / node_area : 3.4e38f;
+            if (it.count <= kMaxLeaf && float(it.count) <= split_cost) {
+                make_leaf();
+                continue;
+            }
+            uint32_t mid;
+            int split_axis = best_axis;
+            if (best_axis >= 0 && (it.count > kMaxLeaf || split_cost < float(it.count))) {
+                const float lo = cbox.mn[best_axis], scale = float(kBins) / (cbox.mx[best_axis] - cbox.mn[best_axis]);
+                const std::vector<float>& c = axis(best_axis);
+                auto first = idx.begin() + it.first;
+                mid = uint32_t(std::partition(first, first + it.count, [&](uint32_t t) {
+                          int b = int((c[t] - lo) * scale);
+                          b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                          return b < best_plane;
+                      }) - first);
+            } else {  // every centroid in one spot (or no plane separates): halve along the widest axis of the box
+                split_axis = 0;
+                for (int a = 1; a < 3; ++a)
+                    if (box.mx[a] - box.mn[a] > box.mx[split_axis] - box.mn[split_axis]) split_axis = a;
+                const std::vector<float>& c = axis(split_axis);
+                auto first = idx.begin() + it.first;
+                std::nth_element(first, first + it.count / 2, first + it.count, [&](uint32_t x, uint32_t y) { return c[x] < c[y] || (c[x] == c[y] && x < y); });
+                mid = it.count / 2;
+            }
+            if (mid == 0u || mid == it.count) {
+                make_leaf();
+                continue;
+            }
+            const uint32_t children = uint32_t(nodes.size());
+            nodes.push_back(hiprz_node{}), nodes.push_back(hiprz_node{});
+            // partition type of the node layout: X = 2, Y = 1, Z = 0 (bvh_tree_node.hpp:22-28); the first child holds the lower centroids
+            nodes[it.node].begin = children;
+            nodes[it.node].meta = uint32_t(2 - split_axis) << HIPRZ_NODE_PTYPE_SHIFT;
+            stack.push_back({children + 1u, it.first + mid, it.count - mid, it.depth + 1u});
+            stack.push_back({children, it.first, mid, it.depth + 1u});
+        }
+        return root;
+    }
+};
+
+}  // namespace hiprz_trees
+
+extern "C" int hiprz_rebuild_mesh_trees(const hiprz_scene* sc, uint32_t method, hiprz_node* nodes_out, uint32_t max_nodes, uint32_t* n_nodes_out,
+                                        uint32_t* tri_order_out, uint32_t* blas_roots_out, uint32_t* tlas_root_out) {
+    if (!sc || !nodes_out || !n_nodes_out || !tri_order_out || !blas_roots_out || !tlas_root_out || method != 1u) return HIPRZ_ERR_INVALID;
+    std::vector<hiprz_node> nodes;
+    // the world tree is copied as it is (breadth-first, children adjacent)
+    *tlas_root_out = 0u;
+    if (sc->n_instances && sc->n_tlas_order) {
+        if (sc->tlas_root >= sc->n_nodes) return HIPRZ_ERR_INVALID;
+        std::vector<uint32_t> queue{sc->tlas_root};
+        nodes.push_back(sc->nodes[sc->tlas_root]);
+        for (size_t q = 0; q < queue.size(); ++q) {
+            const hiprz_node old = sc->nodes[queue[q]];
+            if (old.meta & HIPRZ_NODE_LEAF) continue;
+            if (uint64_t(old.begin) + 1 >= sc->n_nodes || nodes.size() > size_t(2) * sc->n_nodes) return HIPRZ_ERR_INVALID;
+            nodes[q].begin = uint32_t(nodes.size());
+            queue.push_back(old.begin), queue.push_back(old.begin + 1u);
+            nodes.push_back(sc->nodes[old.begin]), nodes.push_back(sc->nodes[old.begin + 1u]);
+        }
+    }
+    // every distinct mesh: its triangle range from the leaves of its reference tree, then a new tree over that range
+    std::vector<uint32_t> new_root(sc->n_nodes, 0xFFFFFFFFu);
+    uint32_t tri_cursor = 0u;
+    std::vector<uint8_t> tri_seen(sc->n_tris, 0);
+    for (uint32_t i = 0; i < sc->n_instances; ++i) {
+        const uint32_t root = sc->instances[i].blas_root;
+        blas_roots_out[i] = root;
+        if (root >= sc->n_nodes) continue;  // an instance without mesh: never entered (left out of the world tree)
+        if (new_root[root] == 0xFFFFFFFFu) {
+            uint32_t lo = 0xFFFFFFFFu, total = 0u;
+            std::vector<uint32_t> walk{root};
+            size_t steps = 0;
+            while (!walk.empty()) {
+                if (++steps > size_t(sc->n_nodes) + 1u) return HIPRZ_ERR_INVALID;
+                const hiprz_node n = sc->nodes[walk.back()];
+                walk.pop_back();
+                if (n.meta & HIPRZ_NODE_LEAF) {
+                    const uint32_t count = n.meta & HIPRZ_NODE_COUNT_MASK;
+                    if (uint64_t(n.begin) + count > sc->n_tris) return HIPRZ_ERR_INVALID;
+                    if (count) lo = std::min(lo, n.begin), total += count;
+                } else {
+                    if (uint64_t(n.begin) + 1 >= sc->n_nodes) return HIPRZ_ERR_INVALID;
+                    walk.push_back(n.begin), walk.push_back(n.begin + 1u);
+                }
+            }
+            if (total == 0u) {
+                new_root[root] = uint32_t(nodes.size());
+                hiprz_node leaf = sc->nodes[root];
+                leaf.begin = 0u, leaf.meta = HIPRZ_NODE_LEAF;
+                nodes.push_back(leaf);
+            } else {
+                if (uint64_t(lo) + total > sc->n_tris) return HIPRZ_ERR_INVALID;
+                for (uint32_t t = lo; t < lo + total; ++t) {
+                    if (tri_seen[t]) return HIPRZ_ERR_INVALID;  // the leaves of a mesh must tile one contiguous range
+                    tri_seen[t] = 1;
+                }
+                hiprz_trees::SahBuilder builder(sc->tris + lo, total, nodes, tri_cursor);
+                new_root[root] = builder.build();
+                for (uint32_t k = 0; k < total; ++k) tri_order_out[tri_cursor + k] = lo + builder.idx[k];
+                tri_cursor += total;
+            }
+        }
+        blas_roots_out[i] = new_root[root];
+    }
+    for (uint32_t t = 0; t < sc->n_tris; ++t)  // triangles no instance reaches keep a slot behind the others
+        if (!tri_seen[t]) tri_order_out[tri_cursor++] = t;
+    if (nodes.size() > max_nodes) return HIPRZ_ERR_INVALID;
+    std::memcpy(nodes_out, nodes.data(), nodes.size() * sizeof(hiprz_node));
+    *n_nodes_out = uint32_t(nodes.size());
+    return HIPRZ_OK;
+}

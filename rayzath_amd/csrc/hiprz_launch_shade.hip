@@ -28,7 +28,7 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
         launch_sort(c);
         if (f.shadow_key) launch_shadow_sort(c);
         const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
-        if (COUNT ? c->walk_order == 2 : c->walk_order != 0) {
+        if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) || c->scene_tree != HIPRZ_TREE_REFERENCE) {
             hipLaunchKernelGGL((rz_shadow_coop_kernel<FIRST, COUNT, 4>), sgrid, sblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
         } else {
             const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;

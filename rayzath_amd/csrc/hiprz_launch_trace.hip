@@ -13,7 +13,7 @@ void launch_trace_t(hiprz_ctx* c, const DFrame& f) {
     if (g.mode == 3) {
         // one wave per workgroup: a workgroup's slot is free as soon as ITS slowest ray is done
         const dim3 grid(c->n_local_tiles * 4u), block(64);
-        if (COUNT ? c->walk_order == 2 : c->walk_order != 0) {
+        if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) || c->scene_tree != HIPRZ_TREE_REFERENCE) {
             // front-to-back mesh walks on per-octant skip links with the cooperative triangle phase; 4 waves per SIMD for every
             // tree size (D: 1 037 us against 1 131 us with 6 waves)
             if (c->trace_waves >= 6) hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 6>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);

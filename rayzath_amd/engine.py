@@ -90,6 +90,10 @@ class Context:
         """0 = the CPU kernel (default, parity-checked); COMPAT_* flags add behaviours of the reference's CUDA engine (include/hiprz.h)."""
         self._check(self.lib.hiprz_set_mode(self._ctx, compat_flags))
 
+    def set_tree(self, tree):
+        """0 = the uploaded (reference) mesh trees, 1 = rebuilt with a binned SAH at the next upload_scene (same frames, fewer tests)."""
+        self._check(self.lib.hiprz_set_tree(self._ctx, tree))
+
     def set_pipeline(self, pipeline):
         self._check(self.lib.hiprz_set_pipeline(self._ctx, pipeline))
 
