@@ -252,6 +252,13 @@ typedef struct hiprz_ctx hiprz_ctx;
 
 /* --- lifecycle (replaces Cuda::Engine ctor/dtor, RayZath/cuda_engine.cu:8-21) --- */
 int hiprz_create(hiprz_ctx** out, int device_id);
+/* One context over several GPUs of a node (replaces the device selection of Cuda::EngineCore, cuda_engine_core.cu:17, which is pinned
+ * to device 0): device r of n renders the interleaved tiles t with t % n == r (hiprz_set_shard then splits the context's share once
+ * more), the scene is mirrored to every device, and hiprz_read_* / hiprz_pick / hiprz_ray_count return the whole frame — the peers'
+ * tiles cross xGMI in peer-to-peer copies on the head's stream.  Global pixel ids and seeds are unchanged: the frame equals the
+ * single-device frame bit for bit.  The same id may be listed more than once (several shards on one GPU). */
+int hiprz_create_multi(hiprz_ctx** out, const int* device_ids, int n_devices);
+int hiprz_device_count(hiprz_ctx* ctx, uint32_t* out);
 int hiprz_destroy(hiprz_ctx* ctx);
 /* message of the last non-OK return on this context (ctx may be NULL for create failures) */
 const char* hiprz_last_error(const hiprz_ctx* ctx);
@@ -267,7 +274,19 @@ void hiprz_abi_sizes(uint32_t out[13]);
 /* --- host→device mirroring (replaces Cuda::World::reconstruct*, cuda_world.cu:28-57) --- */
 int hiprz_upload_scene(hiprz_ctx* ctx, const hiprz_scene* scene);   /* validates, copies; caller keeps ownership */
 int hiprz_upload_camera(hiprz_ctx* ctx, const hiprz_camera* camera); /* (re)allocates per-pixel state on resize */
+/* Materials and lights changed, geometry did not (the reference tracks modifications per container, updatable.cpp:23-51, and the
+ * CUDA backend re-mirrors only what changed, cuda_world.cu:28-57): replaces those records of the uploaded scene in place — no tree is
+ * rebuilt or re-derived.  n_materials must equal the uploaded scene's; light counts may differ.  Restarts accumulation. */
+int hiprz_update_shading(hiprz_ctx* ctx, const hiprz_material* materials, uint32_t n_materials, const hiprz_spot_light* spot_lights,
+                         uint32_t n_spot_lights, const hiprz_direct_light* direct_lights, uint32_t n_direct_lights);
 int hiprz_set_config(hiprz_ctx* ctx, const hiprz_config* config);
+/* Cameras.  The reference renders every enabled camera of the world per call, each with its own accumulation state
+ * (cpu_engine_renderer.cpp:97-117, CameraContext).  A context keeps one frame state per camera: hiprz_set_camera_count(n), then
+ * hiprz_select_camera(k) decides which camera hiprz_upload_camera / hiprz_reset / hiprz_render* / hiprz_tonemap / hiprz_read_* /
+ * hiprz_pick / hiprz_ray_count / hiprz_pass_count address.  Scene, config and every setting are shared.  Default: one camera. */
+int hiprz_set_camera_count(hiprz_ctx* ctx, uint32_t n);
+int hiprz_camera_count(hiprz_ctx* ctx, uint32_t* out);
+int hiprz_select_camera(hiprz_ctx* ctx, uint32_t index);
 /* Own only the 32x8-pixel tiles t with t % world == rank (global pixel ids and seeds are
  * unchanged, so results are identical for any world size).  Default rank 0 of 1. */
 int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);

@@ -27,7 +27,10 @@ typedef struct hiprz_scene_file hiprz_scene_file;
 int hiprz_scene_file_load(const char* path, hiprz_scene_file** out);
 void hiprz_scene_file_free(hiprz_scene_file* file);
 const hiprz_scene* hiprz_scene_file_scene(const hiprz_scene_file* file);   /* valid until hiprz_scene_file_free */
-const hiprz_camera* hiprz_scene_file_camera(const hiprz_scene_file* file);
+const hiprz_camera* hiprz_scene_file_camera(const hiprz_scene_file* file);  /* the first enabled camera (default camera if none) */
+/* every ENABLED camera of the file, in file order: the reference renders all of them per call (cpu_engine_renderer.cpp:97-117) */
+uint32_t hiprz_scene_file_camera_count(const hiprz_scene_file* file);
+int hiprz_scene_file_camera_at(const hiprz_scene_file* file, uint32_t index, hiprz_camera* out);
 /* "[message] ...\n[warning] ...\n[error] ...\n" in the reference's LoadResult order */
 const char* hiprz_scene_file_log(const hiprz_scene_file* file);
 uint32_t hiprz_scene_file_error_count(const hiprz_scene_file* file);

@@ -111,6 +111,12 @@ ENTRY_POINTS = {
     "hiprz_set_traversal_mode": (C.c_int, [P, C.c_int]),
     "hiprz_set_walk_order": (C.c_int, [P, C.c_int]),
     "hiprz_set_mode": (C.c_int, [P, U32]),
+    "hiprz_create_multi": (C.c_int, [C.POINTER(P), C.POINTER(C.c_int), C.c_int]),
+    "hiprz_device_count": (C.c_int, [P, C.POINTER(U32)]),
+    "hiprz_set_camera_count": (C.c_int, [P, U32]),
+    "hiprz_camera_count": (C.c_int, [P, C.POINTER(U32)]),
+    "hiprz_select_camera": (C.c_int, [P, U32]),
+    "hiprz_update_shading": (C.c_int, [P, P, U32, P, U32, P, U32]),
     "hiprz_set_tree": (C.c_int, [P, U32]),
     "hiprz_rebuild_mesh_trees": (C.c_int, [C.POINTER(Scene), U32, P, U32, C.POINTER(U32), P, P, C.POINTER(U32)]),
     "hiprz_set_lds_scene": (C.c_int, [P, C.c_int]),

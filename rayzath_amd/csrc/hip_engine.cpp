@@ -69,6 +69,61 @@ void normalize3(float* v) {
 }
 }  // namespace
 
+namespace {
+// Transformation (render_parts.hpp:39-69) of an instance, composed through its groups as Transformation::operator*= does
+// (render_parts.cpp:75-82): position rotated by the group's axes and moved by its position, axes rotated, scales multiplied.
+struct Xform {
+    float p[3], s[3], x[3], y[3], z[3];
+};
+void forward(const Xform& g, float* v) {  // CoordSystem::transformForward: x_axis * v.x + y_axis * v.y + z_axis * v.z
+    const float a = v[0], b = v[1], c = v[2];
+    for (int k = 0; k < 3; ++k) v[k] = (g.x[k] * a + g.y[k] * b) + g.z[k] * c;
+}
+Xform own_transform(const vec3f& position, const vec3f& rotation, const vec3f& scale) {
+    Xform t;
+    put3(t.p, position), put3(t.s, scale);
+    float rot[3];
+    put3(rot, rotation);
+    hiprz_axes_from_rotation(rot, t.x, t.y, t.z);
+    return t;
+}
+Xform in_group(const Instance& inst) {  // Instance::calculateBoundingBox, instance.cpp:125-133
+    Xform t = own_transform(inst.position, inst.rotation, inst.scale);
+    for (const Group* g = inst.group.get(); g; g = g->group.get()) {
+        const Xform gt = own_transform(g->position, g->rotation, g->scale);
+        forward(gt, t.p);
+        for (int k = 0; k < 3; ++k) t.p[k] += gt.p[k];
+        forward(gt, t.x), forward(gt, t.y), forward(gt, t.z);
+        for (int k = 0; k < 3; ++k) t.s[k] *= gt.s[k];
+    }
+    return t;
+}
+void store(hiprz_instance& r, const Xform& t) {
+    std::memcpy(r.position, t.p, 12), std::memcpy(r.scale, t.s, 12);
+    std::memcpy(r.x_axis, t.x, 12), std::memcpy(r.y_axis, t.y, 12), std::memcpy(r.z_axis, t.z, 12);
+}
+void flatten_lights(const World& world, FlatScene& f) {
+    for (const auto& l : world.spot_lights) {
+        hiprz_spot_light r{};
+        put3(r.position, l->position), put3(r.direction, l->direction);
+        normalize3(r.direction);
+        r.size = std::max(l->size, std::numeric_limits<float>::min()), r.emission = std::max(l->emission, 0.0f);
+        r.color[0] = l->color.red, r.color[1] = l->color.green, r.color[2] = l->color.blue, r.color[3] = l->color.alpha;
+        r.angle = std::min(std::max(l->beam_angle, 0.0f), 3.14159f), r.cos_angle = std::cos(r.angle);
+        f.spot_lights.push_back(r);
+    }
+    for (const auto& l : world.direct_lights) {
+        hiprz_direct_light r{};
+        put3(r.direction, l->direction);
+        normalize3(r.direction);
+        r.emission = std::max(l->emission, 0.0f);
+        r.color[0] = l->color.red, r.color[1] = l->color.green, r.color[2] = l->color.blue, r.color[3] = l->color.alpha;
+        r.angular_size = std::min(std::max(l->angular_size, 0.0f), 3.14159265358979f), r.cos_angular_size = std::cos(r.angular_size);
+        f.direct_lights.push_back(r);
+    }
+}
+}  // namespace
+
 FlatScene flatten(const World& world) {
     FlatScene f;
     std::map<const TextureBuffer*, int32_t> tex_index;
@@ -134,10 +189,8 @@ FlatScene flatten(const World& world) {
     std::vector<uint8_t> has_mesh;
     for (const auto& inst : world.instances) {
         hiprz_instance r{};
-        put3(r.position, inst->position), put3(r.scale, inst->scale);
-        float rot[3];
-        put3(rot, inst->rotation);
-        hiprz_axes_from_rotation(rot, r.x_axis, r.y_axis, r.z_axis);
+        const Xform own = own_transform(inst->position, inst->rotation, inst->scale), grouped = in_group(*inst);
+        store(r, grouped);  // the bounding box always comes from the composed transformation (instance.cpp:125-155)
         r.material_base = uint32_t(f.inst_materials.size());
         uint32_t count = 0;
         for (uint32_t k = 0; k < Instance::materialCapacity(); ++k)
@@ -149,6 +202,7 @@ FlatScene flatten(const World& world) {
             f.inst_materials.push_back(m ? mat_index[m.get()] : -1);
         }
         if (inst->mesh) hiprz_instance_bounds(inst->mesh->vertices.data(), uint32_t(inst->mesh->vertices.size() / 3), &r);
+        if (world.group_transforms == World::GroupTransforms::Cpu) store(r, own);  // ... but the CPU kernel takes rays into the instance's OWN one (cpu_engine_kernel.cpp:308)
         has_mesh.push_back(inst->mesh ? 1 : 0);
         f.instances.push_back(r);
     }
@@ -176,24 +230,34 @@ FlatScene flatten(const World& world) {
     for (size_t i = 0; i < world.instances.size(); ++i)
         if (world.instances[i]->mesh) f.instances[i].blas_root = roots[mesh_slot[world.instances[i]->mesh.get()]];
 
-    for (const auto& l : world.spot_lights) {
-        hiprz_spot_light r{};
-        put3(r.position, l->position), put3(r.direction, l->direction);
-        normalize3(r.direction);
-        r.size = std::max(l->size, std::numeric_limits<float>::min()), r.emission = std::max(l->emission, 0.0f);
-        r.color[0] = l->color.red, r.color[1] = l->color.green, r.color[2] = l->color.blue, r.color[3] = l->color.alpha;
-        r.angle = std::min(std::max(l->beam_angle, 0.0f), 3.14159f), r.cos_angle = std::cos(r.angle);
-        f.spot_lights.push_back(r);
-    }
-    for (const auto& l : world.direct_lights) {
-        hiprz_direct_light r{};
-        put3(r.direction, l->direction);
-        normalize3(r.direction);
-        r.emission = std::max(l->emission, 0.0f);
-        r.color[0] = l->color.red, r.color[1] = l->color.green, r.color[2] = l->color.blue, r.color[3] = l->color.alpha;
-        r.angular_size = std::min(std::max(l->angular_size, 0.0f), 3.14159265358979f), r.cos_angular_size = std::cos(r.angular_size);
-        f.direct_lights.push_back(r);
-    }
+    flatten_lights(world, f);
+    return f;
+}
+
+FlatScene flattenShading(const World& world) {
+    // the map indices must be those of the uploaded scene: textures are numbered in first-use order over world material, default
+    // material and the world's materials — exactly what flatten() does, so the numbering is replayed without copying any texels
+    FlatScene f;
+    std::map<const TextureBuffer*, int32_t> tex_index;
+    auto tex_id = [&](const std::shared_ptr<TextureBuffer>& t) -> int32_t {
+        if (!t) return -1;
+        auto it = tex_index.find(t.get());
+        if (it != tex_index.end()) return it->second;
+        const int32_t id = int32_t(tex_index.size());
+        return tex_index[t.get()] = id;
+    };
+    auto add_material = [&](const Material& m) {
+        hiprz_material r{};
+        r.color[0] = m.color.red, r.color[1] = m.color.green, r.color[2] = m.color.blue, r.color[3] = m.color.alpha;
+        r.metalness = m.metalness(), r.roughness = m.roughness(), r.emission = m.emission(), r.ior = m.ior(), r.scattering = m.scattering();
+        r.texture = tex_id(m.texture), r.normal_map = tex_id(m.normal_map), r.metalness_map = tex_id(m.metalness_map);
+        r.roughness_map = tex_id(m.roughness_map), r.emission_map = tex_id(m.emission_map);
+        f.materials.push_back(r);
+    };
+    add_material(world.material);
+    add_material(world.default_material);
+    for (const auto& m : world.materials) add_material(*m);
+    flatten_lights(world, f);
     return f;
 }
 
@@ -221,10 +285,23 @@ Engine::Engine(int device) {
     const int rc = hiprz_create(&m_ctx, device);
     if (rc != HIPRZ_OK) throw Exception(rc, std::string("HIPGPU backend unavailable: ") + hiprz_last_error(nullptr));
 }
+Engine::Engine(const std::vector<int>& devices) {
+    const int rc = hiprz_create_multi(&m_ctx, devices.data(), int(devices.size()));
+    if (rc != HIPRZ_OK) throw Exception(rc, std::string("HIPGPU backend unavailable: ") + hiprz_last_error(nullptr));
+}
 Engine::~Engine() { hiprz_destroy(m_ctx); }
 
 void Engine::check(int rc) {
     if (rc != HIPRZ_OK) throw Exception(rc, hiprz_last_error(m_ctx));
+}
+void Engine::mode(uint32_t compat_flags) {
+    std::lock_guard<std::mutex> lock(m_mutex);
+    check(hiprz_set_mode(m_ctx, compat_flags));
+}
+void Engine::tree(uint32_t tree) {
+    std::lock_guard<std::mutex> lock(m_mutex);
+    check(hiprz_set_tree(m_ctx, tree));
+    m_last_world = nullptr;  // takes effect at the next scene upload: force one
 }
 
 void Engine::readback(Camera& camera) {
@@ -236,6 +313,14 @@ void Engine::readback(Camera& camera) {
     check(hiprz_ray_count(m_ctx, &camera.ray_count));
 }
 
+std::vector<Camera*> Engine::enabledCameras(World& world) const {  // cpu_engine_renderer.cpp:97-100: every enabled camera
+    std::vector<Camera*> out;
+    if (world.camera.enabled) out.push_back(&world.camera);
+    for (auto& c : world.cameras)
+        if (c && c->enabled) out.push_back(c.get());
+    return out;
+}
+
 void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, bool sync) {
     std::lock_guard<std::mutex> lock(m_mutex);
     if (m_deferred) {  // error of the previous, already returned, asynchronous frame
@@ -243,23 +328,28 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
         m_deferred.reset();
         throw e;
     }
-    if (m_pending_readback) {  // pipelined frame of the previous non-sync call
+    const std::vector<Camera*> cameras = enabledCameras(world);
+    if (m_pending_readback) {  // pipelined frames of the previous non-sync call
         m_pending_readback = false;
-        readback(world.camera);
+        for (size_t k = 0; k < m_camera_slots.size(); ++k)
+            for (Camera* cam : cameras)
+                if (cam == m_camera_slots[k]) {
+                    check(hiprz_select_camera(m_ctx, uint32_t(k)));
+                    readback(*cam);
+                }
     }
-    // re-mirror what changed; either change restarts accumulation (cpu_engine_renderer.cpp:108-112)
+    // re-mirror what changed; any change restarts accumulation (cpu_engine_renderer.cpp:108-112)
     if (world.isModified() || m_last_world != &world) {
         const FlatScene flat = flatten(world);
         const hiprz_scene view = flat.view();
         check(hiprz_upload_scene(m_ctx, &view));
-        world.makeUnmodified();
-        world.camera.makeModified();
+        world.makeUnmodified(), world.makeShadingUnmodified();
         m_last_world = &world;
-    }
-    if (world.camera.isModified()) {
-        const hiprz_camera cam = cameraRecord(world.camera);
-        check(hiprz_upload_camera(m_ctx, &cam));
-        world.camera.makeUnmodified();
+    } else if (world.isShadingModified()) {  // materials / lights only: replaced in place, no tree is touched
+        const FlatScene flat = flattenShading(world);
+        check(hiprz_update_shading(m_ctx, flat.materials.data(), uint32_t(flat.materials.size()), flat.spot_lights.data(), uint32_t(flat.spot_lights.size()),
+                                   flat.direct_lights.data(), uint32_t(flat.direct_lights.size())));
+        world.makeShadingUnmodified();
     }
     hiprz_config c{};
     c.max_depth = cfg.tracing.max_depth, c.rpp = cfg.tracing.rpp;
@@ -267,14 +357,29 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
     c.direct_samples = std::max<uint32_t>(cfg.light_sampling.direct_light, 1u);
     c.seed = cfg.seed;
     check(hiprz_set_config(m_ctx, &c));
-    check(hiprz_render(m_ctx, std::max(cfg.tracing.rpp, 1u)));
-    check(hiprz_tonemap(m_ctx));
-    if (sync) {
-        readback(world.camera);
-    } else {
-        m_pending_readback = true;
-        // nothing has been waited for: a device fault would surface at the next call's first hip* return
+    // one frame state per enabled camera, in the order the reference iterates them
+    bool slots_changed = m_camera_slots.size() != cameras.size();
+    for (size_t k = 0; !slots_changed && k < cameras.size(); ++k) slots_changed = m_camera_slots[k] != cameras[k];
+    if (slots_changed) {
+        check(hiprz_set_camera_count(m_ctx, uint32_t(std::max<size_t>(cameras.size(), 1))));
+        m_camera_slots.assign(cameras.begin(), cameras.end());
+        for (Camera* cam : cameras) cam->makeModified();
     }
+    for (size_t k = 0; k < cameras.size(); ++k) {
+        Camera& cam = *cameras[k];
+        check(hiprz_select_camera(m_ctx, uint32_t(k)));
+        if (cam.isModified()) {
+            const hiprz_camera rec = cameraRecord(cam);
+            check(hiprz_upload_camera(m_ctx, &rec));
+            cam.makeUnmodified();
+        }
+        check(hiprz_render(m_ctx, std::max(cfg.tracing.rpp, 1u)));
+        check(hiprz_tonemap(m_ctx));
+        if (sync) readback(cam);
+    }
+    // not sync: nothing has been waited for — the buffers are filled by the next call, and a device fault would surface at that
+    // call's first hip* return
+    if (!sync) m_pending_readback = true;
 }
 
 std::string Engine::timingsString() {

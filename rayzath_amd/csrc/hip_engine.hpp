@@ -26,10 +26,20 @@
 
 namespace RayZath::Hip {
 
-// RayZath::Exception : std::runtime_error (rzexception.hpp:11-18); Cuda::Exception's peer.
-struct Exception : public std::runtime_error {
+// Cuda::Exception's peer (cuda_exception.hpp:9-19).  Built inside RayZath (-DHIPRZ_RAYZATH_BUILD) it derives from the
+// facade's RayZath::Exception (rzexception.hpp:11-18), so the facade's `catch (RayZath::Exception&)` paths see it like a CUDA
+// backend error; stand-alone (that header drags in the un-vendored CUDA driver types) it derives from the same std::runtime_error.
+#ifdef HIPRZ_RAYZATH_BUILD
+}  // namespace RayZath::Hip
+#include "rzexception.hpp"
+namespace RayZath::Hip {
+using ExceptionBase = RayZath::Exception;
+#else
+using ExceptionBase = std::runtime_error;
+#endif
+struct Exception : public ExceptionBase {
     int code;
-    Exception(int code_, const std::string& message) : std::runtime_error(message), code(code_) {}
+    Exception(int code_, const std::string& message) : ExceptionBase(message), code(code_) {}
 };
 
 struct vec3f {
@@ -87,11 +97,17 @@ struct Mesh {  // mesh.hpp
     static std::shared_ptr<Mesh> generateCube();  // world.cpp:129-166
 };
 
+struct Group {  // group.hpp: a transformation over instances and sub-groups (groupable.hpp)
+    vec3f position, rotation, scale{1, 1, 1};
+    std::shared_ptr<Group> group;  // the group this one belongs to
+};
+
 struct Instance {  // instance.hpp:9-60
     static constexpr uint32_t materialCapacity() { return 64; }
     vec3f position, rotation, scale{1, 1, 1};
     std::shared_ptr<Mesh> mesh;
     std::array<std::shared_ptr<Material>, 64> materials;
+    std::shared_ptr<Group> group;  // Groupable::group()
 };
 
 struct SpotLight {  // spot_light.hpp
@@ -110,6 +126,7 @@ struct Camera : public Updatable {  // camera.hpp:127-161
     uint32_t width = 1280, height = 720;
     float fov = 1.57079632679f, near_plane = 1.0e-2f, far_plane = 1.0e3f;
     float focal_distance = 10.0f, aperture = 0.02f, exposure_time = 1.0f / 60.0f;
+    bool enabled = true;  // camera.hpp:150; disabled cameras are skipped by the renderers (cpu_engine_renderer.cpp:99)
     // outputs the backend writes (camera.hpp:50-56, 113-119)
     std::vector<uint8_t> image_buffer;  // RGBA8 W*H
     std::vector<float> depth_buffer;    // W*H
@@ -123,9 +140,23 @@ struct World : public Updatable {  // world.hpp:64-76
     std::vector<std::shared_ptr<Instance>> instances;
     std::vector<std::shared_ptr<SpotLight>> spot_lights;
     std::vector<std::shared_ptr<DirectLight>> direct_lights;
-    Camera camera;
+    Camera camera;                                  // the first camera ...
+    std::vector<std::shared_ptr<Camera>> cameras;   // ... and the others: every enabled one is rendered per call (cpu_engine_renderer.cpp:97-117)
+    std::vector<std::shared_ptr<Group>> groups;
     Material material;          // world / sky medium (world.cpp:33-38)
     Material default_material;  // world.cpp:39-43
+    // How an instance inside groups is mirrored.  Cpu (default): what the CPU engine does — the bounding box comes from the
+    // transformation composed through its groups (Instance::calculateBoundingBox, instance.cpp:125-155) while rays are taken into
+    // the instance's OWN transformation (cpu_engine_kernel.cpp:308); the two agree only outside groups.  Cuda: the composed
+    // transformation for both (cuda_instance.cu:244, transformationInGroup()).
+    enum class GroupTransforms { Cpu, Cuda } group_transforms = GroupTransforms::Cpu;
+    // materials / lights changed but no geometry: the engine replaces those records only (updatable.cpp:23-51 per container)
+    void makeShadingModified() { m_shading_modified = true; }
+    bool isShadingModified() const { return m_shading_modified; }
+    void makeShadingUnmodified() { m_shading_modified = false; }
+
+private:
+    bool m_shading_modified = false;
 };
 
 struct LightSampling {  // engine_parts.hpp:76-94
@@ -157,11 +188,15 @@ struct FlatScene {
     hiprz_scene view() const;
 };
 FlatScene flatten(const World& world);           // pure host
+FlatScene flattenShading(const World& world);    // materials + lights only (for hiprz_update_shading): pure host
 hiprz_camera cameraRecord(const Camera& camera); // pure host
 
 class Engine {
 public:
     explicit Engine(int device = 0);  // throws Hip::Exception: the facade then falls back to CPU (rayzath.cpp:21-28)
+    explicit Engine(const std::vector<int>& devices);  // one context over several GPUs: tiles interleaved, peer-to-peer gather
+    void mode(uint32_t compat_flags);  // hiprz_set_mode: behaviours of the CUDA engine (default 0 = the CPU kernel)
+    void tree(uint32_t tree);          // hiprz_set_tree, applied at the next scene upload
     ~Engine();
     Engine(const Engine&) = delete;
     Engine& operator=(const Engine&) = delete;
@@ -178,12 +213,14 @@ public:
 private:
     void check(int rc);
     void readback(Camera& camera);
+    std::vector<Camera*> enabledCameras(World& world) const;
 
     hiprz_ctx* m_ctx = nullptr;
     std::mutex m_mutex;  // renderWorld is serialised (cpu_engine_core.cpp:15)
     bool m_pending_readback = false;
     std::unique_ptr<Exception> m_deferred;
     const World* m_last_world = nullptr;
+    std::vector<const Camera*> m_camera_slots;  // camera k of the context mirrors this camera
 };
 
 }  // namespace RayZath::Hip

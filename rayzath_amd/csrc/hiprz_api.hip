@@ -148,7 +148,19 @@ int fail(hiprz_ctx* ctx, int code, const std::string& msg) {
     else g_create_error = msg;
     return code;
 }
+// settings are shared by the cameras of a context: a change invalidates the graph of every one of them
+void invalidate_graphs(hiprz_ctx* c) {
+    c->graph_valid = false;
+    for (auto& f : c->parked) f.graph_valid = false;
+}
 }  // namespace hiprz
+
+// Multi-device contexts (hiprz_create_multi): a call on the head is repeated on every peer first; a peer's failure is the call's.
+#define RZ_FANOUT(c, call)                                                                                                     \
+    for (hiprz_ctx* p : (c)->peers) {                                                                                         \
+        const int rz_rc = (call);                                                                                             \
+        if (rz_rc != HIPRZ_OK) return fail(c, rz_rc, "device " + std::to_string(p->device) + ": " + p->error);              \
+    }
 
 namespace {
 
@@ -195,12 +207,12 @@ struct TreeCheck {
     }
 };
 
-void release_frame(hiprz_ctx* c) {
+void release_frame(hiprz_frame_state* c) {
     c->st0.release(), c->st1.release(), c->st2.release(), c->accum.release(), c->depth.release(), c->rgba8.release();
     c->hit0.release(), c->hit1.release();
     c->nee_base.release(), c->nee_a.release(), c->nee_b.release(), c->nee_point.release(), c->nee_dir.release(), c->nee_term.release();
     c->sort_keys.release(), c->sort_keys_out.release(), c->sort_iota.release(), c->sort_perm.release(), c->sort_temp.release(), c->shadow_keys.release(), c->shadow_perm.release();
-    c->image_f4.release(), c->state_md.release(), c->state_ray.release();
+    c->image_f4.release(), c->state_md.release(), c->state_ray.release(), c->gather.release();
 }
 
 int allocate_frame(hiprz_ctx* c) {
@@ -326,7 +338,7 @@ void resolve_pipeline(hiprz_ctx* c) {
         const bool mode_ok = c->traversal_mode == -1 || c->traversal_mode == 1 || c->traversal_mode == 2;  // walks the batch kernel has
         c->pipeline = (c->have_scene && c->lds_scene && c->lds_scene_override != 0 && mode_ok && lds <= 40u * 1024u) ? 2 : 1;
     }
-    if (c->pipeline != before) c->graph_valid = false;
+    if (c->pipeline != before) invalidate_graphs(c);
 }
 
 bool use_lds_scene(const hiprz_ctx* c) {
@@ -531,8 +543,8 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     return finish_batch(c, e0, e1, n_passes, timer);
 }
 
-template <typename T>
-int read_untiled(hiprz_ctx* c, const T* tiles, T* dst, size_t bytes, const char* what) {
+template <typename T, typename PeerTiles>
+int read_untiled(hiprz_ctx* c, const T* tiles, T* dst, size_t bytes, const char* what, PeerTiles peer_tiles_of) {
     if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "readback before camera upload");
     const size_t n = size_t(c->camera.width) * c->camera.height;
     if (!dst || bytes != n * sizeof(T)) return fail(c, HIPRZ_ERR_INVALID, std::string(what) + ": destination size mismatch");
@@ -542,6 +554,21 @@ int read_untiled(hiprz_ctx* c, const T* tiles, T* dst, size_t bytes, const char*
     if (c->n_local_tiles)
         hipLaunchKernelGGL((rz_untile_kernel<T>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, tiles, image,
                            c->camera.width, c->camera.height, c->tiles_x, c->rank, c->world);
+    // multi-device head: every peer's tiles come over a peer-to-peer copy (xGMI between the GPUs of a node) on THIS stream, after
+    // the peer's stream has finished them, and are untiled into the same image
+    for (hiprz_ctx* p : c->peers) {
+        const T* peer_tiles = peer_tiles_of(p);
+        const size_t peer_bytes = size_t(p->n_local_tiles) * 256u * sizeof(T);
+        if (!peer_bytes) continue;
+        RZ_HIP(c, c->gather.resize(peer_bytes));
+        (void)hipSetDevice(p->device);
+        RZ_HIP(c, hipEventRecord(p->peer_done, p->stream));
+        (void)hipSetDevice(c->device);
+        RZ_HIP(c, hipStreamWaitEvent(c->stream, p->peer_done, 0));
+        RZ_HIP(c, hipMemcpyPeerAsync(c->gather.ptr, c->device, peer_tiles, p->device, peer_bytes, c->stream));
+        hipLaunchKernelGGL((rz_untile_kernel<T>), dim3(p->n_local_tiles), dim3(256), 0, c->stream, reinterpret_cast<const T*>(c->gather.ptr), image,
+                           c->camera.width, c->camera.height, c->tiles_x, p->rank, p->world);
+    }
     RZ_HIP(c, hipMemcpyAsync(dst, image, bytes, hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));
     c->timings.set(what, timer.ms());
@@ -732,13 +759,21 @@ int derive_tables(const hiprz_scene* sc, SceneCheck& chk, DerivedTables& out) {
 }  // namespace
 
 namespace {
+// hiprz_select_camera on one context: the selected camera's frame state lives in the context itself, the others are parked
+void select_camera_one(hiprz_ctx* c, uint32_t k) {
+    if (k == c->active_camera || k >= c->parked.size()) return;
+    hiprz_frame_state& self = *c;
+    std::swap(c->parked[c->active_camera], self);  // park the active one (its slot held an empty state)
+    std::swap(self, c->parked[k]);
+    c->active_camera = k;
+}
 // A captured graph of a batch of passes stays valid while nothing its kernel arguments depend on has changed: the setters
 // invalidate it only when a value really differs (both host sides call hiprz_set_config before every frame).
 template <typename T>
 void assign_setting(hiprz_ctx* c, T& field, const T& value) {
     if (std::memcmp(&field, &value, sizeof(T)) != 0) {
         field = value;
-        c->graph_valid = false;
+        invalidate_graphs(c);
     }
 }
 }  // namespace
@@ -779,7 +814,9 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     if (const char* w = std::getenv("HIPRZ_SORT_BITS")) c->sort_bits = std::min(24, std::max(0, std::atoi(w)));
     if (const char* w = std::getenv("HIPRZ_SHADOW_SORT")) c->shadow_sort = std::atoi(w) != 0;
     c->device = device_id;
+    c->parked.resize(1);  // one camera; its state lives in the context itself
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->peer_done, hipEventDisableTiming);
     if (e == hipSuccess) e = c->pass_dev.resize(1);
     if (e == hipSuccess) e = c->counters_dev.resize(16);
     if (e == hipSuccess) e = c->pick_dev.resize(2);
@@ -793,10 +830,97 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     return HIPRZ_OK;
 }
 
+int hiprz_create_multi(hiprz_ctx** out, const int* device_ids, int n_devices) {
+    if (!out) return fail(nullptr, HIPRZ_ERR_INVALID, "hiprz_create_multi: out is null");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) return fail(nullptr, HIPRZ_ERR_INVALID, "hiprz_create_multi: 1..64 device ids");
+    hiprz_ctx* head = nullptr;
+    int rc = hiprz_create(&head, device_ids[0]);
+    if (rc != HIPRZ_OK) return rc;
+    for (int r = 1; r < n_devices; ++r) {
+        hiprz_ctx* peer = nullptr;
+        rc = hiprz_create(&peer, device_ids[r]);
+        if (rc != HIPRZ_OK) {
+            const std::string msg = g_create_error;
+            (void)hiprz_destroy(head);
+            return fail(nullptr, rc, msg);
+        }
+        head->peers.push_back(peer);
+        if (device_ids[r] != device_ids[0]) {  // direct copies between the two GPUs (xGMI); absent peer access hip stages them through the host
+            int can = 0;
+            (void)hipDeviceCanAccessPeer(&can, device_ids[0], device_ids[r]);
+            if (can) {
+                (void)hipSetDevice(device_ids[0]);
+                (void)hipDeviceEnablePeerAccess(device_ids[r], 0);
+                (void)hipGetLastError();  // "already enabled" is fine
+            }
+        }
+    }
+    rc = hiprz_set_shard(head, 0u, 1u);
+    if (rc != HIPRZ_OK) {
+        const std::string msg = head->error;
+        (void)hiprz_destroy(head);
+        return fail(nullptr, rc, msg);
+    }
+    *out = head;
+    return HIPRZ_OK;
+}
+
+int hiprz_device_count(hiprz_ctx* c, uint32_t* out) {
+    if (!c || !out) return HIPRZ_ERR_INVALID;
+    *out = uint32_t(c->peers.size()) + 1u;
+    return HIPRZ_OK;
+}
+
+// ---- cameras: the reference renders every enabled camera of the world per call (cpu_engine_renderer.cpp:97-117) ----
+int hiprz_set_camera_count(hiprz_ctx* c, uint32_t n) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_camera_count(p, n));
+    if (n == 0u || n > 4096u) return fail(c, HIPRZ_ERR_INVALID, "set_camera_count: 1..4096 cameras");
+    (void)hipSetDevice(c->device);
+    if (c->active_camera >= n) select_camera_one(c, 0u);
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t k = n; k < uint32_t(c->parked.size()); ++k) {
+        if (c->parked[k].graph_exec) (void)hipGraphExecDestroy(c->parked[k].graph_exec);
+        release_frame(&c->parked[k]);
+        c->parked[k].pass_dev.release();
+    }
+    c->parked.resize(n);
+    return HIPRZ_OK;
+}
+
+int hiprz_camera_count(hiprz_ctx* c, uint32_t* out) {
+    if (!c || !out) return HIPRZ_ERR_INVALID;
+    *out = uint32_t(c->parked.size());
+    return HIPRZ_OK;
+}
+
+int hiprz_select_camera(hiprz_ctx* c, uint32_t index) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_select_camera(p, index));
+    if (index >= c->parked.size()) return fail(c, HIPRZ_ERR_INVALID, "select_camera: index beyond hiprz_set_camera_count");
+    select_camera_one(c, index);
+    if (!c->pass_dev.ptr) {  // a camera selected for the first time: its device-resident pass index
+        (void)hipSetDevice(c->device);
+        RZ_HIP(c, c->pass_dev.resize(1));
+        RZ_HIP(c, hipMemsetAsync(c->pass_dev.ptr, 0, sizeof(uint32_t), c->stream));
+    }
+    return HIPRZ_OK;
+}
+
 int hiprz_destroy(hiprz_ctx* c) {
     if (!c) return HIPRZ_OK;
+    for (hiprz_ctx* p : c->peers) (void)hiprz_destroy(p);
+    c->peers.clear();
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (uint32_t k = 0; k < uint32_t(c->parked.size()); ++k) {  // every camera's frame
+        if (k == c->active_camera) continue;
+        if (c->parked[k].graph_exec) (void)hipGraphExecDestroy(c->parked[k].graph_exec);
+        release_frame(&c->parked[k]);
+        c->parked[k].pass_dev.release();
+    }
+    if (c->peer_done) (void)hipEventDestroy(c->peer_done);
     drop_graph(c);
     for (auto& p : c->pending_events) {
         (void)hipEventDestroy(p.first);
@@ -817,7 +941,8 @@ const char* hiprz_last_error(const hiprz_ctx* c) { return c ? c->error.c_str() :
 
 int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     if (!c) return HIPRZ_ERR_INVALID;
-    c->graph_valid = false;
+    RZ_FANOUT(c, hiprz_upload_scene(p, sc));
+    invalidate_graphs(c);
     StageTimer timer;
     SceneCheck chk;
     if (check_scene(sc, chk) != HIPRZ_OK) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: " + chk.error);
@@ -991,13 +1116,53 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     if (own_trees) c->lds_scene = false;  // rebuilt trees are walked front to back on skip links only (ties by reference position)
     c->have_scene = true;
     resolve_pipeline(c);
-    c->reset_pending = true;  // world changed => accumulation restarts (cpu_engine_renderer.cpp:108-112)
+    c->reset_pending = true;  // world changed => accumulation restarts (cpu_engine_renderer.cpp:108-112), for every camera
+    for (auto& f : c->parked) f.reset_pending = true;
     c->timings.set("upload scene", timer.ms());
+    return HIPRZ_OK;
+}
+
+// Materials and lights of the uploaded scene changed, geometry did not (the reference's dirty flags per container, updatable.cpp:23-51;
+// Cuda::World re-mirrors only modified containers, cuda_world.cu:28-57): the records are replaced in place — no tree is rebuilt,
+// re-derived or re-validated.  The material count must be that of the uploaded scene (instances refer to materials by index).
+int hiprz_update_shading(hiprz_ctx* c, const hiprz_material* materials, uint32_t n_materials, const hiprz_spot_light* spot_lights,
+                         uint32_t n_spot_lights, const hiprz_direct_light* direct_lights, uint32_t n_direct_lights) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_update_shading(p, materials, n_materials, spot_lights, n_spot_lights, direct_lights, n_direct_lights));
+    if (!c->have_scene) return fail(c, HIPRZ_ERR_STATE, "update_shading before upload_scene");
+    const uint32_t uploaded = (c->dscene.off_inst_materials - c->dscene.off_materials) / uint32_t(sizeof(hiprz_material));
+    if (!materials || n_materials < 2u || ((n_materials * sizeof(hiprz_material) + 15u) & ~size_t(15)) != size_t(c->dscene.off_inst_materials - c->dscene.off_materials))
+        return fail(c, HIPRZ_ERR_INVALID, "update_shading: the scene was uploaded with " + std::to_string(uploaded) + " material slots");
+    if ((n_spot_lights && !spot_lights) || (n_direct_lights && !direct_lights)) return fail(c, HIPRZ_ERR_INVALID, "update_shading: null array with non-zero count");
+    std::vector<hiprz_texture> tex(c->n_textures);
+    (void)hipSetDevice(c->device);
+    if (c->n_textures) RZ_HIP(c, hipMemcpy(tex.data(), c->textures.ptr, sizeof(hiprz_texture) * c->n_textures, hipMemcpyDeviceToHost));
+    auto tex_ok = [&](int32_t t, uint32_t kind) { return t < 0 || (uint32_t(t) < c->n_textures && tex[t].kind == kind); };
+    for (uint32_t i = 0; i < n_materials; ++i) {
+        const hiprz_material& m = materials[i];
+        if (!tex_ok(m.texture, HIPRZ_TEX_RGBA8) || !tex_ok(m.normal_map, HIPRZ_TEX_RGBA8) || !tex_ok(m.metalness_map, HIPRZ_TEX_R8) ||
+            !tex_ok(m.roughness_map, HIPRZ_TEX_R8) || !tex_ok(m.emission_map, HIPRZ_TEX_R32F))
+            return fail(c, HIPRZ_ERR_INVALID, "update_shading: material " + std::to_string(i) + ": map index/kind invalid");
+    }
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    RZ_HIP(c, hipMemcpy(c->hot.ptr + c->dscene.off_materials, materials, sizeof(hiprz_material) * n_materials, hipMemcpyHostToDevice));
+    RZ_HIP(c, c->spot_lights.assign(spot_lights, n_spot_lights, c->stream));
+    RZ_HIP(c, c->direct_lights.assign(direct_lights, n_direct_lights, c->stream));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    c->dscene.spot_lights = reinterpret_cast<const float4*>(c->spot_lights.ptr);
+    c->dscene.direct_lights = reinterpret_cast<const float4*>(c->direct_lights.ptr);
+    c->dscene.n_spot_lights = n_spot_lights, c->dscene.n_direct_lights = n_direct_lights;
+    const bool no_shadow_sort = (n_spot_lights + n_direct_lights) && c->shadow_sort == 0;
+    if (!std::getenv("HIPRZ_SORT_KEY")) c->dscene.sort_variant = no_shadow_sort ? 0u : 2u;
+    invalidate_graphs(c);
+    c->reset_pending = true;  // the world changed: accumulation restarts (cpu_engine_renderer.cpp:108-112), for every camera
+    for (auto& f : c->parked) f.reset_pending = true;
     return HIPRZ_OK;
 }
 
 int hiprz_upload_camera(hiprz_ctx* c, const hiprz_camera* cam) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_upload_camera(p, cam));
     if (!cam) return fail(c, HIPRZ_ERR_INVALID, "upload_camera: camera is null");
     if (cam->width == 0 || cam->height == 0 || cam->width > 32768u || cam->height > 32768u)
         return fail(c, HIPRZ_ERR_INVALID, "upload_camera: resolution must be 1..32768");
@@ -1027,6 +1192,7 @@ int hiprz_upload_camera(hiprz_ctx* c, const hiprz_camera* cam) {
 
 int hiprz_set_config(hiprz_ctx* c, const hiprz_config* cfg) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_config(p, cfg));
     if (!cfg) return fail(c, HIPRZ_ERR_INVALID, "set_config: config is null");
     if (cfg->max_depth == 0 || cfg->max_depth > 254u) return fail(c, HIPRZ_ERR_INVALID, "max_depth must be 1..254 (u8, 255 = path ended)");
     // The CPU kernel divides by sample_count/light_count and yields NaN for 0 samples
@@ -1037,23 +1203,43 @@ int hiprz_set_config(hiprz_ctx* c, const hiprz_config* cfg) {
     return HIPRZ_OK;
 }
 
+namespace {
+int set_shard_one(hiprz_ctx* c, uint32_t rank, uint32_t world) {
+    const bool changed = rank != c->rank || world != c->world;
+    c->rank = rank, c->world = world;
+    if (!changed) return HIPRZ_OK;
+    invalidate_graphs(c);
+    (void)hipSetDevice(c->device);
+    const uint32_t active = c->active_camera;
+    for (uint32_t k = 0; k < uint32_t(c->parked.size()); ++k) {  // every camera's frame is re-tiled for the new shard
+        select_camera_one(c, k);
+        if (c->have_camera) {
+            const int rc = allocate_frame(c);
+            if (rc != HIPRZ_OK) return rc;
+            c->reset_pending = true;
+        }
+    }
+    select_camera_one(c, active);
+    return HIPRZ_OK;
+}
+}  // namespace
+
 int hiprz_set_shard(hiprz_ctx* c, uint32_t rank, uint32_t world) {
     if (!c) return HIPRZ_ERR_INVALID;
     if (world == 0 || rank >= world) return fail(c, HIPRZ_ERR_INVALID, "set_shard: need rank < world");
-    const bool changed = rank != c->rank || world != c->world;
-    c->rank = rank, c->world = world;
-    if (changed) c->graph_valid = false;
-    if (changed && c->have_camera) {
-        (void)hipSetDevice(c->device);
-        const int rc = allocate_frame(c);
-        if (rc != HIPRZ_OK) return rc;
-        c->reset_pending = true;
+    // a multi-device context splits ITS shard once more over its devices: device r of n renders shard rank * n + r of world * n
+    const uint32_t n = uint32_t(c->peers.size()) + 1u;
+    c->user_rank = rank, c->user_world = world;
+    for (uint32_t r = 1; r < n; ++r) {
+        const int rc = set_shard_one(c->peers[r - 1u], rank * n + r, world * n);
+        if (rc != HIPRZ_OK) return fail(c, rc, "device " + std::to_string(c->peers[r - 1u]->device) + ": " + c->peers[r - 1u]->error);
     }
-    return HIPRZ_OK;
+    return set_shard_one(c, rank * n, world * n);
 }
 
 int hiprz_set_traversal_mode(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_traversal_mode(p, mode));
     if (mode < -1 || mode == 0 || mode > 3) return fail(c, HIPRZ_ERR_INVALID, "traversal mode: -1 = per scene, 1 = LDS stack, 2 = workgroup-binned, 3 = skip links (single-wave workgroups)");
     assign_setting(c, c->traversal_mode, mode);
     resolve_pipeline(c);
@@ -1062,11 +1248,13 @@ int hiprz_set_traversal_mode(hiprz_ctx* c, int mode) {
 
 int hiprz_set_mode(hiprz_ctx* c, uint32_t compat_flags) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_mode(p, compat_flags));
     if (compat_flags & ~HIPRZ_MODE_CUDA_COMPAT) return fail(c, HIPRZ_ERR_INVALID, "set_mode: unknown HIPRZ_COMPAT_* flag");
     if (compat_flags != c->mode_flags) {
         c->mode_flags = compat_flags;
-        c->graph_valid = false;
+        invalidate_graphs(c);
         c->reset_pending = true;  // another integrator: what has been accumulated does not mix with it
+        for (auto& f : c->parked) f.reset_pending = true;
         resolve_pipeline(c);
     }
     return HIPRZ_OK;
@@ -1074,6 +1262,7 @@ int hiprz_set_mode(hiprz_ctx* c, uint32_t compat_flags) {
 
 int hiprz_set_tree(hiprz_ctx* c, uint32_t tree) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_tree(p, tree));
     if (tree > HIPRZ_TREE_SAH) return fail(c, HIPRZ_ERR_INVALID, "set_tree: HIPRZ_TREE_REFERENCE or HIPRZ_TREE_SAH");
     c->tree_mode = tree;
     return HIPRZ_OK;
@@ -1081,6 +1270,7 @@ int hiprz_set_tree(hiprz_ctx* c, uint32_t tree) {
 
 int hiprz_set_walk_order(hiprz_ctx* c, int order) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_walk_order(p, order));
     if (order < 0 || order > 2) return fail(c, HIPRZ_ERR_INVALID, "walk order: 0 = the reference's child order, 1 = front-to-back, 2 = front-to-back also in counted renders");
     assign_setting(c, c->walk_order, order);
     return HIPRZ_OK;
@@ -1088,6 +1278,7 @@ int hiprz_set_walk_order(hiprz_ctx* c, int order) {
 
 int hiprz_set_lds_scene(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_lds_scene(p, mode));
     if (mode < -1 || mode > 1) return fail(c, HIPRZ_ERR_INVALID, "lds scene: -1 auto, 0 off, 1 on");
     assign_setting(c, c->lds_scene_override, mode);
     resolve_pipeline(c);
@@ -1096,6 +1287,7 @@ int hiprz_set_lds_scene(hiprz_ctx* c, int mode) {
 
 int hiprz_set_pipeline(hiprz_ctx* c, int pipeline) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_pipeline(p, pipeline));
     if (pipeline < -1 || pipeline > 2) return fail(c, HIPRZ_ERR_INVALID, "pipeline: -1 = per scene, 0 = fused pass kernel, 1 = trace kernel + shade kernel, 2 = resident (one launch per batch of passes)");
     assign_setting(c, c->pipeline_setting, pipeline);
     resolve_pipeline(c);
@@ -1116,6 +1308,7 @@ int hiprz_traversal_mode(hiprz_ctx* c, int* out) {
 
 int hiprz_set_ray_sort(hiprz_ctx* c, int mode) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_ray_sort(p, mode));
     if (mode < -1 || mode > 1) return fail(c, HIPRZ_ERR_INVALID, "ray sort: -1 auto, 0 off, 1 on");
     assign_setting(c, c->sort_rays, mode);
     return HIPRZ_OK;
@@ -1123,12 +1316,14 @@ int hiprz_set_ray_sort(hiprz_ctx* c, int mode) {
 
 int hiprz_set_xcd_swizzle(hiprz_ctx* c, int enabled) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_xcd_swizzle(p, enabled));
     assign_setting(c, c->xcd_swizzle, enabled != 0);
     return HIPRZ_OK;
 }
 
 int hiprz_set_graph(hiprz_ctx* c, int enabled) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_graph(p, enabled));
     c->use_graph = enabled != 0;
     return HIPRZ_OK;
 }
@@ -1141,12 +1336,14 @@ int hiprz_graph_captures(hiprz_ctx* c, uint32_t* out) {
 
 int hiprz_reset(hiprz_ctx* c) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_reset(p));
     c->reset_pending = true;
     return HIPRZ_OK;
 }
 
 int hiprz_render(hiprz_ctx* c, uint32_t n_passes) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_render(p, n_passes));
     (void)hipSetDevice(c->device);
     return render_impl(c, n_passes, false);
 }
@@ -1154,6 +1351,15 @@ int hiprz_render(hiprz_ctx* c, uint32_t n_passes) {
 int hiprz_render_counted(hiprz_ctx* c, uint32_t n_passes, hiprz_counters* out) {
     if (!c) return HIPRZ_ERR_INVALID;
     if (!out) return fail(c, HIPRZ_ERR_INVALID, "render_counted: out is null");
+    hiprz_counters peers_total{};
+    for (hiprz_ctx* p : c->peers) {
+        hiprz_counters part{};
+        const int rz_rc = hiprz_render_counted(p, n_passes, &part);
+        if (rz_rc != HIPRZ_OK) return fail(c, rz_rc, "device " + std::to_string(p->device) + ": " + p->error);
+        uint64_t* t = reinterpret_cast<uint64_t*>(&peers_total);
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(&part);
+        for (size_t k = 0; k < sizeof(hiprz_counters) / sizeof(uint64_t); ++k) t[k] += q[k];
+    }
     (void)hipSetDevice(c->device);
     RZ_HIP(c, hipMemsetAsync(c->counters_dev.ptr, 0, 16 * sizeof(unsigned long long), c->stream));
     const int rc = render_impl(c, n_passes, true);
@@ -1164,11 +1370,17 @@ int hiprz_render_counted(hiprz_ctx* c, uint32_t n_passes, hiprz_counters* out) {
     out->segments = v[0], out->box_tests = v[1], out->tri_tests = v[2], out->hits = v[3];
     out->shadow_rays = v[4], out->light_samples = v[5], out->texel_fetches = v[6], out->finished = v[7];
     out->shadow_box_tests = v[8], out->shadow_tri_tests = v[9];
+    {
+        uint64_t* t = reinterpret_cast<uint64_t*>(out);
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(&peers_total);
+        for (size_t k = 0; k < sizeof(hiprz_counters) / sizeof(uint64_t); ++k) t[k] += q[k];
+    }
     return HIPRZ_OK;
 }
 
 int hiprz_tonemap(hiprz_ctx* c) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_tonemap(p));
     if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "tonemap before camera upload");
     (void)hipSetDevice(c->device);
     if (c->rgba8_valid && !c->reset_pending) return HIPRZ_OK;  // the resident kernel already wrote this frame's pixels
@@ -1182,6 +1394,7 @@ int hiprz_tonemap(hiprz_ctx* c) {
 
 int hiprz_sync(hiprz_ctx* c) {
     if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_sync(p));
     (void)hipSetDevice(c->device);
     RZ_HIP(c, hipStreamSynchronize(c->stream));
     return HIPRZ_OK;
@@ -1190,17 +1403,17 @@ int hiprz_sync(hiprz_ctx* c) {
 int hiprz_read_rgba8(hiprz_ctx* c, uint8_t* dst, size_t bytes) {
     if (!c) return HIPRZ_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    return read_untiled<uint32_t>(c, c->rgba8.ptr, reinterpret_cast<uint32_t*>(dst), bytes, "read rgba8");
+    return read_untiled<uint32_t>(c, c->rgba8.ptr, reinterpret_cast<uint32_t*>(dst), bytes, "read rgba8", [](hiprz_ctx* p) { return (const uint32_t*)p->rgba8.ptr; });
 }
 int hiprz_read_depth(hiprz_ctx* c, float* dst, size_t bytes) {
     if (!c) return HIPRZ_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    return read_untiled<float>(c, c->depth.ptr, dst, bytes, "read depth");
+    return read_untiled<float>(c, c->depth.ptr, dst, bytes, "read depth", [](hiprz_ctx* p) { return (const float*)p->depth.ptr; });
 }
 int hiprz_read_accum(hiprz_ctx* c, float* dst, size_t bytes) {
     if (!c) return HIPRZ_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    return read_untiled<float4>(c, c->accum.ptr, reinterpret_cast<float4*>(dst), bytes, "read accum");
+    return read_untiled<float4>(c, c->accum.ptr, reinterpret_cast<float4*>(dst), bytes, "read accum", [](hiprz_ctx* p) { return (const float4*)p->accum.ptr; });
 }
 
 int hiprz_read_state(hiprz_ctx* c, float* ray9, uint32_t* md2, size_t n_pixels) {
@@ -1217,6 +1430,23 @@ int hiprz_read_state(hiprz_ctx* c, float* ray9, uint32_t* md2, size_t n_pixels) 
         hipLaunchKernelGGL(rz_untile_state_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->st0.ptr, c->st1.ptr,
                            c->st2.ptr, c->state_ray.ptr, c->state_md.ptr, c->camera.width, c->camera.height, c->tiles_x, c->rank,
                            c->world);
+    for (hiprz_ctx* p : c->peers) {  // multi-device head: the peers' path state, one peer at a time through the gather buffer
+        const size_t n_local = size_t(p->n_local_tiles) * 256u;
+        if (!n_local) continue;
+        RZ_HIP(c, c->gather.resize(n_local * 40u));
+        float4* g0 = reinterpret_cast<float4*>(c->gather.ptr);
+        float4* g1 = g0 + n_local;
+        float2* g2 = reinterpret_cast<float2*>(g1 + n_local);
+        (void)hipSetDevice(p->device);
+        RZ_HIP(c, hipEventRecord(p->peer_done, p->stream));
+        (void)hipSetDevice(c->device);
+        RZ_HIP(c, hipStreamWaitEvent(c->stream, p->peer_done, 0));
+        RZ_HIP(c, hipMemcpyPeerAsync(g0, c->device, p->st0.ptr, p->device, n_local * 16u, c->stream));
+        RZ_HIP(c, hipMemcpyPeerAsync(g1, c->device, p->st1.ptr, p->device, n_local * 16u, c->stream));
+        RZ_HIP(c, hipMemcpyPeerAsync(g2, c->device, p->st2.ptr, p->device, n_local * 8u, c->stream));
+        hipLaunchKernelGGL(rz_untile_state_kernel, dim3(p->n_local_tiles), dim3(256), 0, c->stream, g0, g1, g2, c->state_ray.ptr, c->state_md.ptr,
+                           c->camera.width, c->camera.height, c->tiles_x, p->rank, p->world);
+    }
     RZ_HIP(c, hipMemcpyAsync(ray9, c->state_ray.ptr, 9 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipMemcpyAsync(md2, c->state_md.ptr, 2 * n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));
@@ -1226,6 +1456,7 @@ int hiprz_read_state(hiprz_ctx* c, float* ray9, uint32_t* md2, size_t n_pixels) 
 int hiprz_ray_count(hiprz_ctx* c, uint64_t* out) {
     if (!c || !out) return HIPRZ_ERR_INVALID;
     *out = c->ray_count;
+    for (hiprz_ctx* p : c->peers) *out += p->ray_count;
     return HIPRZ_OK;
 }
 int hiprz_pass_count(hiprz_ctx* c, uint32_t* out) {
@@ -1241,6 +1472,7 @@ int hiprz_local_pixel_capacity(hiprz_ctx* c, size_t* out) {
 }
 int hiprz_export_accum_tiles(hiprz_ctx* c, void* dst_device, size_t bytes) {
     if (!c) return HIPRZ_ERR_INVALID;
+    if (!c->peers.empty()) return fail(c, HIPRZ_ERR_STATE, "tile export is for single-device contexts (a multi-device context gathers inside hiprz_read_*)");
     const size_t need = size_t(c->n_local_tiles) * 256u * sizeof(float4);
     if (!dst_device || bytes < need) return fail(c, HIPRZ_ERR_INVALID, "export_accum_tiles: destination too small");
     (void)hipSetDevice(c->device);
@@ -1249,6 +1481,7 @@ int hiprz_export_accum_tiles(hiprz_ctx* c, void* dst_device, size_t bytes) {
 }
 int hiprz_export_rgba8_tiles(hiprz_ctx* c, void* dst_device, size_t bytes) {
     if (!c) return HIPRZ_ERR_INVALID;
+    if (!c->peers.empty()) return fail(c, HIPRZ_ERR_STATE, "tile export is for single-device contexts (a multi-device context gathers inside hiprz_read_*)");
     const size_t need = size_t(c->n_local_tiles) * 256u * sizeof(uint32_t);
     if (!dst_device || bytes < need) return fail(c, HIPRZ_ERR_INVALID, "export_rgba8_tiles: destination too small");
     (void)hipSetDevice(c->device);
@@ -1331,7 +1564,11 @@ int hiprz_pick(hiprz_ctx* c, uint32_t x, uint32_t y, int32_t* instance_out, int3
     // depth of the pixel: only the shard that owns it can answer
     const uint32_t tile = (y / 8u) * c->tiles_x + (x / 32u);
     *instance_out = *material_out = -1;
-    if (tile % c->world != c->rank) return HIPRZ_OK;
+    if (tile % c->world != c->rank) {
+        for (hiprz_ctx* p : c->peers)
+            if (tile % p->world == p->rank) return hiprz_pick(p, x, y, instance_out, material_out);
+        return HIPRZ_OK;
+    }
     const uint32_t lt = tile / c->world, in_tile = ((x % 32u) / 8u) * 64u + (y % 8u) * 8u + (x % 8u);
     float depth = 0.0f;
     RZ_HIP(c, hipMemcpyAsync(&depth, c->depth.ptr + size_t(lt) * 256u + in_tile, sizeof(float), hipMemcpyDeviceToHost, c->stream));

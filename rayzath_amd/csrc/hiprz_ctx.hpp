@@ -82,11 +82,59 @@ struct DeviceArray {
 
 }  // namespace hiprz
 
-struct hiprz_ctx {
+// What belongs to ONE camera of the world: its record, the per-pixel path state and accumulators, the device-resident pass index, the
+// ray-order and shadow hand-over buffers sized for its resolution, the graph that was captured over these pointers.  The reference
+// renders every enabled camera per call (cpu_engine_renderer.cpp:97-117); a context keeps one of these per camera and the calls
+// address the selected one (hiprz_select_camera): hiprz_ctx IS-A frame state, the others are parked.
+struct hiprz_frame_state {
+    hiprz_camera camera{};
+    hiprz::DCamera dcamera{};
+    bool have_camera = false;
+    uint32_t tiles_x = 0, tiles_y = 0, n_local_tiles = 0;
+    uint64_t owned_pixels = 0;
+    hiprz::DeviceArray<float4> st0, st1, accum, hit0;
+    hiprz::DeviceArray<uint32_t> hit1;
+    bool rgba8_valid = false;  // the resident kernel tone-maps on its way out: hiprz_tonemap has nothing to do
+    hiprz::DeviceArray<float2> st2;
+    hiprz::DeviceArray<float> depth;
+    hiprz::DeviceArray<uint32_t> rgba8;
+    hiprz::DeviceArray<float4> image_f4;  // row-major staging for readback
+    hiprz::DeviceArray<uint32_t> state_md;
+    hiprz::DeviceArray<float> state_ray;
+    hiprz::DeviceArray<uint32_t> pass_dev;
+    bool reset_pending = true;
+    uint32_t passes = 0;
+    uint64_t ray_count = 0;
+    // hipGraph of one batch of cumulative passes ([pass kernel, pass update] x n): replayed while nothing that
+    // the captured kernel arguments depend on has changed (scene, camera, config, shard, variants)
+    hipGraphExec_t graph_exec = nullptr;
+    uint32_t graph_passes = 0;
+    bool graph_valid = false;
+    // ray reordering between passes (split pipeline): keys from the shade kernel -> radix sort -> permutation
+    hiprz::DeviceArray<uint32_t> sort_keys, sort_keys_out, sort_iota, sort_perm;
+    hiprz::DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
+    hiprz::DeviceArray<uint8_t> sort_temp;
+    size_t sort_temp_bytes = 0;
+    bool sorted_this_pass = false;  // the deferred shadow kernel wants the NEXT pass's ray order: the sort then runs before it
+    hiprz::DeviceArray<float4> nee_base, nee_a, nee_b, nee_point, nee_dir, nee_term;
+    hiprz::DeviceArray<uint8_t> gather;  // multi-device head: the peers' tile buffers land here before one launch untiles them all
+};
+
+struct hiprz_ctx : hiprz_frame_state {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string error;
     hiprz::TimeTable timings;
+
+    // multi-device (hiprz_create_multi): the head context owns shard 0 and one peer context per further device; every call fans out,
+    // readbacks gather the peers' tiles over P2P copies.  Peers have no peers.
+    std::vector<hiprz_ctx*> peers;
+    hipEvent_t peer_done = nullptr;  // peer side: recorded on its stream when its tiles are ready, awaited by the head's stream
+    uint32_t user_rank = 0, user_world = 1;  // hiprz_set_shard as the caller sees it; peers refine it: (rank * n + r, world * n)
+
+    // cameras (hiprz_set_camera_count / hiprz_select_camera)
+    std::vector<hiprz_frame_state> parked;  // slot [active_camera] is empty while that camera's state lives in the context itself
+    uint32_t active_camera = 0;
 
     // scene mirror
     hiprz::DeviceArray<uint8_t> hot;  // nodes | tlas_order | instances | tris | tri_attrs | materials | inst_materials
@@ -103,61 +151,29 @@ struct hiprz_ctx {
     bool lds_scene = false;      // hot blob is staged into LDS by every workgroup
     int lds_scene_override = -1; // -1 auto, 0 never, 1 always (if it fits at all)
 
-    // camera + per-pixel state
-    hiprz_camera camera{};
-    hiprz::DCamera dcamera{};
-    bool have_camera = false;
-    uint32_t rank = 0, world = 1;
-    uint32_t tiles_x = 0, tiles_y = 0, n_local_tiles = 0;
-    uint64_t owned_pixels = 0;
-    hiprz::DeviceArray<float4> st0, st1, accum, hit0;
-    hiprz::DeviceArray<uint32_t> hit1;
+    uint32_t rank = 0, world = 1;  // the shard this context renders
     // 0 fused (one kernel per pass), 1 split (trace kernel -> shade kernel per pass), 2 resident (one kernel per batch
     // of passes).  -1: resident when the scene is staged in LDS (config B: as fast as split on a whole frame, 2.26 ms per
     // 8 passes, and 0.34 vs 0.45 ms on an eighth of it — per-pass launch/ramp/tail costs vanish), else split (10-20 % faster
     // than fused on configs C, D; the resident kernel has no LDS room for the tree-top cache).
     int pipeline_setting = -1;
     int pipeline = 1;  // resolved by resolve_pipeline() at upload / set time
-    bool rgba8_valid = false;  // the resident kernel tone-maps on its way out: hiprz_tonemap has nothing to do
-    hiprz::DeviceArray<float2> st2;
-    hiprz::DeviceArray<float> depth;
-    hiprz::DeviceArray<uint32_t> rgba8;
-    hiprz::DeviceArray<float4> image_f4;  // row-major staging for readback
-    hiprz::DeviceArray<uint32_t> state_md;
-    hiprz::DeviceArray<float> state_ray;
-    hiprz::DeviceArray<uint32_t> pass_dev;
     hiprz::DeviceArray<unsigned long long> counters_dev;
     hiprz::DeviceArray<int32_t> pick_dev;
 
     hiprz_config config{8u, 8u, 1u, 1u, 20240501u};
-    bool reset_pending = true;
-    uint32_t passes = 0;
-    uint64_t ray_count = 0;
     int traversal_mode = -1;  // -1 = choose per scene (effective_mode)
     uint32_t tree_mode = 0;   // HIPRZ_TREE_* (hiprz_set_tree), applied by hiprz_upload_scene
     uint32_t scene_tree = 0;  // ... of the scene that is uploaded now
     uint32_t mode_flags = 0;  // HIPRZ_COMPAT_* (hiprz_set_mode): non-zero routes every pass through rz_compat_pass_kernel
-
-    // hipGraph of one batch of cumulative passes ([pass kernel, pass update] x n): replayed while nothing that
-    // the captured kernel arguments depend on has changed (scene, camera, config, shard, variants)
-    hipGraphExec_t graph_exec = nullptr;
-    uint32_t graph_passes = 0;
-    bool graph_valid = false;
     uint32_t graph_captures = 0;  // how often a batch was captured + instantiated (hiprz_graph_captures)
-    // ray reordering between passes (split pipeline): keys from the shade kernel -> radix sort -> permutation
-    hiprz::DeviceArray<uint32_t> sort_keys, sort_keys_out, sort_iota, sort_perm;
-    hiprz::DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
     uint32_t n_textures = 0;  // of the uploaded scene
     int batch_waves = 0;  // HIPRZ_BATCH_WAVES=4: never the 5-wave build of the plain batch kernel
     int nolight_kernels = 1;  // scenes without lights use the instantiations without next-event estimation (HIPRZ_NOLIGHT_KERNELS=0: the general ones)
     int sort_bits = 0;    // most significant key bits the radix sorts look at; 0 = by frame size (HIPRZ_SORT_BITS)
     int shadow_sort = 1;  // HIPRZ_SHADOW_SORT=0: the shadow kernel follows the next pass's ray order instead
-    hiprz::DeviceArray<uint8_t> sort_temp;
-    size_t sort_temp_bytes = 0;
     int sort_rays = -1;  // -1 auto (on for scenes walked with MODE 3), 0 off, 1 on
-    bool sorted_this_pass = false;  // the deferred shadow kernel wants the NEXT pass's ray order: the sort then runs before it
     bool defer_shadow_rays = true;  // HIPRZ_DEFER_SHADOWS=0: walk them inside the shade kernel
-    hiprz::DeviceArray<float4> nee_base, nee_a, nee_b, nee_point, nee_dir, nee_term;
     int trace_waves = 0;  // 0 = by tree size; HIPRZ_TRACE_WAVES = 4 | 6 forces the register budget
     uint32_t n_nodes = 0;
     bool time_kernels = false;  // record events around the trace and the shade kernel of every pass of a batch

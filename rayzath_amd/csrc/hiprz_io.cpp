@@ -48,6 +48,20 @@ int hiprz_scene_file_load(const char* path, hiprz_scene_file** out) {
 void hiprz_scene_file_free(hiprz_scene_file* f) { delete f; }
 const hiprz_scene* hiprz_scene_file_scene(const hiprz_scene_file* f) { return f ? &f->scene : nullptr; }
 const hiprz_camera* hiprz_scene_file_camera(const hiprz_scene_file* f) { return f ? &f->camera : nullptr; }
+uint32_t hiprz_scene_file_camera_count(const hiprz_scene_file* f) {
+    if (!f) return 0u;
+    uint32_t n = f->world.camera.enabled ? 1u : 0u;
+    for (const auto& c : f->world.cameras) n += c && c->enabled ? 1u : 0u;
+    return n;
+}
+int hiprz_scene_file_camera_at(const hiprz_scene_file* f, uint32_t index, hiprz_camera* out) {
+    if (!f || !out) return -1;
+    uint32_t k = 0;
+    if (f->world.camera.enabled && k++ == index) return *out = cameraRecord(f->world.camera), 0;
+    for (const auto& c : f->world.cameras)
+        if (c && c->enabled && k++ == index) return *out = cameraRecord(*c), 0;
+    return -1;
+}
 const char* hiprz_scene_file_log(const hiprz_scene_file* f) { return f ? f->log_text.c_str() : ""; }
 uint32_t hiprz_scene_file_error_count(const hiprz_scene_file* f) { return f ? uint32_t(f->log.errors.size()) : 0u; }
 uint32_t hiprz_scene_file_warning_count(const hiprz_scene_file* f) { return f ? uint32_t(f->log.warnings.size()) : 0u; }

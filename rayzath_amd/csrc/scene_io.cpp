@@ -670,6 +670,7 @@ struct SceneLoader {
     std::map<std::string, std::shared_ptr<Mesh>> meshes;
     std::map<std::string, std::shared_ptr<TextureBuffer>> maps[5];  // Texture, NormalMap, MetalnessMap, RoughnessMap, EmissionMap
     bool have_camera = false;
+    std::map<std::string, std::shared_ptr<Instance>> instances;  // by name, for the groups
 
     // json_loader.cpp:75-163: a map object (or the name of one loaded before)
     std::shared_ptr<TextureBuffer> load_texture(const Json& j, int which) {
@@ -918,7 +919,67 @@ struct SceneLoader {
             // "temporal blend": CUDA-only reprojection, not on this path
         }
         log.message("Loaded camera \"" + name + "\".");
-        if (enabled && !have_camera) world.camera = c, have_camera = true;  // the twin World holds one camera: the first enabled one
+        c.enabled = enabled;
+        if (enabled && !have_camera) world.camera = c, have_camera = true;  // World::camera: the first enabled one ...
+        else world.cameras.push_back(std::make_shared<Camera>(c));          // ... the others follow; the renderer skips disabled ones
+    }
+    // json_loader.cpp:886-1033: groups carry a transformation over the instances (and sub-groups) they list.  How it reaches the
+    // flattened scene is the World's group_transforms setting (hip_engine.hpp): like the CPU engine by default.
+    void load_groups(const Json& objects) {
+        const Json* groups = objects.find("Group");
+        if (!groups) return;
+        std::vector<std::pair<std::shared_ptr<Group>, const Json*>> loaded;
+        std::map<std::string, std::shared_ptr<Group>> by_name;
+        auto load_group = [&](const Json& j) {
+            if (!j.is_object()) return log.error("a group is an object");
+            auto g = std::make_shared<Group>();
+            std::string name = "name";
+            for (const auto& [key, value] : j.members) {
+                if (key == "name" && value.is_string()) name = value.str;
+                else if (key == "position") g->position = to_vec3(value);
+                else if (key == "rotation") g->rotation = to_vec3(value);
+                else if (key == "scale") g->scale = to_vec3(value);
+            }
+            if (by_name.count(name)) return log.error("group '" + name + "' is defined twice");
+            by_name[name] = g;
+            world.groups.push_back(g);
+            loaded.emplace_back(g, &j);
+            if (const Json* members = j.find("objects")) {
+                if (!members->is_array()) return log.error("group '" + name + "': \"objects\" is a list of instance names");
+                for (const Json& m : members->items) {
+                    if (!m.is_string()) {
+                        log.error("group '" + name + "': an object is named by a string");
+                        continue;
+                    }
+                    const auto it = instances.find(m.str);
+                    if (it == instances.end()) log.error("group '" + name + "': no instance named '" + m.str + "'");
+                    else it->second->group = g;
+                }
+            }
+            log.message("Loaded group \"" + name + "\".");
+        };
+        if (groups->is_object()) return load_group(*groups);
+        if (!groups->is_array()) return;
+        for (const Json& j : groups->items) load_group(j);
+        for (const auto& [g, j] : loaded) {  // sub-groups, once every group exists
+            const Json* subs = j->find("groups");
+            if (!subs) continue;
+            if (!subs->is_array()) {
+                log.error("\"groups\" is a list of group names");
+                continue;
+            }
+            for (const Json& sname : subs->items) {
+                const auto it = sname.is_string() ? by_name.find(sname.str) : by_name.end();
+                if (it == by_name.end()) {
+                    log.error("a sub-group names a group that does not exist");
+                    continue;
+                }
+                bool circular = it->second == g;
+                for (const Group* up = g->group.get(); up && !circular; up = up->group.get()) circular = up == it->second.get();
+                if (circular) log.error("groups must not contain themselves: '" + sname.str + "' is skipped");
+                else it->second->group = g;
+            }
+        }
     }
     void load_spot_light(const Json& j) {  // json_loader.cpp:713-748
         if (!j.is_object()) return log.error("Value of spot light definition has to be an object.");
@@ -981,6 +1042,7 @@ struct SceneLoader {
             }
         }
         if (material_count >= Instance::materialCapacity()) log.error("Reached the limit of 64 materials per instance in definition of \"" + name + "\".");
+        instances[name] = inst;
         log.message("Loaded instance \"" + name + "\".");
     }
 
@@ -1014,7 +1076,7 @@ struct SceneLoader {
             each(*objects, "SpotLight", [&](const Json& j) { load_spot_light(j); });
             each(*objects, "DirectLight", [&](const Json& j) { load_direct_light(j); });
             each(*objects, "Instance", [&](const Json& j) { load_instance(j); });
-            if (objects->contains("Group")) log.message("Groups are not applied: the CPU kernel uses each instance's own transformation.");
+            load_groups(*objects);
         }
         if (const Json* m = root.find("Material")) load_into(*m, world.material);
         if (const Json* m = root.find("DefaultMaterial")) load_into(*m, world.default_material);

@@ -40,15 +40,47 @@ COMPAT_BEER_LAMBERT, COMPAT_SCATTERING, COMPAT_SHADOW_COLOR, COMPAT_TEXTURE_MULT
 
 
 class Context:
-    """Owns one hiprz_ctx (one GPU, one stream)."""
+    """Owns one hiprz_ctx: one GPU and one stream — or, given a list of device ids, one context over several GPUs
+    (hiprz_create_multi: tiles interleaved over the devices, readbacks gather the peers' tiles over peer-to-peer copies)."""
 
     def __init__(self, device=0):
         self.lib = _lib.load()
         self._ctx = C.c_void_p()
-        rc = self.lib.hiprz_create(C.byref(self._ctx), int(device))
+        if isinstance(device, (list, tuple)):
+            ids = (C.c_int * len(device))(*[int(d) for d in device])
+            rc = self.lib.hiprz_create_multi(C.byref(self._ctx), ids, len(device))
+        else:
+            rc = self.lib.hiprz_create(C.byref(self._ctx), int(device))
         if rc != _abi.OK:
             raise HiprzError(rc, (self.lib.hiprz_last_error(None) or b"").decode())
         self.width = self.height = 0
+        self._sizes = {}
+
+    def device_count(self):
+        v = C.c_uint32()
+        self._check(self.lib.hiprz_device_count(self._ctx, C.byref(v)))
+        return v.value
+
+    # --- cameras: one frame state each, the calls below address the selected one ---
+    def set_camera_count(self, n):
+        self._check(self.lib.hiprz_set_camera_count(self._ctx, n))
+
+    def camera_count(self):
+        v = C.c_uint32()
+        self._check(self.lib.hiprz_camera_count(self._ctx, C.byref(v)))
+        return v.value
+
+    def select_camera(self, index):
+        self._check(self.lib.hiprz_select_camera(self._ctx, index))
+        self._sizes[getattr(self, "_camera", 0)] = (self.width, self.height)
+        self._camera = index
+        self.width, self.height = self._sizes.get(index, (0, 0))
+
+    def update_shading(self, flat_scene):
+        """Materials and lights of `flat_scene` replace those of the uploaded scene in place (same material count); no tree work."""
+        f = flat_scene
+        self._check(self.lib.hiprz_update_shading(self._ctx, f.materials.ctypes.data, len(f.materials), f.spot_lights.ctypes.data, len(f.spot_lights),
+                                                  f.direct_lights.ctypes.data, len(f.direct_lights)))
 
     def close(self):
         if self._ctx:
@@ -241,7 +273,7 @@ class Engine:
         self.context = Context(device)
         self.backend = HostBackend(self.context.lib)
         self._world_key = None
-        self._camera_key = None
+        self._camera_key, self._camera_ids = {}, None
 
     def renderWorld(self, world, render_config, block=True, sync=True):
         ctx = self.context
@@ -252,18 +284,23 @@ class Engine:
             ctx.upload_scene(self._flat)
             self._world_key = world_key
             world._dirty = False
-        cam = world.camera
-        cam_key = (cam.width, cam.height, cam.position.tobytes(), cam.rotation.tobytes(), cam.fov, cam.near_far,
-                   cam.focal_distance, cam.aperture, cam.exposure_time)
-        if self._camera_key != cam_key:
-            ctx.upload_camera(camera_struct(cam, self.backend))
-            self._camera_key = cam_key
         ctx.set_config(render_config.struct())
-        ctx.render(max(render_config.tracing.rpp, 1))
-        ctx.tonemap()
-        cam.image_buffer = ctx.read_rgba8()  # synchronises
-        cam.depth_buffer = ctx.read_depth()
-        cam.ray_count = ctx.ray_count()
+        cameras = [c for c in [world.camera] + list(getattr(world, "cameras", [])) if getattr(c, "enabled", True)]
+        if [id(c) for c in cameras] != self._camera_ids:  # one frame state per enabled camera, in the reference's order
+            ctx.set_camera_count(max(len(cameras), 1))
+            self._camera_ids, self._camera_key = [id(c) for c in cameras], {}
+        for k, cam in enumerate(cameras):
+            ctx.select_camera(k)
+            cam_key = (cam.width, cam.height, cam.position.tobytes(), cam.rotation.tobytes(), cam.fov, cam.near_far,
+                       cam.focal_distance, cam.aperture, cam.exposure_time)
+            if self._camera_key.get(k) != cam_key:
+                ctx.upload_camera(camera_struct(cam, self.backend))
+                self._camera_key[k] = cam_key
+            ctx.render(max(render_config.tracing.rpp, 1))
+            ctx.tonemap()
+            cam.image_buffer = ctx.read_rgba8()  # synchronises
+            cam.depth_buffer = ctx.read_depth()
+            cam.ray_count = ctx.ray_count()
 
     def timingsString(self):
         return self.context.timings()

@@ -122,6 +122,20 @@ class Instance:
         self.materials = list(materials) if isinstance(materials, (list, tuple)) else [materials]
         assert len(self.materials) <= self.MATERIAL_CAPACITY
         self.position, self.rotation, self.scale = _f3(position), _f3(rotation), _f3(scale)
+        self.group = None  # Groupable::group()
+
+
+class Group:
+    """RayZath/group.hpp: a transformation over the instances and sub-groups linked to it (Group::link)."""
+
+    def __init__(self, position=(0, 0, 0), rotation=(0, 0, 0), scale=(1, 1, 1), objects=(), groups=(), name="group"):
+        self.name = name
+        self.position, self.rotation, self.scale = _f3(position), _f3(rotation), _f3(scale)
+        self.group = None
+        for o in objects:
+            o.group = self
+        for g in groups:
+            g.group = self
 
 
 class SpotLight:
@@ -151,8 +165,9 @@ class Camera:
     """RayZath/camera.hpp:127-161 defaults, camera.cpp setters (clamps)."""
 
     def __init__(self, position=(0, 0, -10), rotation=(0, 0, 0), resolution=(1280, 720), fov=math.pi / 2,
-                 near_far=(1.0e-2, 1.0e3), focal_distance=10.0, aperture=0.02, exposure_time=1.0 / 60.0):
+                 near_far=(1.0e-2, 1.0e3), focal_distance=10.0, aperture=0.02, exposure_time=1.0 / 60.0, enabled=True):
         eps = float(np.finfo(np.float32).eps)
+        self.enabled = bool(enabled)
         self.position, self.rotation = _f3(position), _f3(rotation)
         self.width, self.height = max(int(resolution[0]), 1), max(int(resolution[1]), 1)
         self.fov = min(max(float(fov), eps), math.pi - eps)
@@ -175,14 +190,19 @@ class World:
     def __init__(self):
         self.materials, self.meshes, self.instances = [], [], []
         self.spot_lights, self.direct_lights = [], []
-        self.camera = Camera()
+        self.camera = Camera()   # the first camera ...
+        self.cameras = []        # ... and the others; every enabled one is rendered per call (cpu_engine_renderer.cpp:97-117)
+        self.groups = []
+        # "cpu" (default): like the CPU engine — box from the transformation composed through the groups (instance.cpp:125-155), rays
+        # into the instance's own transformation (cpu_engine_kernel.cpp:308); "cuda": the composed one for both (cuda_instance.cu:244)
+        self.group_transforms = "cpu"
         # world.cpp:33-43; Palette::LightGrey comes from the un-vendored Graphics library, value assumed
         self.material = Material((0xFF, 0xFF, 0xFF, 0x00), 0.0, 0.0, 0.0, 1.0, 0.0, name="world_material")
         self.default_material = Material((0xC0, 0xC0, 0xC0, 0xFF), name="world_default_material")
 
     def add(self, obj):
         {Material: self.materials, Mesh: self.meshes, Instance: self.instances, SpotLight: self.spot_lights,
-         DirectLight: self.direct_lights}[type(obj)].append(obj)
+         DirectLight: self.direct_lights, Group: self.groups}[type(obj)].append(obj)
         return obj
 
 
@@ -386,6 +406,27 @@ def _normalize3(v):
     return (v * (F32(1.0) / F32(np.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])))).astype(F32)
 
 
+def _forward(axes, v):
+    """CoordSystem::transformForward (render_parts.cpp:40-43): x_axis * v.x + y_axis * v.y + z_axis * v.z in fp32."""
+    x, y, z = axes
+    v = np.asarray(v, dtype=F32)
+    return ((x * v[0] + y * v[1]) + z * v[2]).astype(F32)
+
+
+def _in_group(inst, backend):
+    """Transformation of an instance composed through its groups, Transformation::operator*= (render_parts.cpp:75-82)."""
+    p, s = inst.position.astype(F32), inst.scale.astype(F32)
+    x, y, z = backend.axes(inst.rotation)
+    g = getattr(inst, "group", None)
+    while g is not None:
+        axes = backend.axes(g.rotation)
+        p = (_forward(axes, p) + g.position.astype(F32)).astype(F32)
+        x, y, z = _forward(axes, x), _forward(axes, y), _forward(axes, z)
+        s = (s * g.scale.astype(F32)).astype(F32)
+        g = g.group
+    return p, s, x, y, z
+
+
 def flatten(world, backend=None):
     """World -> FlatScene (the arrays `hiprz_upload_scene` copies)."""
     backend = backend or HostBackend()
@@ -431,9 +472,9 @@ def flatten(world, backend=None):
     has_mesh = np.zeros(len(world.instances), dtype=np.uint8)
     for i, inst in enumerate(world.instances):
         r = instances[i:i + 1]
-        r["position"], r["scale"] = inst.position, inst.scale
-        x, y, z = backend.axes(inst.rotation)
-        r["x_axis"], r["y_axis"], r["z_axis"] = x, y, z
+        own = (inst.position, inst.scale) + backend.axes(inst.rotation)
+        grouped = _in_group(inst, backend)   # the bounding box always comes from the composed transformation (instance.cpp:125-155)
+        r["position"], r["scale"], r["x_axis"], r["y_axis"], r["z_axis"] = grouped
         r["material_base"], r["material_count"] = len(inst_materials), len(inst.materials)
         for m in inst.materials:
             if m is not None and id(m) not in mat_index:
@@ -442,6 +483,8 @@ def flatten(world, backend=None):
         if inst.mesh is not None:
             has_mesh[i] = 1
             backend.instance_bounds(inst.mesh.vertices, r)
+        if world.group_transforms == "cpu":  # ... but the CPU kernel takes rays into the instance's OWN transformation
+            r["position"], r["scale"], r["x_axis"], r["y_axis"], r["z_axis"] = own
 
     world_nodes, order = backend.world_tree(instances, has_mesh) if len(instances) else (np.zeros(0, _abi.node_dtype), np.zeros(0, np.uint32))
     node_parts, tri_parts, attr_parts = [world_nodes], [], []

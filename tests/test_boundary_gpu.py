@@ -1,0 +1,161 @@
+"""Boundary features of SURVEY.md §8(b) beyond one camera on one GPU:
+
+  * one context over several devices (hiprz_create_multi; here: several shards on GPU 0) == the single-device frame, bit for bit
+  * every camera of the world with its own accumulation state (hiprz_select_camera) == one context per camera
+  * materials / lights replaced in place (hiprz_update_shading) == a full re-upload
+  * group transformations: the CPU engine's behaviour (default) and the CUDA engine's (composed transformation)
+"""
+import numpy as np
+import pytest
+
+import oracle
+from rayzath_amd import scenes
+from rayzath_amd.engine import Context, Engine, LightSampling, RenderConfig, Tracing
+from rayzath_amd.scene import Camera, Group, Instance, Material, camera_struct, flatten, generate_cube
+
+pytestmark = pytest.mark.gpu
+
+
+def _all(ctx):
+    ctx.tonemap()
+    return ctx.read_accum(), ctx.read_depth(), ctx.read_rgba8(), ctx.read_state()
+
+
+def _same(a, b):
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    for k in a[3]:
+        assert np.array_equal(a[3][k], b[3][k]), k
+
+
+@pytest.mark.parametrize("scene", ["cornell", "living room"])
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0, 0]])
+def test_multi_device_context_equals_single_device(built, scene, devices):
+    world = scenes.cornell_box(200, 120) if scene == "cornell" else scenes.living_room(160, 96, 16)
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(LightSampling(2, 1), Tracing(5, 4)).struct()
+    one, many = Context(0), Context(devices)
+    assert many.device_count() == len(devices)
+    counted = []
+    for c in (one, many):
+        c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+        counted.append(c.render_counted(1))
+        c.render(4), c.render(4)
+    _same(_all(one), _all(many))
+    assert counted[0] == counted[1]                                # the shards' work counters add up to the frame's
+    assert one.ray_count() == many.ray_count() == 9 * 200 * 120 if scene == "cornell" else True
+    for xy in [(10, 10), (100, 60), (150, 100), (60, 90)]:
+        assert one.pick(*xy) == many.pick(*xy)
+    # a further split of the multi-device context's share, as an 8-GPU job of 2 processes x 4 devices would do
+    halves = []
+    for rank in range(2):
+        c = Context(devices)
+        c.set_shard(rank, 2)
+        c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+        c.render(1), c.render(4), c.render(4)
+        halves.append(c.read_accum())
+    assert np.array_equal(halves[0] + halves[1], one.read_accum())  # disjoint tiles, zero elsewhere
+    assert (halves[0][..., 3] > 0).sum() + (halves[1][..., 3] > 0).sum() == (one.read_accum()[..., 3] > 0).sum()
+
+
+def test_every_camera_has_its_own_frame(built):
+    world = scenes.cornell_sphere(160, 96, resolution=24)
+    flat = flatten(world)
+    cams = [world.camera, Camera(position=(1.0, 1.5, -3.0), rotation=(0.1, -0.2, 0.0), resolution=(96, 128), fov=1.2, focal_distance=4.0),
+            Camera(position=(-1.0, 0.5, -3.2), rotation=(0.0, 0.25, 0.0), resolution=(64, 40), fov=1.0, focal_distance=4.0)]
+    cfg = RenderConfig(tracing=Tracing(5, 4)).struct()
+    multi = Context(0)
+    multi.set_pipeline(1)
+    multi.upload_scene(flat), multi.set_config(cfg)
+    multi.set_camera_count(3)
+    assert multi.camera_count() == 3
+    for k, cam in enumerate(cams):
+        multi.select_camera(k)
+        multi.upload_camera(camera_struct(cam))
+    for n in (1, 4, 4, 3):                      # interleaved: the cameras advance independently
+        for k in (2, 0, 1):
+            multi.select_camera(k)
+            multi.render(n)
+    multi.select_camera(1)
+    multi.render(4)                              # camera 1 is four passes ahead
+    for k, cam in enumerate(cams):
+        single = Context(0)
+        single.set_pipeline(1)
+        single.upload_scene(flat), single.upload_camera(camera_struct(cam)), single.set_config(cfg)
+        for n in (1, 4, 4, 3) + ((4,) if k == 1 else ()):
+            single.render(n)
+        multi.select_camera(k)
+        assert multi.pass_count() == single.pass_count() == (16 if k == 1 else 12)
+        assert multi.ray_count() == single.ray_count()
+        _same(_all(multi), _all(single))
+    # the Engine renders every enabled camera of a world per call and skips disabled ones
+    world.cameras = cams[1:]
+    cams[2].enabled = False
+    eng = Engine(0)
+    eng.renderWorld(world, RenderConfig(tracing=Tracing(5, 4)))
+    assert world.camera.image_buffer.shape[:2] == (96, 160) and cams[1].image_buffer.shape[:2] == (128, 96)
+    assert not hasattr(cams[2], "image_buffer") and cams[1].ray_count == 4 * 96 * 128
+
+
+def test_update_shading_equals_a_full_upload(built):
+    world = scenes.living_room(128, 80, 12)
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(LightSampling(1, 1), Tracing(5, 4)).struct()
+    a = Context(0)
+    a.upload_scene(flat), a.upload_camera(cam), a.set_config(cfg)
+    a.render(5)
+    world.materials[1].color = (30, 200, 90, 255)            # the red wall turns green, the mirror rough, a light goes away
+    world.materials[4].roughness = 0.4
+    world.spot_lights.pop()
+    changed = flatten(world)
+    assert np.array_equal(changed.nodes, flat.nodes) and np.array_equal(changed.tris, flat.tris)
+    a.update_shading(changed)
+    a.render(5)
+    b = Context(0)
+    b.upload_scene(changed), b.upload_camera(cam), b.set_config(cfg)
+    b.render(5)
+    _same(_all(a), _all(b))
+    assert a.pass_count() == 5                               # the change restarted accumulation
+    with pytest.raises(Exception):
+        a.update_shading(flatten(scenes.cornell_box(64, 64)))  # another material count: refused
+
+
+def _grouped_world(mode):
+    world = scenes.cornell_box(160, 100)
+    blue = world.add(Material((40, 40, 220, 255), 0.2, 0.4))
+    cube = world.add(generate_cube())
+    a = world.add(Instance(cube, [blue], position=(0.3, 0.0, 0.0), rotation=(0.0, 0.4, 0.0), scale=(0.5, 0.7, 0.5)))
+    b = world.add(Instance(cube, [blue], position=(-0.4, 0.2, 0.3), rotation=(0.2, 0.0, 0.1), scale=(0.4, 0.4, 0.4)))
+    inner = world.add(Group(position=(0.2, 0.6, 0.0), rotation=(0.0, 0.0, 0.3), scale=(1.0, 1.2, 1.0), objects=[a]))
+    world.add(Group(position=(0.0, 0.3, 0.4), rotation=(0.0, 0.5, 0.0), scale=(1.1, 1.0, 0.9), objects=[b], groups=[inner]))
+    world.group_transforms = mode
+    return world, (a, b)
+
+
+def test_group_transformations(built):
+    cfg = RenderConfig(tracing=Tracing(5, 4)).struct()
+    frames = {}
+    for mode in ("cpu", "cuda"):
+        world, _ = _grouped_world(mode)
+        flat, cam = flatten(world), camera_struct(world.camera)
+        ctx = Context(0)
+        ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(cfg)
+        ctx.render(5)
+        ref = oracle.OracleRenderer(flat, cam, cfg)             # the oracle follows the flattened records in either mode
+        ref.render(5)
+        frames[mode] = ctx.read_accum()
+        assert np.array_equal(ctx.read_depth(), ref.depth) and np.array_equal(frames[mode][..., 3], ref.accum[..., 3])
+        assert (np.abs(frames[mode][..., :3] - ref.accum[..., :3]) <= 1e-3 * np.maximum(np.abs(ref.accum[..., :3]), 1.0)).all(-1).mean() >= 0.998
+    assert not np.array_equal(frames["cpu"], frames["cuda"])
+    # "cuda": exactly the scene whose instances carry the composed transformation themselves, outside any group
+    world, (a, b) = _grouped_world("cuda")
+    flat = flatten(world)
+    loose, _ = _grouped_world("cuda")
+    recs = flat.instances[-2:]
+    for inst in loose.instances[-2:]:
+        inst.group = None
+    plain = flatten(loose)
+    plain.instances[-2:] = recs                                # same composed position / axes / scale / box
+    ctx = Context(0)
+    ctx.upload_scene(plain), ctx.upload_camera(camera_struct(world.camera)), ctx.set_config(cfg)
+    ctx.render(5)
+    assert np.array_equal(ctx.read_accum(), frames["cuda"])

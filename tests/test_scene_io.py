@@ -178,7 +178,7 @@ def test_json_statements(tmp_path):
     path.write_text(doc)
     s = scene_io.load_scene_file(str(path))
     f = s.flat
-    assert "no material named 'nope'" in s.log and "Groups are not applied" in s.log
+    assert "no material named 'nope'" in s.log and "Loaded group \"g\"" in s.log
     assert s.errors == 1
     m = f.materials
     assert tuple(m[0]["color"]) == (10, 20, 30, 0) and m[0]["emission"] == 2.5 and m[0]["ior"] == 1.0       # world medium keeps ior 1
