@@ -94,7 +94,7 @@ std::vector<RenderTask> prepareTasks(const std::string& task_file) {
     }
 }
 
-std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& report_dir, bool save_images, int device, bool quiet) {
+std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& report_dir, bool save_images, const std::vector<int>& devices, bool quiet) {
     World world;
     {
         if (!quiet) std::printf("Loading \"%s\"\n", file_name(task.scene_path).c_str());
@@ -109,7 +109,7 @@ std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& r
             std::printf("Engine %s is not part of this host library: skipped.\n", engine_name.c_str());
             continue;
         }
-        Engine engine(device);
+        Engine engine(devices);  // several ids: tiles interleaved over the GPUs, gathered inside the readback
         RenderConfig config;
         config.tracing.max_depth = uint8_t(task.max_depth);
         config.tracing.rpp = 1;
@@ -183,7 +183,7 @@ std::string reportText(const std::vector<TaskResult>& results) {
     return out;
 }
 
-int run(const std::string& task_file, std::string report_dir, bool save_images, int device, bool quiet) {
+int run(const std::string& task_file, std::string report_dir, bool save_images, const std::vector<int>& devices, bool quiet) {
     try {
         if (report_dir.empty()) report_dir = parent_dir(task_file);
         if (!report_dir.empty() && report_dir.back() != '/') report_dir.push_back('/');
@@ -196,7 +196,7 @@ int run(const std::string& task_file, std::string report_dir, bool save_images, 
         const auto tasks = prepareTasks(task_file);
         std::vector<TaskResult> results;
         for (const auto& task : tasks) {
-            auto r = executeTask(task, report_dir, save_images, device, quiet);
+            auto r = executeTask(task, report_dir, save_images, devices, quiet);
             results.insert(results.end(), r.begin(), r.end());
         }
         const std::string path = report_dir + "report.txt";

@@ -32,10 +32,10 @@ struct TaskResult {  // headless.hpp:18-33
 // relative scene paths are relative to the task file.  "max depth" is an extension (the reference renders at 16).
 std::vector<RenderTask> prepareTasks(const std::string& task_file);
 // Headless::executeTask (headless.cpp:163-276) for the engines this host side has ("HIPGPU"; others are reported and skipped)
-std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& report_dir, bool save_images, int device, bool quiet);
+std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& report_dir, bool save_images, const std::vector<int>& devices, bool quiet);
 // Headless::generateReport (headless.cpp:297-330): the same three lines per result
 std::string reportText(const std::vector<TaskResult>& results);
 // Headless::run (headless.cpp:17-55)
-int run(const std::string& task_file, std::string report_dir, bool save_images, int device, bool quiet);
+int run(const std::string& task_file, std::string report_dir, bool save_images, const std::vector<int>& devices, bool quiet);  // devices: one context over all of them
 
 }  // namespace RayZath::Hip::Headless

@@ -211,7 +211,9 @@ void release_frame(hiprz_frame_state* c) {
     c->st0.release(), c->st1.release(), c->st2.release(), c->accum.release(), c->depth.release(), c->rgba8.release();
     c->hit0.release(), c->hit1.release();
     c->nee_base.release(), c->nee_a.release(), c->nee_b.release(), c->nee_point.release(), c->nee_dir.release(), c->nee_term.release();
-    c->sort_keys.release(), c->sort_keys_out.release(), c->sort_iota.release(), c->sort_perm.release(), c->sort_temp.release(), c->shadow_keys.release(), c->shadow_perm.release();
+    c->sort_keys.release(), c->sort_perm.release();
+    for (auto& t : c->sort_temp) t.keys_out.release(), t.vals_a.release(), t.vals_b.release(), t.counts.release(), t.digit_total.release();
+    c->shadow_keys.release(), c->shadow_perm.release();
     c->image_f4.release(), c->state_md.release(), c->state_ray.release(), c->gather.release();
 }
 
@@ -237,20 +239,12 @@ int allocate_frame(hiprz_ctx* c) {
     RZ_HIP(c, c->hit0.resize(n));
     RZ_HIP(c, c->hit1.resize(n));
     RZ_HIP(c, c->sort_keys.resize(n));
-    RZ_HIP(c, c->sort_keys_out.resize(n));
     RZ_HIP(c, c->sort_perm.resize(n));
-    RZ_HIP(c, c->sort_iota.resize(n));
     RZ_HIP(c, c->shadow_keys.resize(n));
     RZ_HIP(c, c->shadow_perm.resize(n));
     if (n) {
-        std::vector<uint32_t> iota(n);
-        for (size_t i = 0; i < n; ++i) iota[i] = uint32_t(i);
-        RZ_HIP(c, hipMemcpyAsync(c->sort_iota.ptr, iota.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        RZ_HIP(c, hipMemcpyAsync(c->sort_perm.ptr, iota.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));  // identity until the first sort
-        RZ_HIP(c, hipMemcpyAsync(c->shadow_perm.ptr, iota.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         RZ_HIP(c, hipMemsetAsync(c->sort_keys.ptr, 0, n * sizeof(uint32_t), c->stream));
         RZ_HIP(c, hipMemsetAsync(c->shadow_keys.ptr, 0, n * sizeof(uint32_t), c->stream));
-        RZ_HIP(c, hipStreamSynchronize(c->stream));
         const int src = sort_workspace(c, n);
         if (src != HIPRZ_OK) return src;
     }
@@ -298,7 +292,7 @@ DFrame make_frame(hiprz_ctx* c, bool counted) {
     f.nee_point = c->nee_point.ptr, f.nee_dir = c->nee_dir.ptr, f.nee_term = c->nee_term.ptr;
     const bool sorting = sort_enabled(c);
     f.sort_key = sorting ? c->sort_keys.ptr : nullptr;
-    f.perm = sorting ? c->sort_perm.ptr : nullptr;  // always a valid permutation (identity until the first sort)
+    f.perm = sorting ? c->sort_perm.ptr : nullptr;
     const bool shadow_sorting = sorting && c->shadow_sort != 0 && c->pipeline == 1 && defer_shadows(c);
     f.shadow_key = shadow_sorting ? c->shadow_keys.ptr : nullptr;
     f.shadow_perm = shadow_sorting ? c->shadow_perm.ptr : nullptr;
@@ -452,6 +446,8 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
         RZ_HIP(c, c->nee_term.resize(n * k));
     }
     const DFrame f = make_frame(c, counted);
+    if (!f.perm) c->perm_valid = false;                                        // passes without reordering leave the order behind
+    else if (!c->reset_pending && !c->perm_valid) launch_sort_identity(c);    // reordering was switched on between two batches
     hipEvent_t e0 = take_event(c), e1 = take_event(c);
     RZ_HIP(c, hipEventRecord(e0, c->stream));
     c->rgba8_valid = false;
@@ -817,6 +813,9 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     c->parked.resize(1);  // one camera; its state lives in the context itself
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->peer_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming);
     if (e == hipSuccess) e = c->pass_dev.resize(1);
     if (e == hipSuccess) e = c->counters_dev.resize(16);
     if (e == hipSuccess) e = c->pick_dev.resize(2);
@@ -921,6 +920,9 @@ int hiprz_destroy(hiprz_ctx* c) {
         c->parked[k].pass_dev.release();
     }
     if (c->peer_done) (void)hipEventDestroy(c->peer_done);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream), (void)hipStreamDestroy(c->aux_stream);
+    if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
+    if (c->aux_join) (void)hipEventDestroy(c->aux_join);
     drop_graph(c);
     for (auto& p : c->pending_events) {
         (void)hipEventDestroy(p.first);

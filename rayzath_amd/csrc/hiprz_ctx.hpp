@@ -110,11 +110,15 @@ struct hiprz_frame_state {
     hipGraphExec_t graph_exec = nullptr;
     uint32_t graph_passes = 0;
     bool graph_valid = false;
-    // ray reordering between passes (split pipeline): keys from the shade kernel -> radix sort -> permutation
-    hiprz::DeviceArray<uint32_t> sort_keys, sort_keys_out, sort_iota, sort_perm;
+    // ray reordering between passes (split pipeline, hiprz_sort.hip): keys from the shade kernel -> radix sort -> the permutation the
+    // next trace kernel follows
+    hiprz::DeviceArray<uint32_t> sort_keys, sort_perm;
+    struct SortTemp {  // ping-pong buffers of one sort; the ray sort and the shadow-ray sort of a pass run side by side, each on its own set
+        hiprz::DeviceArray<uint32_t> keys_out, vals_a, vals_b, counts, digit_total;
+    } sort_temp[2];
+    bool sort_beside = false;  // a sort is running on the auxiliary stream: join_sort() before its order is used
+    bool perm_valid = false;  // sort_perm holds the order of the NEXT cumulative pass's rays
     hiprz::DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
-    hiprz::DeviceArray<uint8_t> sort_temp;
-    size_t sort_temp_bytes = 0;
     bool sorted_this_pass = false;  // the deferred shadow kernel wants the NEXT pass's ray order: the sort then runs before it
     hiprz::DeviceArray<float4> nee_base, nee_a, nee_b, nee_point, nee_dir, nee_term;
     hiprz::DeviceArray<uint8_t> gather;  // multi-device head: the peers' tile buffers land here before one launch untiles them all
@@ -125,6 +129,9 @@ struct hiprz_ctx : hiprz_frame_state {
     hipStream_t stream = nullptr;
     std::string error;
     hiprz::TimeTable timings;
+    // second stream + events: the sort of the NEXT pass's rays runs beside the shadow-ray kernel of this pass (hiprz_launch_shade.hip)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t aux_fork = nullptr, aux_join = nullptr;
 
     // multi-device (hiprz_create_multi): the head context owns shard 0 and one peer context per further device; every call fans out,
     // readbacks gather the peers' tiles over P2P copies.  Peers have no peers.
@@ -226,8 +233,11 @@ void launch_trace(hiprz_ctx* c, const DFrame& f, bool first, bool counted);   //
 void launch_shade(hiprz_ctx* c, const DFrame& f, bool first, bool counted);   // split pipeline: shading (+ deferred shadow rays and their sorts)
 void launch_fused(hiprz_ctx* c, const DFrame& f, bool first, bool counted);   // fused pipeline: one kernel per pass
 void launch_batch(hiprz_ctx* c, const DFrame& f, uint32_t n_passes, bool counted, hipEvent_t before, hipEvent_t after);  // resident pipeline
-void launch_sort(hiprz_ctx* c);         // keys of the next rays -> permutation the next trace kernel follows
+void launch_sort(hiprz_ctx* c, bool beside = false);  // keys of the next rays -> the permutation the next trace kernel follows;
+                                                      // beside: on the auxiliary stream, joined by join_sort()
+void join_sort(hiprz_ctx* c);
 void launch_shadow_sort(hiprz_ctx* c);  // keys of the pass's shadow rays -> the order the shadow kernel follows
+void launch_sort_identity(hiprz_ctx* c);  // the identity order (no sort has run on this frame's rays yet)
 int sort_workspace(hiprz_ctx* c, size_t n);  // (re)allocates the sort's buffers for n keys
 
 }  // namespace hiprz

@@ -145,7 +145,7 @@ struct DFrame {
     uint32_t rank, world;  // tile sharding
     uint32_t n_local_tiles;
     uint32_t* sort_key;    // shade kernel: sort key of the pixel's NEXT ray (nullptr = ray reordering off)
-    const uint32_t* perm;  // trace kernel: thread i walks the ray of local pixel perm[i] (nullptr = identity)
+    const uint32_t* perm;  // trace kernel: thread i walks the ray of local pixel perm[i] (nullptr = pixel order)
     uint32_t xcd_swizzle;  // 1: workgroup b works on owned tile (b % 8) * ceil(n/8) + b / 8 (see pixel_of_thread)
     // deferred shadow rays (rz_shade_kernel<..., RZ_SHADOW_DEFER> -> rz_shadow_kernel); null when shadow rays are walked inline
     float4* nee_base;   // [pixel] radiance before next-event estimation, bits(path continues | NEE ran << 1 | sample mask << 2)

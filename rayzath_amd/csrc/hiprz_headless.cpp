@@ -1,5 +1,5 @@
 // hiprz_headless — command line of the headless runner (Application/main.cpp:41-77):
-//   hiprz_headless --headless <tasks.json> [report_dir] [-r] [--device N] [--quiet]
+//   hiprz_headless --headless <tasks.json> [report_dir] [-r] [--device N | --devices N,M,...] [--quiet]
 //   hiprz_headless --format <integer>        prints scientificWithPrefix(integer) (used by the tests)
 #include <cstdio>
 #include <cstdlib>
@@ -11,11 +11,11 @@
 int main(int argc, char** argv) {
     std::string task_file, report_dir;
     bool save_images = false, quiet = false, headless = false;
-    int device = 0;
+    std::vector<int> devices{0};
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "-h" || a == "--help") {
-            std::printf("usage: %s --headless <task_path> [report_path] [-r|--render] [--device N] [--quiet]\n", argv[0]);
+            std::printf("usage: %s --headless <task_path> [report_path] [-r|--render] [--device N | --devices N,M,...] [--quiet]\n", argv[0]);
             return 0;
         } else if (a == "--format" && i + 1 < argc) {
             std::printf("%s\n", RayZath::Hip::Headless::scientificWithPrefix(std::strtoull(argv[++i], nullptr, 10)).c_str());
@@ -27,7 +27,14 @@ int main(int argc, char** argv) {
         } else if (a == "-r" || a == "--render") {
             save_images = true;
         } else if (a == "--device" && i + 1 < argc) {
-            device = std::atoi(argv[++i]);
+            devices.assign(1, std::atoi(argv[++i]));
+        } else if (a == "--devices" && i + 1 < argc) {  // one context over several GPUs of the node
+            devices.clear();
+            for (const char* p = argv[++i]; *p;) {
+                devices.push_back(int(std::strtol(p, const_cast<char**>(&p), 10)));
+                if (*p == ',') ++p;
+            }
+            if (devices.empty()) devices.assign(1, 0);
         } else if (a == "--quiet") {
             quiet = true;
         } else {
@@ -39,5 +46,5 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "usage: %s --headless <task_path> [report_path] [-r] (this host side has no UI)\n", argv[0]);
         return 2;
     }
-    return RayZath::Hip::Headless::run(task_file, report_dir, save_images, device, quiet);
+    return RayZath::Hip::Headless::run(task_file, report_dir, save_images, devices, quiet);
 }

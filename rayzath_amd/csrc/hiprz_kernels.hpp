@@ -356,9 +356,7 @@ __global__ void __launch_bounds__(256, RZ_TRACE_MIN_WAVES) rz_trace_kernel(const
     DScene s = scene_in;
     unsigned char* workspace = rz_lds + stage_scene<LDS_SCENE>(s, rz_lds);
     uint32_t* lds_column = stack_column<MODE>(workspace);
-    // sorted order: thread i walks the ray of pixel perm[i] (the hit record still goes to that pixel's slot)
-    const uint32_t sorted_slot = blockIdx.x * 256u + threadIdx.x;
-    const PixelId p = (!FIRST && f.perm) ? pixel_of_local(f, cam, f.perm[sorted_slot]) : pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
+    const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);  // scenes staged in LDS are never reordered
     Counters cnt;
     Ray ray;
     {
@@ -373,6 +371,18 @@ __global__ void __launch_bounds__(256, RZ_TRACE_MIN_WAVES) rz_trace_kernel(const
         f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
     }
     flush_counters<COUNT>(f, 0u, cnt);
+}
+
+// The ray a thread of the single-wave trace kernels walks: in sorted order thread i takes the ray of local pixel perm[i] (the hit
+// record still goes to that pixel's slot).  The three 16-byte gathers per ray hide well behind the walk: gathering the rays into a
+// contiguous stream first (a kernel of its own after the sort) took 108 us per pass on config C and saved the walk 21.
+template <bool FIRST>
+RZ_DEV PixelId trace_ray_of_slot(const DFrame& f, const DCamera& cam, uint32_t slot, Ray& ray) {
+    const PixelId p = pixel_of_local(f, cam, (!FIRST && f.perm) ? f.perm[slot] : slot);
+    PathState ps;
+    load_path<FIRST>(f, cam, p, ps);
+    ray = ps.ray;
+    return p;
 }
 
 // MODE 3 trace kernel, one wave per workgroup.  A workgroup's registers and LDS stay allocated until its LAST wave ends and
@@ -390,14 +400,9 @@ __global__ void __launch_bounds__(64, MINW) rz_trace_skip_kernel(const DScene s,
     for (uint32_t i = threadIdx.x; i < 2u * top_n; i += uint32_t(WG)) ln[i] = s.nodes[i];
     for (uint32_t i = threadIdx.x; i < top_n; i += uint32_t(WG)) ls[i] = s.node_skip[i];
     const uint32_t slot = blockIdx.x * uint32_t(WG) + threadIdx.x;
-    const PixelId p = pixel_of_local(f, cam, (!FIRST && f.perm) ? f.perm[slot] : slot);
     Counters cnt;
     Ray ray;
-    {
-        PathState ps;
-        load_path<FIRST>(f, cam, p, ps);
-        ray = ps.ray;
-    }
+    const PixelId p = trace_ray_of_slot<FIRST>(f, cam, slot, ray);
     Hit hit;
     hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
     int found = 0;
@@ -418,14 +423,9 @@ template <bool FIRST, bool COUNT, int MINW>
 __global__ void __launch_bounds__(64, MINW) rz_trace_coop_kernel(const DScene s, const DCamera cam, const DFrame f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
-    const PixelId p = pixel_of_local(f, cam, (!FIRST && f.perm) ? f.perm[slot] : slot);
     Counters cnt;
     Ray ray;
-    {
-        PathState ps;
-        load_path<FIRST>(f, cam, p, ps);
-        ray = ps.ray;
-    }
+    const PixelId p = trace_ray_of_slot<FIRST>(f, cam, slot, ray);
     Hit hit;
     hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
     int found = 0;

@@ -24,8 +24,9 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
     } else if (lights && defer_shadows(c)) {
         // shading without shadow walks, then every shadow ray of the pass in a lean single-wave kernel
         hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-        // the next pass's ray order is sorted here so that the shadow kernel may follow it when it has no order of its own
-        launch_sort(c);
+        // The next pass's ray order: needed by the shadow kernel only when it has no order of its own (HIPRZ_SHADOW_SORT=0) — otherwise
+        // that sort runs on the auxiliary stream beside the shadow-ray sort and walk, and the main stream picks it up after them.
+        launch_sort(c, f.shadow_key != nullptr);
         if (f.shadow_key) launch_shadow_sort(c);
         const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
         if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) || c->scene_tree != HIPRZ_TREE_REFERENCE) {
@@ -36,6 +37,7 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
             if (big_trees) hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 6>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
             else hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 4>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
         }
+        join_sort(c);
     } else {  // shadow rays inline on skip links with the tree tops staged in LDS
         const uint32_t shade_top = std::min<uint32_t>(c->dscene.top_count, kTopCacheNodes);
         hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, 3>), grid, block, TopCache::bytes_host(shade_top), c->stream, c->dscene, c->dcamera, cfg, f, shade_top);

@@ -178,3 +178,15 @@ def test_ray_order_and_shadow_deferral_are_invisible_at_full_size(built, name, m
         out.append(digest(c.read_accum()))
         c.close()
     assert out[0] == out[1]
+
+
+@pytest.mark.parametrize("name", ["C", "D"])
+def test_batches_survive_another_hip_user_in_the_process(built, name):
+    """bench.py's flow: batches of 8 passes replayed from a captured graph back to back, torch allocating tensors between the repeats.
+    C's graph holds the ray sort (with the library radix sort in it such a replay faulted; the sort is hand-written since), D's not."""
+    import os, subprocess, sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "other_hip_user_check.py")
+    env = dict(os.environ, CFG=name)
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "done graph captures" in r.stdout and "Memory access fault" not in r.stdout + r.stderr, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stdout.strip().endswith("graph captures 1")

@@ -572,6 +572,7 @@ def test_engine_frames_replay_the_captured_graph(built):
     world = scenes.cornell_sphere(160, 96, resolution=24)     # not staged in LDS by default? force the split pipeline below
     eng = Engine(0)
     eng.context.set_pipeline(1)
+    eng.context.set_ray_sort(0)                    # batches that reorder rays are launched eagerly (the library sort is kept out of graphs)
     cfg = RenderConfig(LightSampling(1, 1), Tracing(6, 4))
     eng.renderWorld(world, cfg)                   # first pass + 3 cumulative: eager
     assert eng.context.graph_captures() == 0
@@ -585,7 +586,7 @@ def test_engine_frames_replay_the_captured_graph(built):
     # the frames themselves: the same passes through a fresh context, eagerly
     flat, cam = flatten(world), camera_struct(world.camera)
     ref = Context(0)
-    ref.set_pipeline(1), ref.set_graph(False)
+    ref.set_pipeline(1), ref.set_graph(False), ref.set_ray_sort(0)
     ref.upload_scene(flat), ref.upload_camera(cam)
     ref.set_config(cfg.struct())
     for _ in range(5):
