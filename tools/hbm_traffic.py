@@ -19,7 +19,7 @@ def means(path, counter):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter and "rz_" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+            agg[r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("hiprz::", "").split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
