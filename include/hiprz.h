@@ -455,6 +455,10 @@ typedef struct hiprz_mesh_desc {
  * max_nodes is too small (2*n_triangles+1 always suffices). */
 int hiprz_build_mesh_tree(const hiprz_mesh_desc* mesh, hiprz_node* nodes_out, uint32_t max_nodes,
                           uint32_t* n_nodes_out, hiprz_tri* tris_out, hiprz_tri_attr* attrs_out);
+/* The intersection + shading records of the triangles order[0..n) of a mesh (de-indexed vertices, texcrds, normals, face normal as
+ * Triangle::calculateNormal, mesh_component.cpp:19-26): what hiprz_build_mesh_tree writes for its own leaf order.  For callers that
+ * bring a tree of their own — the adapter that mirrors the reference's ComponentBVH (rayzath_adapter.hpp). */
+int hiprz_fill_triangles(const hiprz_mesh_desc* mesh, const uint32_t* order, uint32_t n, hiprz_tri* tris_out, hiprz_tri_attr* attrs_out);
 /* Builds the world tree over instance boxes (bb_min/bb_max of each instance; has_mesh[i]==0
  * instances are left out, bvh.hpp:40-47).  order_out receives instance ids in leaf order. */
 int hiprz_build_world_tree(const hiprz_instance* instances, const uint8_t* has_mesh, uint32_t n_instances,

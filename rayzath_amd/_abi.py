@@ -154,6 +154,7 @@ ENTRY_POINTS = {
     "hiprz_kernel_time_ms": (C.c_int, [P, C.POINTER(C.c_double), C.POINTER(U64)]),
     "hiprz_build_mesh_tree": (C.c_int, [C.POINTER(MeshDesc), P, U32, C.POINTER(U32), P, P]),
     "hiprz_build_world_tree": (C.c_int, [P, P, U32, P, U32, C.POINTER(U32), P, C.POINTER(U32)]),
+    "hiprz_fill_triangles": (C.c_int, [P, P, U32, P, P]),
     "hiprz_instance_bounds": (C.c_int, [P, U32, P]),
     "hiprz_axes_from_rotation": (None, [P, P, P, P]),
     "hiprz_axes_look_at": (None, [P, P, P, P]),

@@ -210,7 +210,7 @@ struct TreeCheck {
 void release_frame(hiprz_frame_state* c) {
     c->st0.release(), c->st1.release(), c->st2.release(), c->accum.release(), c->depth.release(), c->rgba8.release();
     c->hit0.release(), c->hit1.release();
-    c->nee_base.release(), c->nee_a.release(), c->nee_b.release(), c->nee_point.release(), c->nee_dir.release(), c->nee_term.release();
+    c->nee.release();
     c->sort_keys.release(), c->sort_perm.release();
     for (auto& t : c->sort_temp) t.keys_out.release(), t.vals_a.release(), t.vals_b.release(), t.counts.release(), t.digit_total.release();
     c->shadow_keys.release(), c->shadow_perm.release();
@@ -288,8 +288,7 @@ DFrame make_frame(hiprz_ctx* c, bool counted) {
     f.counters = counted ? c->counters_dev.ptr : nullptr;
     f.tiles_x = c->tiles_x, f.rank = c->rank, f.world = c->world, f.n_local_tiles = c->n_local_tiles;
     f.xcd_swizzle = c->xcd_swizzle ? 1u : 0u;
-    f.nee_base = c->nee_base.ptr, f.nee_a = c->nee_a.ptr, f.nee_b = c->nee_b.ptr;
-    f.nee_point = c->nee_point.ptr, f.nee_dir = c->nee_dir.ptr, f.nee_term = c->nee_term.ptr;
+    f.nee = c->nee.ptr, f.nee_quads = 4u + 2u * (c->config.spot_samples + c->config.direct_samples);
     const bool sorting = sort_enabled(c);
     f.sort_key = sorting ? c->sort_keys.ptr : nullptr;
     f.perm = sorting ? c->sort_perm.ptr : nullptr;
@@ -437,13 +436,8 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     StageTimer timer;
     if (defer_shadows(c)) {  // hand-over buffers of the deferred shadow rays: (4 + 2 * samples) float4 per owned pixel
         const size_t n = size_t(c->n_local_tiles) * 256u, k = c->config.spot_samples + c->config.direct_samples;
-        if (c->nee_dir.count < n * k || c->nee_base.count < n) c->graph_valid = false;
-        RZ_HIP(c, c->nee_base.resize(n));
-        RZ_HIP(c, c->nee_a.resize(n));
-        RZ_HIP(c, c->nee_b.resize(n));
-        RZ_HIP(c, c->nee_point.resize(n));
-        RZ_HIP(c, c->nee_dir.resize(n * k));
-        RZ_HIP(c, c->nee_term.resize(n * k));
+        if (c->nee.count < n * (4u + 2u * k)) c->graph_valid = false;
+        RZ_HIP(c, c->nee.resize(n * (4u + 2u * k)));
     }
     const DFrame f = make_frame(c, counted);
     if (!f.perm) c->perm_valid = false;                                        // passes without reordering leave the order behind

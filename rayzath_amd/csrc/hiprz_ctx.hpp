@@ -120,7 +120,7 @@ struct hiprz_frame_state {
     bool perm_valid = false;  // sort_perm holds the order of the NEXT cumulative pass's rays
     hiprz::DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
     bool sorted_this_pass = false;  // the deferred shadow kernel wants the NEXT pass's ray order: the sort then runs before it
-    hiprz::DeviceArray<float4> nee_base, nee_a, nee_b, nee_point, nee_dir, nee_term;
+    hiprz::DeviceArray<float4> nee;  // DFrame::nee
     hiprz::DeviceArray<uint8_t> gather;  // multi-device head: the peers' tile buffers land here before one launch untiles them all
 };
 

@@ -148,12 +148,13 @@ struct DFrame {
     const uint32_t* perm;  // trace kernel: thread i walks the ray of local pixel perm[i] (nullptr = pixel order)
     uint32_t xcd_swizzle;  // 1: workgroup b works on owned tile (b % 8) * ceil(n/8) + b / 8 (see pixel_of_thread)
     // deferred shadow rays (rz_shade_kernel<..., RZ_SHADOW_DEFER> -> rz_shadow_kernel); null when shadow rays are walked inline
-    float4* nee_base;   // [pixel] radiance before next-event estimation, bits(path continues | NEE ran << 1 | sample mask << 2)
-    float4* nee_a;      // [pixel] final += (direct * a) * b
-    float4* nee_b;
-    float4* nee_point;  // [pixel] shadow-ray origin
-    float4* nee_dir;    // [sample][pixel] direction, far
-    float4* nee_term;   // [sample][pixel] unshadowed contribution
+    // hand-over record of the deferred shadow rays, ONE contiguous record of nee_quads float4 per pixel (the shadow kernels follow
+    // their own sorted order, so every array they read costs a scattered cache line per pixel: nine arrays were 5.3 GB per launch
+    // on config E).  [0] radiance before next-event estimation, bits(path continues | NEE ran << 1 | sample mask << 2);
+    // [1] shadow-ray origin; [2], [3] a, b of final += (direct * a) * b; [4 + 2k] direction + far of sample k, [5 + 2k] its
+    // unshadowed contribution
+    float4* nee;
+    uint32_t nee_quads;
     uint32_t* shadow_key;         // deferred shadow rays: sort key of the pixel's shadow rays (origin cell + direction towards the light)
     const uint32_t* shadow_perm;  // rz_shadow_kernel: thread i finishes local pixel shadow_perm[i] (nullptr: follow `perm`)
 };
@@ -1396,10 +1397,7 @@ struct ShadowCtx {
     uint32_t* lds_column;
     TopCache top;
     // deferred shadow rays (split pipeline, scenes with lights that are not staged in LDS)
-    float4* nee_point = nullptr;  // [pixel]            shadow-ray origin (the offset hit point)
-    float4* nee_dir = nullptr;    // [sample][pixel]    direction.xyz, far
-    float4* nee_term = nullptr;   // [sample][pixel]    (light colour * brdf colour) * radiance
-    uint32_t nee_stride = 0u, pixel = 0u;
+    float4* nee = nullptr;  // this pixel's hand-over record (DFrame::nee)
     mutable uint32_t defer_mask = 0u;  // bit k: sample slot k holds a shadow ray
     mutable float key_dir[3] = {0.0f, 0.0f, 0.0f};  // direction of the shadow ray in the highest slot (spot samples come last) and the
     mutable float key_o[3] = {0.0f, 0.0f, 0.0f};    // rays' common origin: what the pixel's shadow sort key is made of
@@ -1677,10 +1675,9 @@ RZ_DEV v3 sample_direction(v3 ray_d, uint32_t& ray_material, Surface& sf, Rng& r
 }
 
 RZ_DEV void defer_sample(const ShadowCtx& sc, uint32_t slot, const Ray& sr, col4 term) {
-    const size_t at = size_t(slot) * sc.nee_stride + sc.pixel;
-    sc.nee_dir[at] = make_float4(sr.d.x, sr.d.y, sr.d.z, sr.far_);
-    sc.nee_term[at] = make_float4(term.r, term.g, term.b, term.a);
-    sc.nee_point[sc.pixel] = make_float4(sr.o.x, sr.o.y, sr.o.z, 0.0f);
+    sc.nee[4u + 2u * slot] = make_float4(sr.d.x, sr.d.y, sr.d.z, sr.far_);
+    sc.nee[5u + 2u * slot] = make_float4(term.r, term.g, term.b, term.a);
+    sc.nee[1] = make_float4(sr.o.x, sr.o.y, sr.o.z, 0.0f);
     if ((1u << slot) > sc.defer_mask) {
         sc.key_dir[0] = sr.d.x, sc.key_dir[1] = sr.d.y, sc.key_dir[2] = sr.d.z;
         sc.key_o[0] = sr.o.x, sc.key_o[1] = sr.o.y, sc.key_o[2] = sr.o.z;

@@ -225,9 +225,16 @@ int hiprz_build_mesh_tree(const hiprz_mesh_desc* mesh, hiprz_node* nodes_out, ui
     FlatTreeBuilder builder(boxes, 8u, 32u, nodes_out, max_nodes, order.data());
     if (!builder.build(root, items)) return HIPRZ_ERR_INVALID;
     *n_nodes_out = builder.nodeCount();
+    return hiprz_fill_triangles(mesh, order.data(), T, tris_out, attrs_out);
+}
 
-    for (uint32_t i = 0; i < T; ++i) {
+int hiprz_fill_triangles(const hiprz_mesh_desc* mesh, const uint32_t* order, uint32_t n, hiprz_tri* tris_out, hiprz_tri_attr* attrs_out) {
+    if (!mesh || (n && (!order || !tris_out || !attrs_out || !mesh->vertices || !mesh->tri_vertices))) return HIPRZ_ERR_INVALID;
+    for (uint32_t i = 0; i < n; ++i) {
         const uint32_t t = order[i];
+        if (t >= mesh->n_triangles) return HIPRZ_ERR_INVALID;
+        for (int k = 0; k < 3; ++k)
+            if (mesh->tri_vertices[3 * t + k] >= mesh->n_vertices) return HIPRZ_ERR_INVALID;
         hiprz_tri& o = tris_out[i];
         hiprz_tri_attr& a = attrs_out[i];
         std::memset(&o, 0, sizeof o);

@@ -195,10 +195,11 @@ RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& 
     if constexpr (SHADOW == RZ_SHADOW_DEFER) {
         // the radiance so far + what rz_shadow_kernel needs to finish it; it also does the accumulation
         const uint32_t bits = (path_continues ? 1u : 0u) | (lds_column.defer_done ? 2u : 0u) | (lds_column.defer_mask << 2);
-        f.nee_base[p.local] = make_float4(final_color.r, final_color.g, final_color.b, __uint_as_float(bits));
+        float4* rec = f.nee + size_t(p.local) * f.nee_quads;
+        rec[0] = make_float4(final_color.r, final_color.g, final_color.b, __uint_as_float(bits));
         if (lds_column.defer_done) {
-            f.nee_a[p.local] = make_float4(lds_column.defer_a.r, lds_column.defer_a.g, lds_column.defer_a.b, lds_column.defer_a.a);
-            f.nee_b[p.local] = make_float4(lds_column.defer_b.r, lds_column.defer_b.g, lds_column.defer_b.b, lds_column.defer_b.a);
+            rec[2] = make_float4(lds_column.defer_a.r, lds_column.defer_a.g, lds_column.defer_a.b, lds_column.defer_a.a);
+            rec[3] = make_float4(lds_column.defer_b.r, lds_column.defer_b.g, lds_column.defer_b.b, lds_column.defer_b.a);
         }
     } else {
         col4 value;
@@ -447,8 +448,6 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScen
     ShadowCtx shadow{stack_column<1>(workspace), TopCache{nullptr, nullptr, 0u}};
     if constexpr (SHADOW == RZ_SHADOW_DEFER) {
         shadow.lds_column = nullptr;
-        shadow.nee_point = f.nee_point, shadow.nee_dir = f.nee_dir, shadow.nee_term = f.nee_term;
-        shadow.nee_stride = f.n_local_tiles * 256u;
     }
     if constexpr (SHADOW == 3) {
         float4* ln = reinterpret_cast<float4*>(workspace);
@@ -472,7 +471,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScen
         hit.bx = h0.y, hit.by = h0.z, hit.triangle = __float_as_uint(h0.w);
         hit.instance = found == 2 ? int32_t(h1 & 0x1FFFFFFFu) : -1;
         hit.external = (h1 & 0x80000000u) != 0u;
-        shadow.pixel = p.local;
+        shadow.nee = f.nee + size_t(p.local) * f.nee_quads;
         shade_and_store<FIRST, COUNT, SHADOW>(s, cam, cfg, f, p, ps, found, hit, shadow, cnt);
     } else if (f.sort_key && p.local < f.n_local_tiles * 256u) {
         f.sort_key[p.local] = 0x00FFFFFFu;  // slots outside the frame sort to the end
@@ -499,18 +498,19 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_kernel(const DScene s, con
     Counters cnt;
     if (p.active) {
         const ShadowCtx sc{nullptr, TopCache{ln, ls, top_n}};
-        const float4 base = f.nee_base[p.local];
+        const float4* rec = f.nee + size_t(p.local) * f.nee_quads;
+        const float4 base = rec[0];
         const uint32_t bits = __float_as_uint(base.w);
         const bool path_continues = (bits & 1u) != 0u;
         col4 final_color{base.x, base.y, base.z, 0.0f};
         if (bits & 2u) {
-            const uint32_t mask = bits >> 2, stride = f.n_local_tiles * 256u;
-            const float4 o = f.nee_point[p.local];
+            const uint32_t mask = bits >> 2;
+            const float4 o = rec[1];
             auto shadowed_sum = [&](uint32_t first, uint32_t count) {
                 col4 total = splat(0.0f);
                 for (uint32_t k = first; k < first + count; ++k) {
                     if (!(mask & (1u << k))) continue;
-                    const float4 d = f.nee_dir[size_t(k) * stride + p.local], t = f.nee_term[size_t(k) * stride + p.local];
+                    const float4 d = rec[4u + 2u * k], t = rec[5u + 2u * k];
                     Ray sr;
                     sr.o = V3(o.x, o.y, o.z), sr.d = V3(d.x, d.y, d.z), sr.near_ = 0.0f, sr.far_ = d.w;
                     const col4 V_PL = splat(any_hit<3, COUNT>(s, sc, sr, cnt));
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_kernel(const DScene s, con
             if (s.n_direct_lights != 0u) direct_total = div_scalar(shadowed_sum(0u, cfg.direct_samples), float(cfg.direct_samples) / float(s.n_direct_lights));
             if (s.n_spot_lights != 0u) spot_total = div_scalar(shadowed_sum(cfg.direct_samples, cfg.spot_samples), float(cfg.spot_samples) / float(s.n_spot_lights));
             const col4 direct = direct_total + spot_total;
-            const float4 a = f.nee_a[p.local], b = f.nee_b[p.local];
+            const float4 a = rec[2], b = rec[3];
             final_color = final_color + (direct * col4{a.x, a.y, a.z, a.w}) * col4{b.x, b.y, b.z, b.w};
         }
         col4 value;
@@ -549,19 +549,20 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_coop_kernel(const DScene s
     Counters cnt;
     float4 base = make_float4(0.0f, 0.0f, 0.0f, 0.0f), o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     uint32_t bits = 0u;
+    const float4* rec = f.nee + size_t(p.local) * f.nee_quads;
     if (p.active) {
-        base = f.nee_base[p.local];
+        base = rec[0];
         bits = __float_as_uint(base.w);
-        if (bits & 2u) o = f.nee_point[p.local];
+        if (bits & 2u) o = rec[1];
     }
-    const uint32_t mask = (bits & 2u) ? bits >> 2 : 0u, stride = f.n_local_tiles * 256u;
+    const uint32_t mask = (bits & 2u) ? bits >> 2 : 0u;
     col4 direct_total = splat(0.0f), spot_total = splat(0.0f);
     const uint32_t n_samples = cfg.direct_samples + cfg.spot_samples;
     for (uint32_t k = 0u; k < n_samples; ++k) {  // wave-uniform
         const bool has = (mask & (1u << k)) != 0u;
         if (!__any(has)) continue;
         float4 d = make_float4(0.0f, 0.0f, 1.0f, 0.0f), t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (has) d = f.nee_dir[size_t(k) * stride + p.local], t = f.nee_term[size_t(k) * stride + p.local];
+        if (has) d = rec[4u + 2u * k], t = rec[5u + 2u * k];
         Ray sr;
         sr.o = V3(o.x, o.y, o.z), sr.d = V3(d.x, d.y, d.z), sr.near_ = 0.0f, sr.far_ = d.w;
         if (has) { RZ_COUNT(shadow_rays); }
@@ -582,7 +583,7 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_coop_kernel(const DScene s
             if (s.n_direct_lights != 0u) dt = div_scalar(direct_total, float(cfg.direct_samples) / float(s.n_direct_lights));
             if (s.n_spot_lights != 0u) st = div_scalar(spot_total, float(cfg.spot_samples) / float(s.n_spot_lights));
             const col4 direct = dt + st;
-            const float4 a = f.nee_a[p.local], b = f.nee_b[p.local];
+            const float4 a = rec[2], b = rec[3];
             final_color = final_color + (direct * col4{a.x, a.y, a.z, a.w}) * col4{b.x, b.y, b.z, b.w};
         }
         col4 value;
