@@ -319,9 +319,18 @@ int hiprz_traversal_mode(hiprz_ctx* ctx, int* effective_mode_out); /* valid afte
 #define HIPRZ_COMPAT_SHADOW_COLOR 4u  /* shadow rays pass through triangles, mask *= opacityColor(uv): cuda_instance.cuh:92-164         */
 #define HIPRZ_COMPAT_TEXTURE_MULT 8u  /* texture x colour, emission map x emission: cuda_material.cuh:75-123                           */
 #define HIPRZ_COMPAT_FILTERING 16u    /* hiprz_texture.sampling honoured (linear filter, clamp / mirror / border): cuda_buffer.cuh:364-438 */
+#define HIPRZ_COMPAT_REPROJECTION 32u  /* spatio-temporal reprojection at a restart: cuda_camera.cuh:382-426, cuda_engine_renderer.cu:139-150 */
 #define HIPRZ_MODE_CPU 0u
-#define HIPRZ_MODE_CUDA_COMPAT 31u
+#define HIPRZ_MODE_CUDA_COMPAT 63u
 int hiprz_set_mode(hiprz_ctx* ctx, uint32_t compat_flags);
+/* HIPRZ_COMPAT_REPROJECTION: when accumulation restarts (camera, scene or config changed, hiprz_reset) the frame rendered so far is
+ * kept as history; after the new first pass every pixel's first hit point is projected into the previous camera and, where the
+ * previous depth buffer agrees within 1 %, the previous accumulator * temporal blend is appended — colour sum and sample count alike,
+ * so the tone map sees a frame that starts with blend * (old sample count) samples.  It changes what a restart starts from, not the
+ * integrator: it combines with any other flag, also with none.  History is per camera and is dropped when the resolution or the
+ * shard changes; in a sharded frame only history from tiles the same context owns is carried over.
+ * hiprz_set_temporal_blend: Camera::temporalBlend of the selected camera (camera.cpp:154-156: clamped to [0, 1]; default 0.75). */
+int hiprz_set_temporal_blend(hiprz_ctx* ctx, float blend);
 
 /* Which mesh trees the walks use.  HIPRZ_TREE_REFERENCE (default): the trees of the uploaded snapshot — the reference's builder
  * (bvh_tree_node.hpp:117-215), the anchor of the work counters.  HIPRZ_TREE_SAH: at upload every mesh tree is rebuilt over the same

@@ -111,6 +111,7 @@ ENTRY_POINTS = {
     "hiprz_set_traversal_mode": (C.c_int, [P, C.c_int]),
     "hiprz_set_walk_order": (C.c_int, [P, C.c_int]),
     "hiprz_set_mode": (C.c_int, [P, U32]),
+    "hiprz_set_temporal_blend": (C.c_int, [P, C.c_float]),
     "hiprz_create_multi": (C.c_int, [C.POINTER(P), C.POINTER(C.c_int), C.c_int]),
     "hiprz_device_count": (C.c_int, [P, C.POINTER(U32)]),
     "hiprz_set_camera_count": (C.c_int, [P, U32]),

@@ -371,6 +371,7 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
         if (cam.isModified()) {
             const hiprz_camera rec = cameraRecord(cam);
             check(hiprz_upload_camera(m_ctx, &rec));
+            check(hiprz_set_temporal_blend(m_ctx, cam.temporal_blend));
             cam.makeUnmodified();
         }
         check(hiprz_render(m_ctx, std::max(cfg.tracing.rpp, 1u)));

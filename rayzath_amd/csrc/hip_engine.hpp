@@ -126,6 +126,7 @@ struct Camera : public Updatable {  // camera.hpp:127-161
     uint32_t width = 1280, height = 720;
     float fov = 1.57079632679f, near_plane = 1.0e-2f, far_plane = 1.0e3f;
     float focal_distance = 10.0f, aperture = 0.02f, exposure_time = 1.0f / 60.0f;
+    float temporal_blend = 0.75f;  // camera.hpp:135; read with HIPRZ_COMPAT_REPROJECTION only
     bool enabled = true;  // camera.hpp:150; disabled cameras are skipped by the renderers (cpu_engine_renderer.cpp:99)
     // outputs the backend writes (camera.hpp:50-56, 113-119)
     std::vector<uint8_t> image_buffer;  // RGBA8 W*H

@@ -217,7 +217,59 @@ void release_frame(hiprz_frame_state* c) {
     c->image_f4.release(), c->state_md.release(), c->state_ray.release(), c->gather.release();
 }
 
+// Camera::reproject (cuda_camera.cuh:390-426) for one pixel of the frame that has just had its first pass: the first hit point —
+// the pixel-centre ray (generateSimpleRay) at the stored depth — seen from the previous camera; where that camera's depth buffer holds
+// the same surface (within 1 % of the distance), its accumulator * blend is appended to this pixel's.
+struct PrevCamera {
+    float position[3], x_axis[3], y_axis[3], z_axis[3];
+    float tan_half_fov, aspect_ratio;
+};
+__global__ void __launch_bounds__(256) rz_reproject_kernel(const DFrame f, const DCamera cam, const PrevCamera prev, const float4* prev_accum,
+                                                           const float* prev_depth, float blend) {
+    const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
+    if (!p.active) return;
+    Ray ray;
+    generate_simple_ray(cam, ray, p.x, p.y);
+    const v3 space_p = ray.o + ray.d * f.depth[p.local];
+    const v3 rel = space_p - ld3(prev.position);
+    const v3 local_p = transform_backward(ld3(prev.x_axis), ld3(prev.y_axis), ld3(prev.z_axis), rel);
+    if (local_p.z <= 0.0f) return;  // behind the previous camera
+    const float fx = (((local_p.x / local_p.z) / prev.tan_half_fov) + 0.5f) * float(cam.width);
+    const float fy = (((local_p.y / local_p.z) / (-prev.tan_half_fov / prev.aspect_ratio)) + 0.5f) * float(cam.height);
+    if (fx < 0.0f || fx >= float(cam.width) || fy < 0.0f || fy >= float(cam.height)) return;  // outside the previous frustum
+    const uint32_t sx = uint32_t(fx), sy = uint32_t(fy);
+    const uint32_t tile = (sy >> 3) * f.tiles_x + (sx >> 5);
+    if (tile % f.world != f.rank) return;  // the source pixel lives in another shard
+    const uint32_t from = (tile / f.world) * 256u + (((sx & 31u) >> 3) << 6) + ((sy & 7u) << 3) + (sx & 7u);
+    const float point_dist = magnitude(rel), buffer_dist = prev_depth[from];
+    if (fabsf(point_dist - buffer_dist) < 0.01f * point_dist) {
+        const float4 a = f.accum[p.local], h = prev_accum[from];
+        f.accum[p.local] = make_float4(a.x + h.x * blend, a.y + h.y * blend, a.z + h.z * blend, a.w + h.w * blend);
+    }
+}
+
+// Called where a first pass is about to run.  Returns whether the finished first pass is to be followed by reproject_after_first_pass.
+bool keep_history(hiprz_ctx* c) {
+    const bool reproject = (c->mode_flags & HIPRZ_COMPAT_REPROJECTION) && c->frame_started && c->n_local_tiles != 0u;
+    if (reproject) {
+        const size_t n = size_t(c->n_local_tiles) * 256u;
+        if (c->prev_accum.resize(n) != hipSuccess || c->prev_depth.resize(n) != hipSuccess) return false;
+        (void)hipMemcpyAsync(c->prev_accum.ptr, c->accum.ptr, n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
+        (void)hipMemcpyAsync(c->prev_depth.ptr, c->depth.ptr, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+    }
+    return reproject;
+}
+void reproject_after_first_pass(hiprz_ctx* c, const DFrame& f, const hiprz_camera& previous) {
+    PrevCamera prev;
+    std::memcpy(prev.position, previous.position, 12), std::memcpy(prev.x_axis, previous.x_axis, 12);
+    std::memcpy(prev.y_axis, previous.y_axis, 12), std::memcpy(prev.z_axis, previous.z_axis, 12);
+    prev.tan_half_fov = previous.tan_half_fov, prev.aspect_ratio = previous.aspect_ratio;
+    const PassGeometry g = pass_geometry(c);
+    hipLaunchKernelGGL(rz_reproject_kernel, g.grid, dim3(256), 0, c->stream, f, c->dcamera, prev, c->prev_accum.ptr, c->prev_depth.ptr, c->temporal_blend);
+}
+
 int allocate_frame(hiprz_ctx* c) {
+    c->frame_started = false;  // whatever history there was belongs to other buffers
     const uint32_t W = c->camera.width, H = c->camera.height;
     c->tiles_x = (W + 31u) / 32u;
     c->tiles_y = (H + 7u) / 8u;
@@ -322,7 +374,7 @@ bool defer_shadows(const hiprz_ctx* c) {
 
 void resolve_pipeline(hiprz_ctx* c) {
     const int before = c->pipeline;
-    if (c->mode_flags != 0u) c->pipeline = 0;  // CUDA-compat mode: the fused compat kernel
+    if (c->mode_flags & kIntegratorFlags) c->pipeline = 0;  // CUDA-compat mode: the fused compat kernel
     else if (c->scene_tree != HIPRZ_TREE_REFERENCE) c->pipeline = 1;
     else if (c->pipeline_setting >= 0) c->pipeline = c->pipeline_setting;
     else {
@@ -448,8 +500,12 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     if (c->pipeline == 2) {
         uint32_t remaining = n_passes;
         if (c->reset_pending) {  // renderFirstPass: the fused kernel
+            const bool history = keep_history(c);
+            const hiprz_camera previous = c->frame_camera;
+            c->frame_camera = c->camera, c->frame_started = true;
             hipLaunchKernelGGL(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
             launch_pass(c, f, true, counted);
+            if (history) reproject_after_first_pass(c, f, previous);
             hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
             c->reset_pending = false;
             c->passes = 1;
@@ -517,8 +573,12 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
             continue;
         }
         if (c->reset_pending) {
+            const bool history = keep_history(c);
+            const hiprz_camera previous = c->frame_camera;
+            c->frame_camera = c->camera, c->frame_started = true;
             hipLaunchKernelGGL(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
             launch_pass(c, f, true, counted);
+            if (history) reproject_after_first_pass(c, f, previous);
             c->reset_pending = false;
             c->passes = 0;
             c->ray_count = 0;
@@ -1247,12 +1307,22 @@ int hiprz_set_mode(hiprz_ctx* c, uint32_t compat_flags) {
     RZ_FANOUT(c, hiprz_set_mode(p, compat_flags));
     if (compat_flags & ~HIPRZ_MODE_CUDA_COMPAT) return fail(c, HIPRZ_ERR_INVALID, "set_mode: unknown HIPRZ_COMPAT_* flag");
     if (compat_flags != c->mode_flags) {
+        const bool integrator_changed = ((compat_flags ^ c->mode_flags) & kIntegratorFlags) != 0u;
         c->mode_flags = compat_flags;
-        invalidate_graphs(c);
-        c->reset_pending = true;  // another integrator: what has been accumulated does not mix with it
-        for (auto& f : c->parked) f.reset_pending = true;
-        resolve_pipeline(c);
+        if (integrator_changed) {
+            invalidate_graphs(c);
+            c->reset_pending = true;  // another integrator: what has been accumulated does not mix with it
+            for (auto& f : c->parked) f.reset_pending = true;
+            resolve_pipeline(c);
+        }
     }
+    return HIPRZ_OK;
+}
+
+int hiprz_set_temporal_blend(hiprz_ctx* c, float blend) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_set_temporal_blend(p, blend));
+    c->temporal_blend = std::min(std::max(blend, 0.0f), 1.0f);  // camera.cpp:154-156
     return HIPRZ_OK;
 }
 

@@ -86,6 +86,9 @@ struct DeviceArray {
 // ray-order and shadow hand-over buffers sized for its resolution, the graph that was captured over these pointers.  The reference
 // renders every enabled camera per call (cpu_engine_renderer.cpp:97-117); a context keeps one of these per camera and the calls
 // address the selected one (hiprz_select_camera): hiprz_ctx IS-A frame state, the others are parked.
+// the HIPRZ_COMPAT_* flags that change the integration (everything but the reprojection of history at a restart)
+constexpr uint32_t kIntegratorFlags = HIPRZ_MODE_CUDA_COMPAT & ~HIPRZ_COMPAT_REPROJECTION;
+
 struct hiprz_frame_state {
     hiprz_camera camera{};
     hiprz::DCamera dcamera{};
@@ -121,6 +124,12 @@ struct hiprz_frame_state {
     hiprz::DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
     bool sorted_this_pass = false;  // the deferred shadow kernel wants the NEXT pass's ray order: the sort then runs before it
     hiprz::DeviceArray<float4> nee;  // DFrame::nee
+    // HIPRZ_COMPAT_REPROJECTION: the frame a restart replaces (accumulator, first-hit depth, the camera it was rendered from)
+    hiprz::DeviceArray<float4> prev_accum;
+    hiprz::DeviceArray<float> prev_depth;
+    hiprz_camera frame_camera{};  // camera of the frame being accumulated
+    bool frame_started = false;   // a first pass ran since the frame buffers were (re)allocated
+    float temporal_blend = 0.75f;
     hiprz::DeviceArray<uint8_t> gather;  // multi-device head: the peers' tile buffers land here before one launch untiles them all
 };
 
@@ -172,7 +181,7 @@ struct hiprz_ctx : hiprz_frame_state {
     int traversal_mode = -1;  // -1 = choose per scene (effective_mode)
     uint32_t tree_mode = 0;   // HIPRZ_TREE_* (hiprz_set_tree), applied by hiprz_upload_scene
     uint32_t scene_tree = 0;  // ... of the scene that is uploaded now
-    uint32_t mode_flags = 0;  // HIPRZ_COMPAT_* (hiprz_set_mode): non-zero routes every pass through rz_compat_pass_kernel
+    uint32_t mode_flags = 0;  // HIPRZ_COMPAT_* (hiprz_set_mode): an integrator flag routes every pass through rz_compat_pass_kernel
     uint32_t graph_captures = 0;  // how often a batch was captured + instantiated (hiprz_graph_captures)
     uint32_t n_textures = 0;  // of the uploaded scene
     int batch_waves = 0;  // HIPRZ_BATCH_WAVES=4: never the 5-wave build of the plain batch kernel

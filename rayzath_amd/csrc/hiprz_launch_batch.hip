@@ -10,7 +10,7 @@ template <bool FIRST, bool COUNT>
 void launch_fused_t(hiprz_ctx* c, const DFrame& f) {
     const PassGeometry g = pass_geometry(c);
     const DConfig cfg = make_config(c);
-    if (c->mode_flags != 0u) {  // CUDA-compat mode: its own fused kernel on the global scene
+    if (c->mode_flags & kIntegratorFlags) {  // CUDA-compat mode: its own fused kernel on the global scene
         hipLaunchKernelGGL((rz_compat_pass_kernel<FIRST, COUNT>), g.grid, g.block, 0, c->stream, c->dscene, c->dcamera, cfg, f);
         return;
     }

@@ -368,6 +368,7 @@ public:
             if (slots_changed || cam.stateRegister().IsModified()) {
                 const hiprz_camera rec = WorldAdapter<Api>::cameraRecord(cam);
                 check(hiprz_upload_camera(m_ctx, &rec));
+                check(hiprz_set_temporal_blend(m_ctx, cam.temporalBlend()));  // camera.hpp:111
                 cam.stateRegister().MakeUnmodified();
             }
             check(hiprz_render(m_ctx, std::max<uint32_t>(config.tracing().rpp(), 1u)));

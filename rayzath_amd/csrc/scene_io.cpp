@@ -916,7 +916,7 @@ struct SceneLoader {
             else if (key == "aperture" && value.is_number()) c.aperture = as_float(value);
             else if (key == "exposure time" && value.is_number()) c.exposure_time = as_float(value);
             else if (key == "enabled" && value.is_bool()) enabled = value.b;
-            // "temporal blend": CUDA-only reprojection, not on this path
+            else if (key == "temporal blend" && value.is_number()) c.temporal_blend = std::min(std::max(as_float(value), 0.0f), 1.0f);  // json_loader.cpp:701, camera.cpp:154-156
         }
         log.message("Loaded camera \"" + name + "\".");
         c.enabled = enabled;
@@ -1236,7 +1236,7 @@ void saveScene(const std::string& path, const World& world) {
     const Camera& c = world.camera;
     out << "\n  ],\n  \"Camera\": [\n   {\"name\": \"camera\", \"position\": " << vec3(c.position) << ", \"rotation\": " << vec3(c.rotation) << ", \"resolution\": [" << c.width << ", "
         << c.height << "], \"fov\": " << num(c.fov) << ", \"near plane\": " << num(c.near_plane) << ", \"far plane\": " << num(c.far_plane) << ", \"focal distance\": "
-        << num(c.focal_distance) << ", \"aperture\": " << num(c.aperture) << ", \"exposure time\": " << num(c.exposure_time) << ", \"enabled\": true}\n  ],\n  \"SpotLight\": [";
+        << num(c.focal_distance) << ", \"aperture\": " << num(c.aperture) << ", \"exposure time\": " << num(c.exposure_time) << ", \"temporal blend\": " << num(c.temporal_blend) << ", \"enabled\": true}\n  ],\n  \"SpotLight\": [";
     for (size_t i = 0; i < world.spot_lights.size(); ++i) {
         const SpotLight& l = *world.spot_lights[i];
         out << (i ? ",\n   " : "\n   ") << "{\"name\": \"spot " << i << "\", \"position\": " << vec3(l.position) << ", \"direction\": " << vec3(l.direction) << ", \"color\": " << color(l.color)

@@ -36,7 +36,7 @@ class RenderConfig:
                            self.light_sampling.direct_light, self.seed & 0xFFFFFFFF)
 
 
-COMPAT_BEER_LAMBERT, COMPAT_SCATTERING, COMPAT_SHADOW_COLOR, COMPAT_TEXTURE_MULT, COMPAT_FILTERING = 1, 2, 4, 8, 16  # hiprz_set_mode
+COMPAT_BEER_LAMBERT, COMPAT_SCATTERING, COMPAT_SHADOW_COLOR, COMPAT_TEXTURE_MULT, COMPAT_FILTERING, COMPAT_REPROJECTION = 1, 2, 4, 8, 16, 32  # hiprz_set_mode
 
 
 class Context:
@@ -121,6 +121,10 @@ class Context:
     def set_mode(self, compat_flags):
         """0 = the CPU kernel (default, parity-checked); COMPAT_* flags add behaviours of the reference's CUDA engine (include/hiprz.h)."""
         self._check(self.lib.hiprz_set_mode(self._ctx, compat_flags))
+
+    def set_temporal_blend(self, blend):
+        """Camera::temporalBlend of the selected camera: the weight of the previous frame's history at a restart (COMPAT_REPROJECTION)."""
+        self._check(self.lib.hiprz_set_temporal_blend(self._ctx, blend))
 
     def set_tree(self, tree):
         """0 = the uploaded (reference) mesh trees, 1 = rebuilt with a binned SAH at the next upload_scene (same frames, fewer tests)."""
@@ -295,6 +299,7 @@ class Engine:
                        cam.focal_distance, cam.aperture, cam.exposure_time)
             if self._camera_key.get(k) != cam_key:
                 ctx.upload_camera(camera_struct(cam, self.backend))
+                ctx.set_temporal_blend(cam.temporal_blend)
                 self._camera_key[k] = cam_key
             ctx.render(max(render_config.tracing.rpp, 1))
             ctx.tonemap()

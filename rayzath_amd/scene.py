@@ -165,9 +165,10 @@ class Camera:
     """RayZath/camera.hpp:127-161 defaults, camera.cpp setters (clamps)."""
 
     def __init__(self, position=(0, 0, -10), rotation=(0, 0, 0), resolution=(1280, 720), fov=math.pi / 2,
-                 near_far=(1.0e-2, 1.0e3), focal_distance=10.0, aperture=0.02, exposure_time=1.0 / 60.0, enabled=True):
+                 near_far=(1.0e-2, 1.0e3), focal_distance=10.0, aperture=0.02, exposure_time=1.0 / 60.0, enabled=True, temporal_blend=0.75):
         eps = float(np.finfo(np.float32).eps)
         self.enabled = bool(enabled)
+        self.temporal_blend = min(max(float(temporal_blend), 0.0), 1.0)   # camera.cpp:154-156; COMPAT_REPROJECTION only
         self.position, self.rotation = _f3(position), _f3(rotation)
         self.width, self.height = max(int(resolution[0]), 1), max(int(resolution[1]), 1)
         self.fov = min(max(float(fov), eps), math.pi - eps)

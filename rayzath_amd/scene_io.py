@@ -243,7 +243,7 @@ def save_scene_json(world, path):
         "Camera": [{"name": "camera", "position": _v(cam.position), "rotation": _v(cam.rotation),
                     "resolution": [int(cam.width), int(cam.height)], "fov": _f(cam.fov), "near plane": _f(cam.near_far[0]),
                     "far plane": _f(cam.near_far[1]), "focal distance": _f(cam.focal_distance), "aperture": _f(cam.aperture),
-                    "exposure time": _f(cam.exposure_time), "enabled": True}],
+                    "exposure time": _f(cam.exposure_time), "temporal blend": _f(cam.temporal_blend), "enabled": True}],
         "SpotLight": [{"name": f"spot {i}", "position": _v(l.position), "direction": _v(l.direction), "color": [int(c) for c in l.color],
                        "size": _f(l.size), "emission": _f(l.emission), "angle": _f(l.beam_angle)} for i, l in enumerate(world.spot_lights)],
         "DirectLight": [{"name": f"direct {i}", "direction": _v(l.direction), "color": [int(c) for c in l.color], "emission": _f(l.emission),

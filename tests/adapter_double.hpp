@@ -201,6 +201,7 @@ struct Camera : Updatable {
     angle_radf m_fov;
     float m_near = 0, m_far = 0, m_focal = 0, m_aperture = 0, m_exposure = 0;
     bool m_enabled = true;
+    float m_temporal_blend = 0.75f;
     uint64_t m_ray_count = 0;
     Buffer2D<Color> m_image;
     Buffer2D<float> m_depth;
@@ -219,6 +220,7 @@ struct Camera : Updatable {
     float focalDistance() const { return m_focal; }
     float aperture() const { return m_aperture; }
     float exposureTime() const { return m_exposure; }
+    float temporalBlend() const { return m_temporal_blend; }
 };
 
 template <class T>

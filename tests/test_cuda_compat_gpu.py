@@ -215,3 +215,111 @@ def test_default_mode_is_untouched_by_the_compat_code():
     assert np.array_equal(a.read_accum(), b.read_accum())
     assert np.array_equal(compat[..., 3], b.read_accum()[..., 3])
     assert np.allclose(compat[..., :3], b.read_accum()[..., :3], rtol=1e-4, atol=1e-6)   # Beer in a medium of alpha 1: x * pow(1, t)
+
+
+# ---- spatio-temporal reprojection (COMPAT_REPROJECTION; cuda_camera.cuh:382-426, cuda_engine_renderer.cu:139-150) ----
+def _host_reprojection(first, depth, prev_accum, prev_depth, cam_now, cam_prev, blend):
+    """Camera::reproject restated with numpy float32 on row-major frames: returns the accumulator the first pass + history must give and
+    the mask of pixels whose source pixel index is safely inside a pixel (not within 1e-3 of a pixel border, where one rounding decides)."""
+    F = np.float32
+    H, W = depth.shape
+    ax = lambda v: np.array(list(v), dtype=F)
+    def axes(c):
+        return ax(c.x_axis), ax(c.y_axis), ax(c.z_axis)
+    xs, ys = np.meshgrid(np.arange(W, dtype=F), np.arange(H, dtype=F))
+    tana_now = F(cam_now.tan_half_fov)
+    dx = ((xs + F(0.5)) / F(W) - F(0.5)) * tana_now
+    dy = ((ys + F(0.5)) / F(H) - F(0.5)) * (-tana_now / F(cam_now.aspect_ratio))
+    xa, ya, za = axes(cam_now)
+    d = dx[..., None] * xa + dy[..., None] * ya + za
+    d = d * (F(1) / np.sqrt((d * d).sum(-1, dtype=F)))[..., None]
+    space = ax(cam_now.position) + d * depth[..., None]
+    rel = space - ax(cam_prev.position)
+    pxa, pya, pza = axes(cam_prev)
+    lx, ly, lz = (rel * pxa).sum(-1, dtype=F), (rel * pya).sum(-1, dtype=F), (rel * pza).sum(-1, dtype=F)
+    tana = F(cam_prev.tan_half_fov)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        fx = ((lx / lz) / tana + F(0.5)) * F(W)
+        fy = ((ly / lz) / (-tana / F(cam_prev.aspect_ratio)) + F(0.5)) * F(H)
+    ok = (lz > 0) & (fx >= 0) & (fx < W) & (fy >= 0) & (fy < H)
+    sx, sy = np.where(ok, fx, 0).astype(np.int64), np.where(ok, fy, 0).astype(np.int64)
+    dist = np.sqrt((rel * rel).sum(-1, dtype=F))
+    ok &= np.abs(dist - prev_depth[sy, sx]) < F(0.01) * dist
+    out = first.copy()
+    out[ok] = first[ok] + prev_accum[sy, sx][ok] * F(blend)
+    safe = (np.abs(fx - np.round(fx)) > 1e-3) & (np.abs(fy - np.round(fy)) > 1e-3) | ~np.isfinite(fx)
+    near_threshold = np.abs(np.abs(dist - prev_depth[sy, sx]) - F(0.01) * dist) < 1e-4 * dist
+    return out, safe & ~near_threshold, ok
+
+
+@pytest.mark.parametrize("pipeline", [-1, 1])
+def test_reprojection_of_an_unchanged_view_adds_the_blended_history(pipeline):
+    """A restart with nothing moved: every pixel finds itself, so the new accumulator is exactly first pass + blend x old accumulator
+    (sample counts included) — in the resident and in the split pipeline; without the flag a restart starts from nothing."""
+    from rayzath_amd.engine import COMPAT_REPROJECTION
+    world = scenes.cornell_sphere(96, 64, 12)
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(tracing=Tracing(5, 4)).struct()
+
+    def context(flags):
+        c = Context(0)
+        c.set_pipeline(pipeline), c.set_mode(flags)
+        c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+        return c
+
+    fresh = context(0)
+    fresh.render(1)
+    first = fresh.read_accum()
+    ctx = context(COMPAT_REPROJECTION)
+    ctx.set_temporal_blend(0.6)
+    ctx.render(1), ctx.render(7)
+    old = ctx.read_accum()
+    fresh.render(7)
+    assert np.array_equal(old, fresh.read_accum())                      # the flag alone changes nothing while a frame accumulates
+    ctx.reset()
+    ctx.render(1)
+    got = ctx.read_accum()
+    assert np.array_equal(got, first + old * np.float32(0.6))
+    assert got[..., 3].min() >= np.float32(0.6) * old[..., 3].min() and old[..., 3].max() > 0
+    ctx.render(3)                                                        # accumulation goes on from there
+    fresh2 = context(0)
+    fresh2.render(1), fresh2.render(3)
+    assert np.allclose(ctx.read_accum() - old * np.float32(0.6), fresh2.read_accum(), rtol=1e-5, atol=1e-4)
+    plain = context(0)
+    plain.render(8), plain.reset(), plain.render(1)
+    assert np.array_equal(plain.read_accum(), first)
+
+
+def test_reprojection_follows_a_moved_camera():
+    """The camera steps sideways and turns a little: history comes from where the surface WAS on the previous screen, and only where
+    the previous depth buffer holds the same surface.  Against a numpy restatement of Camera::reproject on the frames read back."""
+    from rayzath_amd.engine import COMPAT_REPROJECTION
+    world = scenes.cornell_sphere(128, 96, 12)
+    flat = flatten(world)
+    cam_prev = camera_struct(world.camera)
+    moved = Camera(position=tuple(np.asarray(world.camera.position) + np.array([0.25, 0.1, 0.05], dtype=np.float32)),
+                   rotation=tuple(np.asarray(world.camera.rotation) + np.array([0.02, -0.06, 0.0], dtype=np.float32)),
+                   resolution=(world.camera.width, world.camera.height), fov=world.camera.fov, near_far=world.camera.near_far,
+                   focal_distance=world.camera.focal_distance, aperture=world.camera.aperture, exposure_time=world.camera.exposure_time)
+    cam_now = camera_struct(moved)
+    cfg = RenderConfig(tracing=Tracing(5, 4)).struct()
+    ctx = Context(0)
+    ctx.set_mode(COMPAT_REPROJECTION)
+    ctx.upload_scene(flat), ctx.upload_camera(cam_prev), ctx.set_config(cfg)
+    ctx.render(1), ctx.render(5)
+    prev_accum, prev_depth = ctx.read_accum(), ctx.read_depth()
+    ctx.upload_camera(cam_now)                                           # restarts accumulation
+    ctx.render(1)
+    got, depth = ctx.read_accum(), ctx.read_depth()
+    fresh = Context(0)
+    fresh.upload_scene(flat), fresh.upload_camera(cam_now), fresh.set_config(cfg)
+    fresh.render(1)
+    first = fresh.read_accum()
+    assert np.array_equal(depth, fresh.read_depth())
+    want, safe, took = _host_reprojection(first, depth, prev_accum, prev_depth, cam_now, cam_prev, 0.75)
+    carried = took.mean()
+    print(f"reprojection: history carried over on {carried:.3f} of the pixels, {safe.mean():.3f} decided clear of a rounding")
+    assert 0.5 < carried < 0.98                                          # most of the view is still there, the newly uncovered part is not
+    close = np.abs(got - want) <= 1e-4 * np.maximum(np.abs(want), 1.0)
+    assert close[safe].all(-1).mean() >= 0.999
+    assert (got[took][..., 3] > first[took][..., 3]).mean() > 0.9 and (got[~took][..., 3] <= 1.0).all()   # sample counts travel with the colour
