@@ -427,6 +427,29 @@ RZ_DEV float vmax3(float a, float b, float c) {
 }
 // BoundingBox::rayIntersection (render_parts.cpp:197-217) on a prepared ray.  The box comes as the
 // device stores it: b0 = (min.x, max.x, min.y, max.y), b1.xy = (min.z, max.z).
+// The same test with the six quotients computed one by one (the same instruction sequence per quotient, unpacked): for the
+// world-level tests of the cooperative walk — a handful per ray — where keeping the ray's components as register PAIRS for the
+// packed form costs more (18 VGPRs live across the whole kernel) than the few extra instructions.
+template <bool SHARED_RCP>
+RZ_DEV bool box_hit_unpacked(float4 b0, float4 b1, const WalkRay& r) {
+    if (SHARED_RCP && __all(r.fast)) {  // wave-uniform branch
+        const float t1 = div_shared(b0.x - r.o.x, r.d.x, r.y.x), t2 = div_shared(b0.y - r.o.x, r.d.x, r.y.x);
+        const float t3 = div_shared(b0.z - r.o.y, r.d.y, r.y.y), t4 = div_shared(b0.w - r.o.y, r.d.y, r.y.y);
+        const float t5 = div_shared(b1.x - r.o.z, r.d.z, r.y.z), t6 = div_shared(b1.y - r.o.z, r.d.z, r.y.z);
+        const float tmin = vmax3(vmin(t1, t2), vmin(t3, t4), vmin(t5, t6));
+        const float tmax = vmin3(vmax(t1, t2), vmax(t3, t4), vmax(t5, t6));
+        return !(tmax < r.near_ || tmin > tmax || tmin > r.far_);
+    }
+    const float t1 = (b0.x - r.o.x) / r.d.x;
+    const float t2 = (b0.y - r.o.x) / r.d.x;
+    const float t3 = (b0.z - r.o.y) / r.d.y;
+    const float t4 = (b0.w - r.o.y) / r.d.y;
+    const float t5 = (b1.x - r.o.z) / r.d.z;
+    const float t6 = (b1.y - r.o.z) / r.d.z;
+    const float tmin = max_gt(max_gt(min_lt(t1, t2), min_lt(t3, t4)), min_lt(t5, t6));
+    const float tmax = min_lt(min_lt(max_gt(t1, t2), max_gt(t3, t4)), max_gt(t5, t6));
+    return !(tmax < r.near_ || tmin > tmax || tmin > r.far_);
+}
 template <bool SHARED_RCP>
 RZ_DEV bool box_hit(float4 b0, float4 b1, const WalkRay& r) {
     if (SHARED_RCP && __all(r.fast)) {  // wave-uniform branch
@@ -491,7 +514,7 @@ RZ_DEV float to_local(const InstanceXform& x, const WalkRay& g, WalkRay& l, bool
 }
 
 // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352
-template <bool COUNT, bool RCP>
+template <bool COUNT, bool RCP, bool PACKED = true>
 RZ_DEV bool closest_in_mesh_stack(const DScene& s, LdsStack& w, uint32_t root, WalkRay& lr, Hit& hit, Counters& cnt) {
     bool found = false;
     const uint32_t base = w.mark();
@@ -501,7 +524,7 @@ RZ_DEV bool closest_in_mesh_stack(const DScene& s, LdsStack& w, uint32_t root, W
         const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
         RZ_PHASE(3);
         RZ_COUNT(box_tests);
-        if (box_hit<RCP>(n0, n1, lr)) {
+        if (PACKED ? box_hit<RCP>(n0, n1, lr) : box_hit_unpacked<RCP>(n0, n1, lr)) {
             const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
             if (!(meta & HIPRZ_NODE_LEAF)) {
                 n = w.descend(begin);
@@ -710,7 +733,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
                 load_instance_box(s, inst, ib0, ib1);
                 RZ_PHASE(1);
                 RZ_COUNT(box_tests);
-                if (box_hit<RCP>(ib0, ib1, g)) {
+                if (box_hit_unpacked<RCP>(ib0, ib1, g)) {
                     cand = inst;
                     break;
                 }
@@ -720,7 +743,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
             const float4 n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1];
             RZ_PHASE(0);
             RZ_COUNT(box_tests);
-            if (box_hit<RCP>(n0, n1, g)) {
+            if (box_hit_unpacked<RCP>(n0, n1, g)) {
                 const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
                 if (!(meta & HIPRZ_NODE_LEAF)) {
                     n = world.descend(begin);
@@ -772,7 +795,7 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
             const float len = to_local<RCP>(x, w, lr, scene_fast);
             LdsStack mesh(mesh_column);
             Hit h;
-            if (closest_in_mesh_stack<COUNT, RCP>(s, mesh, x.blas_root, lr, h, cnt)) {
+            if (closest_in_mesh_stack<COUNT, RCP, false>(s, mesh, x.blas_root, lr, h, cnt)) {  // single-leaf meshes: one box test per visit
                 lds.ray[6 * 256 + src] = lr.near_ / len;
                 lds.ray[7 * 256 + src] = lr.far_ / len;
                 lds.hit[0 * 256 + src] = h.triangle;
@@ -1094,7 +1117,7 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
             fetch_node_ordered(s, n, 0u, n0, n1, link);  // the world tree keeps the reference's order
             RZ_PHASE(0);
             RZ_COUNT(box_tests);
-            if (box_hit<RCP>(n0, n1, g)) {
+            if (box_hit_unpacked<RCP>(n0, n1, g)) {
                 const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
                 if (!(meta & HIPRZ_NODE_LEAF)) n = begin, descended = true;
                 else i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
@@ -1111,7 +1134,7 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
                 load_instance_box(s, inst, ib0, ib1);
                 RZ_PHASE(1);
                 RZ_COUNT(box_tests);
-                enter = box_hit<RCP>(ib0, ib1, g);
+                enter = box_hit_unpacked<RCP>(ib0, ib1, g);
                 i += 1u;
             }
             if (!__any(enter)) continue;
@@ -1267,7 +1290,7 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
             fetch_node_ordered(s, n, 0u, n0, n1, link);
             RZ_COUNT(box_tests);
             RZ_COUNT(shadow_box_tests);
-            if (box_hit<RCP>(n0, n1, g)) {
+            if (box_hit_unpacked<RCP>(n0, n1, g)) {
                 const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
                 if (!(meta & HIPRZ_NODE_LEAF)) n = begin, descended = true;
                 else i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
@@ -1284,7 +1307,7 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
                 load_instance_box(s, inst, ib0, ib1);
                 RZ_COUNT(box_tests);
                 RZ_COUNT(shadow_box_tests);
-                enter = box_hit<RCP>(ib0, ib1, g);
+                enter = box_hit_unpacked<RCP>(ib0, ib1, g);
                 i += 1u;
             }
             if (!__any(enter)) continue;

@@ -16,7 +16,8 @@ void launch_trace_t(hiprz_ctx* c, const DFrame& f) {
         if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) || c->scene_tree != HIPRZ_TREE_REFERENCE) {
             // front-to-back mesh walks on per-octant skip links with the cooperative triangle phase; 4 waves per SIMD for every
             // tree size (D: 1 037 us against 1 131 us with 6 waves)
-            if (c->trace_waves >= 6) hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 6>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
+            if (c->trace_waves == 5) hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 5>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
+            else if (c->trace_waves >= 6) hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 6>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
             else hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 4>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
         } else {
             // the reference's child order (what the work counters are anchored on), tree tops cached in LDS: 160 KiB over 24 (6 waves
