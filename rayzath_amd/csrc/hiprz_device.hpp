@@ -431,14 +431,14 @@ RZ_DEV float vmax3(float a, float b, float c) {
 // world-level tests of the cooperative walk — a handful per ray — where keeping the ray's components as register PAIRS for the
 // packed form costs more (18 VGPRs live across the whole kernel) than the few extra instructions.
 template <bool SHARED_RCP>
-RZ_DEV bool box_hit_unpacked(float4 b0, float4 b1, const WalkRay& r) {
+RZ_DEV void box_range_unpacked(float4 b0, float4 b1, const WalkRay& r, float& tmin, float& tmax) {
     if (SHARED_RCP && __all(r.fast)) {  // wave-uniform branch
         const float t1 = div_shared(b0.x - r.o.x, r.d.x, r.y.x), t2 = div_shared(b0.y - r.o.x, r.d.x, r.y.x);
         const float t3 = div_shared(b0.z - r.o.y, r.d.y, r.y.y), t4 = div_shared(b0.w - r.o.y, r.d.y, r.y.y);
         const float t5 = div_shared(b1.x - r.o.z, r.d.z, r.y.z), t6 = div_shared(b1.y - r.o.z, r.d.z, r.y.z);
-        const float tmin = vmax3(vmin(t1, t2), vmin(t3, t4), vmin(t5, t6));
-        const float tmax = vmin3(vmax(t1, t2), vmax(t3, t4), vmax(t5, t6));
-        return !(tmax < r.near_ || tmin > tmax || tmin > r.far_);
+        tmin = vmax3(vmin(t1, t2), vmin(t3, t4), vmin(t5, t6));
+        tmax = vmin3(vmax(t1, t2), vmax(t3, t4), vmax(t5, t6));
+        return;
     }
     const float t1 = (b0.x - r.o.x) / r.d.x;
     const float t2 = (b0.y - r.o.x) / r.d.x;
@@ -446,8 +446,13 @@ RZ_DEV bool box_hit_unpacked(float4 b0, float4 b1, const WalkRay& r) {
     const float t4 = (b0.w - r.o.y) / r.d.y;
     const float t5 = (b1.x - r.o.z) / r.d.z;
     const float t6 = (b1.y - r.o.z) / r.d.z;
-    const float tmin = max_gt(max_gt(min_lt(t1, t2), min_lt(t3, t4)), min_lt(t5, t6));
-    const float tmax = min_lt(min_lt(max_gt(t1, t2), max_gt(t3, t4)), max_gt(t5, t6));
+    tmin = max_gt(max_gt(min_lt(t1, t2), min_lt(t3, t4)), min_lt(t5, t6));
+    tmax = min_lt(min_lt(max_gt(t1, t2), max_gt(t3, t4)), max_gt(t5, t6));
+}
+template <bool SHARED_RCP>
+RZ_DEV bool box_hit_unpacked(float4 b0, float4 b1, const WalkRay& r) {
+    float tmin, tmax;
+    box_range_unpacked<SHARED_RCP>(b0, b1, r, tmin, tmax);
     return !(tmax < r.near_ || tmin > tmax || tmin > r.far_);
 }
 template <bool SHARED_RCP>
@@ -691,9 +696,33 @@ struct BinnedLds {  // per-workgroup workspace carved from dynamic LDS (256 lane
     }
 };
 
+// Worlds whose tree is ONE leaf (up to 8 instances: a Cornell box).  The reference tests every instance box of a leaf, one after the
+// other, each against the range as it is when the walk gets there (cpu_engine_kernel.cpp:299-305).  Only `tmin > far` depends on
+// what was hit before, and `tmax < near` on a near end that moves by a rounding at most (a hit rescales it through the instance's
+// length factor and back): so all the boxes are tested ONCE, up front, at full lane utilisation — bit k of the mask = "tmax >= near
+// and tmin <= tmax", tm[k] = tmin — and a round only compares tm[k] with the far end as it is then.  The same verdicts as the
+// one-by-one walk, the same count of box tests; the divergent per-lane search of the next candidate (a wave iterates as often as
+// its slowest lane) becomes eight uniform tests and a few compares per round.
+template <bool COUNT, bool RCP>
+RZ_DEV uint32_t pretest_leaf_instances(const DScene& s, uint32_t begin, uint32_t count, uint32_t from_k, const WalkRay& g, float (&tm)[8], bool counting, Counters& cnt) {
+    uint32_t mask = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) {
+        if (k < count && k >= from_k) {
+            float4 ib0, ib1;
+            load_instance_box(s, s.tlas_order[begin + k], ib0, ib1);
+            float tmin, tmax;
+            box_range_unpacked<RCP>(ib0, ib1, g, tmin, tmax);
+            if (counting) { RZ_PHASE(1); RZ_COUNT(box_tests); }
+            if (!(tmax < g.near_ || tmin > tmax)) mask |= 1u << k, tm[k] = tmin;
+        }
+    }
+    return mask;
+}
+
 // Must be called by ALL 256 threads of the workgroup (it contains barriers); `active` = this lane
 // carries a ray.  Returns 0 / 1 / 2 like closest_hit().
-template <bool COUNT, bool RCP>
+template <bool COUNT, bool RCP, bool FLAT = false>  // FLAT: the host guarantees a one-leaf world tree (<= 8 instances)
 __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char* workspace, bool active, Ray& ray, Hit& hit,
                                                   Counters& cnt) {
     const uint32_t tid = threadIdx.x;
@@ -717,6 +746,20 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
     uint32_t leaf_i = 0, leaf_end = 0;
     bool root_missed = false;
     uint32_t round = 0u;
+    // a world of one leaf: its instance boxes are tested up front (pretest_leaf_instances)
+    const float4 root1 = s.nodes[2 * s.tlas_root + 1];
+    const uint32_t flat_begin = __float_as_uint(root1.z), flat_count = __float_as_uint(root1.w) & HIPRZ_NODE_COUNT_MASK;
+    const bool flat_world = FLAT;  // compile-time: the general world walk below drops out of the FLAT instantiation
+    float tm[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    uint32_t flat_mask = 0u, flat_next = 0u;
+    float flat_near = g.near_;
+    if (flat_world && active) {
+        const float4 root0 = s.nodes[2 * s.tlas_root];
+        RZ_PHASE(0);
+        RZ_COUNT(box_tests);
+        if (box_hit_unpacked<RCP>(root0, root1, g)) flat_mask = pretest_leaf_instances<COUNT, RCP>(s, flat_begin, flat_count, 0u, g, tm, true, cnt);
+        else root_missed = true;
+    }
     if (tid < 128u) lds.bins[tid] = 0u;
     __syncthreads();
 
@@ -725,6 +768,29 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
         // A. advance this ray to its next candidate instance (traverseWorld, cpu_engine_kernel.cpp:254-277, 305)
         RZ_PHASE(5);
         uint32_t cand = RZ_BIN_NONE;
+        if (flat_world) {
+            if (__any(flat_mask != 0u && __float_as_uint(g.near_) != __float_as_uint(flat_near))) {
+                // rare: a hit moved the near end by a rounding — the boxes not yet visited are tested again with it (the ray comes
+                // back from its LDS slot; the tests were counted the first time)
+                if (flat_mask != 0u && __float_as_uint(g.near_) != __float_as_uint(flat_near)) {
+                    WalkRay t;
+                    t.o = V3(lds.ray[0 * 256 + tid], lds.ray[1 * 256 + tid], lds.ray[2 * 256 + tid]);
+                    t.d = V3(lds.ray[3 * 256 + tid], lds.ray[4 * 256 + tid], lds.ray[5 * 256 + tid]);
+                    t.near_ = g.near_, t.far_ = g.far_;
+                    prepare<RCP>(t, scene_fast);
+                    flat_mask = pretest_leaf_instances<COUNT, RCP>(s, flat_begin, flat_count, flat_next, t, tm, false, cnt);
+                    flat_near = g.near_;
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) {
+                if (cand == RZ_BIN_NONE && k >= flat_next && ((flat_mask >> k) & 1u)) {
+                    flat_next = k + 1u;
+                    if (!(tm[k] > g.far_)) cand = s.tlas_order[flat_begin + k];
+                }
+            }
+            if (cand == RZ_BIN_NONE) flat_mask = 0u;
+        } else
         while (true) {
             RZ_GUARD(guard);
             if (leaf_i < leaf_end) {

@@ -68,10 +68,13 @@ RZ_DEV void load_path(const DFrame& f, const DCamera& cam, const PixelId& p, Pat
 }
 
 // closest hit of the segment with the selected walk; MODE 2 must be reached by all 256 threads
+// MODE 4 = MODE 2 for a world tree of ONE leaf with at most 8 instances (the host checks it at upload): the instantiation without the
+// general world walk, whose state would only cost registers (closest_hit_binned<..., FLAT>)
+constexpr bool binned_mode(int mode) { return mode == 2 || mode == 4; }
 template <int MODE, bool COUNT, bool RCP>
 RZ_DEV int trace_path(const DScene& s, unsigned char* workspace, uint32_t* lds_column, bool active, Ray& ray, Hit& hit, Counters& cnt) {
-    if constexpr (MODE == 2) {
-        return closest_hit_binned<COUNT, RCP>(s, workspace, active, ray, hit, cnt);
+    if constexpr (binned_mode(MODE)) {
+        return closest_hit_binned<COUNT, RCP, MODE == 4>(s, workspace, active, ray, hit, cnt);
     } else {
         hit.instance = -1, hit.triangle = 0, hit.bx = hit.by = 0.0f, hit.external = true;
         return active ? closest_hit<MODE, COUNT, RCP>(s, lds_column, ray, hit, cnt) : 0;
@@ -245,7 +248,7 @@ RZ_DEV void flush_counters(const DFrame& f, uint32_t segments, const Counters& c
 // BinnedLds and its stack columns double as the LDS stack of the shadow rays; otherwise it is the stack.
 template <int MODE>
 RZ_DEV uint32_t* stack_column(unsigned char* workspace) {
-    return reinterpret_cast<uint32_t*>(MODE == 2 ? workspace + BinnedLds::kFixedBytes : workspace) + threadIdx.x;
+    return reinterpret_cast<uint32_t*>(binned_mode(MODE) ? workspace + BinnedLds::kFixedBytes : workspace) + threadIdx.x;
 }
 
 // ---- fused pipeline ----
@@ -261,7 +264,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_pass_kernel(const DScene
     load_path<FIRST>(f, cam, p, ps);
     Hit hit;
     int found;
-    if constexpr (MODE == 2) {  // what the walk does not read is parked in LDS meanwhile
+    if constexpr (binned_mode(MODE)) {  // what the walk does not read is parked in LDS meanwhile
         // 4 KiB behind the binned walk's workspace (launch_pass adds them to the fused kernel's LDS size)
         uint32_t* park = reinterpret_cast<uint32_t*>(workspace + BinnedLds::kFixedBytes + (s.world_stack_entries + s.mesh_stack_entries) * 1024u);
         park[0 * 256 + threadIdx.x] = __float_as_uint(ps.color.r), park[1 * 256 + threadIdx.x] = __float_as_uint(ps.color.g);
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(256, WAVES) rz_batch_kernel(const DScene scene
         }
         Hit hit;
         int found;
-        if constexpr (MODE == 2) {
+        if constexpr (binned_mode(MODE)) {
             park[0 * 256] = __float_as_uint(ps.color.r), park[1 * 256] = __float_as_uint(ps.color.g);
             park[2 * 256] = __float_as_uint(ps.color.b), park[3 * 256] = ps.material | (ps.depth << 16);
             found = trace_path<MODE, COUNT, RZ_BATCH_SHARED_RCP != 0>(s, workspace, lds_column, p.active, ps.ray, hit, cnt);

@@ -17,7 +17,8 @@ void launch_fused_t(hiprz_ctx* c, const DFrame& f) {
     // the fused kernel's shadow rays use the stack walk: its columns must exist in every mode
     const size_t lds = g.mode == 2 ? g.walk_lds + 4096u : g.walk_lds;  // mode 2: + the parked path state
     if (g.mode == 2) {
-        if (g.lds_scene) hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 2, true>), g.grid, g.block, g.blob + lds, c->stream, c->dscene, c->dcamera, cfg, f);
+        if (g.lds_scene && c->flat_world) hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 4, true>), g.grid, g.block, g.blob + lds, c->stream, c->dscene, c->dcamera, cfg, f);
+        else if (g.lds_scene) hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 2, true>), g.grid, g.block, g.blob + lds, c->stream, c->dscene, c->dcamera, cfg, f);
         else hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 2, false>), g.grid, g.block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
     } else {
         if (g.lds_scene) hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 1, true>), g.grid, g.block, g.blob + lds, c->stream, c->dscene, c->dcamera, cfg, f);
@@ -47,7 +48,8 @@ void launch_batch_t(hiprz_ctx* c, const DFrame& f, uint32_t n) {
         else hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, 1>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);     \
     } while (0)
     if (g.mode == 2) {
-        if (g.lds_scene) RZ_BATCH(2, true);
+        if (g.lds_scene && c->flat_world) RZ_BATCH(4, true);  // a one-leaf world: instance boxes tested up front
+        else if (g.lds_scene) RZ_BATCH(2, true);
         else RZ_BATCH(2, false);
     } else {
         if (g.lds_scene) RZ_BATCH(1, true);

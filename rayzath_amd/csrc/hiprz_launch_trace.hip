@@ -28,7 +28,8 @@ void launch_trace_t(hiprz_ctx* c, const DFrame& f) {
             else hipLaunchKernelGGL((rz_trace_skip_kernel<FIRST, COUNT, 4>), grid, block, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, f, top_n);
         }
     } else if (g.mode == 2) {
-        if (g.lds_scene) hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 2, true>), g.grid, g.block, g.blob + g.walk_lds, c->stream, c->dscene, c->dcamera, f);
+        if (g.lds_scene && c->flat_world) hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 4, true>), g.grid, g.block, g.blob + g.walk_lds, c->stream, c->dscene, c->dcamera, f);
+        else if (g.lds_scene) hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 2, true>), g.grid, g.block, g.blob + g.walk_lds, c->stream, c->dscene, c->dcamera, f);
         else hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 2, false>), g.grid, g.block, g.walk_lds, c->stream, c->dscene, c->dcamera, f);
     } else {
         if (g.lds_scene) hipLaunchKernelGGL((rz_trace_kernel<FIRST, COUNT, 1, true>), g.grid, g.block, g.blob + g.walk_lds, c->stream, c->dscene, c->dcamera, f);
