@@ -1744,22 +1744,30 @@ RZ_DEV v3 sample_direction(v3 ray_d, uint32_t& ray_material, Surface& sf, Rng& r
         sf.tint_factor = sf.metalness;
         return vO;
     }
-    if (rng.unsignedUniform() > sf.reflectance) {
-        const float u1 = rng.unsignedUniform();
-        const float u2 = rng.unsignedUniform();
-        v3 vO = cosine_sample_hemisphere(u1, u2, sf.mapped_normal);
-        const float d = similarity(vO, sf.normal);
-        if (d < 0.0f) vO = vO + (sf.normal * -2.0f) * d;
-        sf.tint_factor = 1.0f;
-        return vO;
-    }
+    // diffuse (cosine_sample_hemisphere) or glossy (sample_hemisphere around the normal, then a mirror reflection about that half
+    // vector): a wave nearly always holds both kinds (a dielectric reflects a few percent of its rays), so what the two have in
+    // common — the draws, the tangent frame, sincosf(phi), the combination, the flip above the surface — is spelled ONCE, outside the
+    // branch; each lane's operations and their order are those of its own formula (cpu_render_utils.cpp:45-104).
+    const bool diffuse = rng.unsignedUniform() > sf.reflectance;
     const float u1 = rng.unsignedUniform();
     const float u2 = rng.unsignedUniform();
-    const v3 vH = sample_hemisphere(u1, 1.0f - RZ_POWF(u2 + 1.0e-5f, sf.roughness), sf.mapped_normal);
-    v3 vO = reflect_vector(ray_d, vH);
+    float s_xy, c_z;
+    if (diffuse) {
+        s_xy = sqrtf(u2), c_z = sqrtf(1.0f - u2);
+    } else {
+        const float theta = RZ_ACOSF(1.0f - 2.0f * ((1.0f - RZ_POWF(u2 + 1.0e-5f, sf.roughness)) * 0.5f));
+        RZ_SINCOSF(theta, s_xy, c_z);
+    }
+    v3 vX, vY;
+    local_coordinate(sf.mapped_normal, vX, vY);
+    const float phi = u1 * 6.283185f;
+    float sin_phi, cos_phi;
+    RZ_SINCOSF(phi, sin_phi, cos_phi);
+    const v3 around = (((vX * s_xy) * cos_phi) + ((vY * s_xy) * sin_phi)) + sf.mapped_normal * c_z;
+    v3 vO = diffuse ? around : reflect_vector(ray_d, around);
     const float d = similarity(vO, sf.normal);
     if (d < 0.0f) vO = vO + (sf.normal * -2.0f) * d;
-    sf.tint_factor = sf.metalness;
+    sf.tint_factor = diffuse ? 1.0f : sf.metalness;
     return vO;
 }
 
