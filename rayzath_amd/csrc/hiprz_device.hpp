@@ -1062,12 +1062,13 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
 typedef float f4 __attribute__((ext_vector_type(4)));  // a native vector: loads / stores through address-space-qualified pointers
 RZ_DEV f4 F4(float x, float y, float z, float w) { return f4{x, y, z, w}; }
 struct CoopLds {  // LDS-qualified pointers: ds_read / ds_write, not flat accesses
-    RZ_LDS f4* rec;       // [3][128] by entry: (o.xyz, near), (d.xyz, far), bits(first triangle, count <= 4, held triangle + 1 or 0, -)
+    RZ_LDS f4* rec;       // [3][128] by entry: (o.xyz, near), (d.xyz, far), bits(first triangle, count <= 4, held triangle + 1 or 0, R)
     RZ_LDS f4* res;       // [128]    by entry: bits(t) or ~0 = no hit, bits(triangle | external << 31), b1, b2
-    RZ_LDS uint32_t* ref; // [128]    by entry: the winner's position in the reference's leaf order
-    static constexpr uint32_t kEntries = 128u, kBytes = 4u * kEntries * 16u + kEntries * 4u;
-    RZ_DEV explicit CoopLds(unsigned char* base)
-        : rec((RZ_LDS f4*)base), res((RZ_LDS f4*)(base + 3u * kEntries * 16u)), ref((RZ_LDS uint32_t*)(base + 4u * kEntries * 16u)) {}
+    // R: the winner's position in the reference's leaf order, written by the winning tester after the entry's four lanes have read the
+    // record (one wave: LDS operations complete in issue order).  8 KiB per wave: twenty single-wave workgroups fill a CU's 160 KiB.
+    static constexpr uint32_t kEntries = 128u, kBytes = 4u * kEntries * 16u;
+    RZ_DEV explicit CoopLds(unsigned char* base) : rec((RZ_LDS f4*)base), res((RZ_LDS f4*)(base + 3u * kEntries * 16u)) {}
+    RZ_DEV RZ_LDS uint32_t* ref(uint32_t e) const { return (RZ_LDS uint32_t*)(rec + 2u * kEntries + e) + 3; }
 };
 // Hand-over points of the cooperative phase: the LDS unit executes a wave's instructions in issue order, so a fence that keeps the
 // compiler from moving LDS accesses across it is all one wave needs (the workgroup IS one wave).
@@ -1140,16 +1141,16 @@ RZ_DEV void coop_closest_triangles(const DScene& s, const CoopLds& lds, bool hol
         const uint32_t first = quad_min(candidate ? refpos : 0xFFFFFFFFu);  // among equal distances: the one the reference meets first
         if (candidate && refpos == first) {
             lds.res[e] = F4(__uint_as_float(tbits), __uint_as_float(tri | (det > 0.0f ? 0x80000000u : 0u)), b1, b2);
-            lds.ref[e] = refpos;
+            *lds.ref(e) = refpos;
         }
     }
     rz_wave_sync();
     if (holding) {
         f4 best = lds.res[deal.pos];
-        uint32_t best_ref = lds.ref[deal.pos];
+        uint32_t best_ref = *lds.ref(deal.pos);
         if (deal.big) {
             const f4 other = lds.res[deal.pos + 1u];
-            const uint32_t other_ref = lds.ref[deal.pos + 1u];
+            const uint32_t other_ref = *lds.ref(deal.pos + 1u);
             if (__float_as_uint(other.x) < __float_as_uint(best.x) || (__float_as_uint(other.x) == __float_as_uint(best.x) && __float_as_uint(other.x) != 0xFFFFFFFFu && other_ref < best_ref))
                 best = other, best_ref = other_ref;
         }
@@ -1230,7 +1231,7 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
                         fetch_node_ordered(s, m, oct, m0, m1, mlink);
                         RZ_PHASE(3);
                         RZ_COUNT(box_tests);
-                        if (box_hit<RCP>(m0, m1, lr)) {
+                        if (box_hit_unpacked<RCP>(m0, m1, lr)) {
                             const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                             if (!(mmeta & HIPRZ_NODE_LEAF)) mlink = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);  // enter the nearer child first
                             else tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
@@ -1397,7 +1398,7 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
                         fetch_node_ordered(s, m, oct, m0, m1, mlink);
                         RZ_COUNT(box_tests);
                         RZ_COUNT(shadow_box_tests);
-                        if (box_hit<RCP>(m0, m1, lr)) {
+                        if (box_hit_unpacked<RCP>(m0, m1, lr)) {
                             const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                             if (!(mmeta & HIPRZ_NODE_LEAF)) mlink = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);
                             else tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);

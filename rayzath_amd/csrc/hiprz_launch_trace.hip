@@ -14,10 +14,12 @@ void launch_trace_t(hiprz_ctx* c, const DFrame& f) {
         // one wave per workgroup: a workgroup's slot is free as soon as ITS slowest ray is done
         const dim3 grid(c->n_local_tiles * 4u), block(64);
         if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) || c->scene_tree != HIPRZ_TREE_REFERENCE) {
-            // front-to-back mesh walks on per-octant skip links with the cooperative triangle phase; 4 waves per SIMD for every
-            // tree size (D: 1 037 us against 1 131 us with 6 waves)
-            if (c->trace_waves == 5) hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 5>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
-            else if (c->trace_waves >= 6) hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 6>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
+            // front-to-back mesh walks on per-octant skip links with the cooperative triangle phase.  Register budget: 112 VGPRs are what
+            // the kernel wants (4 waves per SIMD, no scratch); trees that do not live in L1 / L2 are bound by the latency of their node
+            // fetches and take a fifth wave at the price of 52 B of scratch (D: 1 014 -> 964 us; C 342 -> 351, E 3 082 -> 3 279 us)
+            const int waves = c->trace_waves > 0 ? c->trace_waves : (c->n_nodes > kLatencyBoundNodes ? 5 : 4);
+            if (waves == 5) hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 5>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
+            else if (waves >= 6) hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 6>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
             else hipLaunchKernelGGL((rz_trace_coop_kernel<FIRST, COUNT, 4>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
         } else {
             // the reference's child order (what the work counters are anchored on), tree tops cached in LDS: 160 KiB over 24 (6 waves
