@@ -210,7 +210,7 @@ struct TreeCheck {
 void release_frame(hiprz_frame_state* c) {
     c->st0.release(), c->st1.release(), c->st2.release(), c->accum.release(), c->depth.release(), c->rgba8.release();
     c->hit0.release(), c->hit1.release();
-    c->nee.release();
+    c->nee.release(), c->prev_accum.release(), c->prev_depth.release();
     c->sort_keys.release(), c->sort_perm.release();
     for (auto& t : c->sort_temp) t.keys_out.release(), t.vals_a.release(), t.vals_b.release(), t.counts.release(), t.digit_total.release();
     c->shadow_keys.release(), c->shadow_perm.release();
