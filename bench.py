@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=-1, help="0 fused pass kernel, 1 trace + shade kernels, 2 resident batch kernel (-1: chosen per scene)")
     ap.add_argument("--ray-sort", type=int, default=-1, help="-1 auto, 0 off, 1 on")
     ap.add_argument("--walk-order", type=int, default=-1, help="mesh child order of the skip-link walk: 0 reference order, 1 front to back (-1: library default)")
+    ap.add_argument("--streams", type=int, default=-1, help="N = 1, after the main measurement: the same steps with the frame split over this many contexts-with-a-stream on the GPU (what the Engine hosts do by default for scenes without lights), reported as `several_streams`; -1 = the hosts' choice (rayzath_amd.engine.default_streams), 1 = skip")
     ap.add_argument("--tree", type=int, default=0, help="0 the scene's (reference) mesh trees, 1 rebuilt with a binned SAH (hiprz_set_tree; same frames, fewer tests; not the default)")
     ap.add_argument("--no-xcd-swizzle", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -210,6 +211,41 @@ def main():
         end_to_end = {"value": args.steps * RPP * W * H / e2e / 1e6, "unit": "Mrays/s", "ms_per_step": e2e / args.steps * 1e3,
                       "includes": "render + tone map + hiprz_read_rgba8 into host memory (8.3 MB per step over PCIe, synchronous)"}
         ctx.kernel_time_ms()
+    # ---- the hosts' default on one GPU (rayzath_amd.engine.default_streams, Hip::Engine::defaultStreams): the frame split over K
+    # contexts-with-a-stream on the SAME GPU (hiprz_create_multi with the device named K times) — one share's sorts, pass bookkeeping and
+    # kernel tails run beside another share's walks.  Measured with the same protocol, reported beside `value`: the roofline above
+    # belongs to whole-frame launches on one stream, which is what `value` times and what a rank of a multi-GPU job runs.
+    several_streams = None
+    from rayzath_amd.engine import default_streams
+    k_streams = args.streams if args.streams > 0 else default_streams(len(flat.spot_lights) + len(flat.direct_lights))
+    if world == 1 and k_streams > 1:
+        fast = Context([local_rank] * k_streams)
+        fast.set_traversal_mode(args.traversal)
+        if args.pipeline >= 0:
+            fast.set_pipeline(args.pipeline)
+        fast.set_ray_sort(args.ray_sort)
+        if args.walk_order >= 0:
+            fast.set_walk_order(args.walk_order)
+        if args.no_xcd_swizzle:
+            fast.set_xcd_swizzle(False)
+        fast.set_tree(args.tree)
+        fast.upload_scene(flat), fast.upload_camera(cam), fast.set_config(cfg)
+        fast.render(1)
+        for _ in range(args.warmup):
+            fast.render(RPP), fast.tonemap()
+        fast_samples = []
+        for _ in range(max(args.repeats, 1)):
+            fast.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                fast.render(RPP), fast.tonemap()
+            fast.sync()
+            fast_samples.append(time.perf_counter() - t0)
+        fast_elapsed = sorted(fast_samples)[len(fast_samples) // 2]
+        several_streams = {"streams": k_streams, "value": args.steps * RPP * W * H / fast_elapsed / 1e6, "unit": "Mrays/s",
+                           "ms_per_step": fast_elapsed / args.steps * 1e3, "repeat_seconds": fast_samples,
+                           "note": "same steps, same protocol; the frame's tiles interleaved over %d contexts on the same GPU, each with its own stream (the Engine hosts' default for scenes without lights)" % k_streams}
+        fast.close()
     rays = args.steps * RPP * W * H
     result = None
     if rank == 0:
@@ -293,6 +329,7 @@ def main():
                        "repeat_seconds": samples, "passes_timed": passes_timed, "timed_wall_seconds": timed_wall},
             "spp_per_s": spp_per_s,
             "end_to_end": end_to_end,
+            "several_streams": several_streams,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": traffic, "kernel": kernel_name, "avg_launch_us": kernel_s * 1e6,
                          "algorithmic_bytes_per_launch": kernel_bytes,

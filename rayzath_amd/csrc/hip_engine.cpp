@@ -281,8 +281,15 @@ hiprz_camera cameraRecord(const Camera& cam) {
 }
 
 // ---- Engine ----
-Engine::Engine(int device) {
-    const int rc = hiprz_create(&m_ctx, device);
+Engine::Engine(int device, int streams) : m_device(device) {
+    int rc;
+    if (streams > 1) {
+        const std::vector<int> ids(size_t(streams), device);
+        rc = hiprz_create_multi(&m_ctx, ids.data(), streams);
+    } else {
+        rc = hiprz_create(&m_ctx, device);
+        m_streams_pending = streams == 0;
+    }
     if (rc != HIPRZ_OK) throw Exception(rc, std::string("HIPGPU backend unavailable: ") + hiprz_last_error(nullptr));
 }
 Engine::Engine(const std::vector<int>& devices) {
@@ -297,10 +304,12 @@ void Engine::check(int rc) {
 void Engine::mode(uint32_t compat_flags) {
     std::lock_guard<std::mutex> lock(m_mutex);
     check(hiprz_set_mode(m_ctx, compat_flags));
+    m_mode = compat_flags;
 }
 void Engine::tree(uint32_t tree) {
     std::lock_guard<std::mutex> lock(m_mutex);
     check(hiprz_set_tree(m_ctx, tree));
+    m_tree = tree;
     m_last_world = nullptr;  // takes effect at the next scene upload: force one
 }
 
@@ -327,6 +336,20 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
         Exception e = *m_deferred;
         m_deferred.reset();
         throw e;
+    }
+    if (m_streams_pending) {  // the first world: as many streams on the GPU as suit it
+        m_streams_pending = false;
+        const int streams = defaultStreams(world);
+        if (streams > 1) {
+            hiprz_ctx* several = nullptr;
+            const std::vector<int> ids(size_t(streams), m_device);
+            if (hiprz_create_multi(&several, ids.data(), streams) == HIPRZ_OK) {
+                hiprz_destroy(m_ctx);
+                m_ctx = several;
+                check(hiprz_set_mode(m_ctx, m_mode));
+                check(hiprz_set_tree(m_ctx, m_tree));
+            }
+        }
     }
     const std::vector<Camera*> cameras = enabledCameras(world);
     if (m_pending_readback) {  // pipelined frames of the previous non-sync call

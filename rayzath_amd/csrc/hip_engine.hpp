@@ -194,8 +194,12 @@ hiprz_camera cameraRecord(const Camera& camera); // pure host
 
 class Engine {
 public:
-    explicit Engine(int device = 0);  // throws Hip::Exception: the facade then falls back to CPU (rayzath.cpp:21-28)
+    // throws Hip::Exception: the facade then falls back to CPU (rayzath.cpp:21-28).  `streams`: how many contexts-with-a-stream share
+    // the GPU (hiprz_create_multi with the device named that often: one share's sorts, bookkeeping and kernel tails run beside another
+    // share's walks); 0 = chosen when the first world is rendered — two for a world without lights, one otherwise (defaultStreams).
+    explicit Engine(int device = 0, int streams = 0);
     explicit Engine(const std::vector<int>& devices);  // one context over several GPUs: tiles interleaved, peer-to-peer gather
+    static int defaultStreams(const World& world) { return world.spot_lights.empty() && world.direct_lights.empty() ? 2 : 1; }
     void mode(uint32_t compat_flags);  // hiprz_set_mode: behaviours of the CUDA engine (default 0 = the CPU kernel)
     void tree(uint32_t tree);          // hiprz_set_tree, applied at the next scene upload
     ~Engine();
@@ -209,7 +213,10 @@ public:
     void renderWorld(World& world, const RenderConfig& render_config, bool block = true, bool sync = true);
     std::string timingsString();
 
-    hiprz_ctx* context() { return m_ctx; }  // for tests
+    hiprz_ctx* context() {  // for tests: settles the stream count as it is
+        m_streams_pending = false;
+        return m_ctx;
+    }
 
 private:
     void check(int rc);
@@ -217,6 +224,9 @@ private:
     std::vector<Camera*> enabledCameras(World& world) const;
 
     hiprz_ctx* m_ctx = nullptr;
+    int m_device = 0;
+    bool m_streams_pending = false;  // the context is still the single one of the constructor: the first world decides
+    uint32_t m_mode = 0, m_tree = 0;  // what mode() / tree() set, for the context that replaces it
     std::mutex m_mutex;  // renderWorld is serialised (cpu_engine_core.cpp:15)
     bool m_pending_readback = false;
     std::unique_ptr<Exception> m_deferred;

@@ -159,3 +159,24 @@ def test_group_transformations(built):
     ctx.upload_scene(plain), ctx.upload_camera(camera_struct(world.camera)), ctx.set_config(cfg)
     ctx.render(5)
     assert np.array_equal(ctx.read_accum(), frames["cuda"])
+
+
+def test_engine_splits_a_world_without_lights_over_two_streams(built):
+    """The hosts' default on one GPU (engine.default_streams / Hip::Engine::defaultStreams): two contexts-with-a-stream for a world
+    without lights, one for a world with lights — and the frames do not depend on it."""
+    from rayzath_amd.engine import Engine, default_streams
+    assert default_streams(0) == 2 and default_streams(3) == 1
+    cfg = RenderConfig(LightSampling(1, 1), Tracing(5, 4))
+    frames = []
+    for streams in (None, 1, 3):
+        world = scenes.cornell_sphere(160, 96, 12)
+        engine = Engine(0, streams=streams)
+        engine.renderWorld(world, cfg), engine.renderWorld(world, cfg)
+        assert engine.context.device_count() == (streams or 2)
+        frames.append((world.camera.image_buffer.copy(), world.camera.depth_buffer.copy(), world.camera.ray_count))
+    for f in frames[1:]:
+        assert np.array_equal(f[0], frames[0][0]) and np.array_equal(f[1], frames[0][1]) and f[2] == frames[0][2]
+    lit = scenes.living_room(96, 64, 8)
+    engine = Engine(0)
+    engine.renderWorld(lit, cfg)
+    assert engine.context.device_count() == 1
