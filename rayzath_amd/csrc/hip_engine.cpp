@@ -303,6 +303,17 @@ void Engine::check(int rc) {
 }
 void Engine::mode(uint32_t compat_flags) {
     std::lock_guard<std::mutex> lock(m_mutex);
+    if ((compat_flags & HIPRZ_COMPAT_REPROJECTION) && m_split_by_default) {
+        // history is carried over within a share only (hiprz.h): reprojection wants the frame in ONE context
+        hiprz_ctx* single = nullptr;
+        const int rc = hiprz_create(&single, m_device);
+        if (rc != HIPRZ_OK) throw Exception(rc, hiprz_last_error(nullptr));
+        hiprz_destroy(m_ctx);
+        m_ctx = single;
+        m_split_by_default = false;
+        m_last_world = nullptr, m_camera_slots.clear(), m_pending_readback = false;
+        check(hiprz_set_tree(m_ctx, m_tree));
+    }
     check(hiprz_set_mode(m_ctx, compat_flags));
     m_mode = compat_flags;
 }
@@ -339,13 +350,14 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
     }
     if (m_streams_pending) {  // the first world: as many streams on the GPU as suit it
         m_streams_pending = false;
-        const int streams = defaultStreams(world);
+        const int streams = (m_mode & HIPRZ_COMPAT_REPROJECTION) ? 1 : defaultStreams(world);
         if (streams > 1) {
             hiprz_ctx* several = nullptr;
             const std::vector<int> ids(size_t(streams), m_device);
             if (hiprz_create_multi(&several, ids.data(), streams) == HIPRZ_OK) {
                 hiprz_destroy(m_ctx);
                 m_ctx = several;
+                m_split_by_default = true;
                 check(hiprz_set_mode(m_ctx, m_mode));
                 check(hiprz_set_tree(m_ctx, m_tree));
             }

@@ -295,10 +295,21 @@ class Engine:
             self._context = Context(self._device)
         return self._context
 
+    def set_mode(self, compat_flags):
+        """Context.set_mode for the engine's context; COMPAT_REPROJECTION keeps the frame in ONE context (history is carried over within
+        a share only)."""
+        self._mode = compat_flags
+        if compat_flags & COMPAT_REPROJECTION and self._context is not None and self._streams is None and self._context.device_count() > 1:
+            self._context.close()
+            self._context, self._world_key, self._camera_key, self._camera_ids = Context(self._device), None, {}, None
+        self.context.set_mode(compat_flags)
+
     def renderWorld(self, world, render_config, block=True, sync=True):
         if self._context is None and not isinstance(self._device, (list, tuple)):
-            k = self._streams or default_streams(len(world.spot_lights) + len(world.direct_lights))
+            k = self._streams or (1 if getattr(self, "_mode", 0) & COMPAT_REPROJECTION else default_streams(len(world.spot_lights) + len(world.direct_lights)))
             self._context = Context([self._device] * k) if k > 1 else Context(self._device)
+            if getattr(self, "_mode", 0):
+                self._context.set_mode(self._mode)
         ctx = self.context
         # the backend re-mirrors what changed and restarts accumulation then (cpu_engine_renderer.cpp:108-112)
         world_key = getattr(world, "_version", None), id(world)
