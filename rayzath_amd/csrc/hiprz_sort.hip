@@ -24,6 +24,7 @@ namespace hiprz {
 namespace {
 
 constexpr uint32_t kTile = 4096u;       // keys per workgroup (256 threads x 16 rounds)
+constexpr uint32_t kTotalCopies = 16u;  // copies of the per-digit totals the count kernel's atomics are spread over
 
 __global__ void __launch_bounds__(256) rz_radix_count_kernel(const uint32_t* keys, uint32_t n, uint32_t shift, uint32_t* counts, uint32_t n_tiles, uint32_t* digit_total) {
     __shared__ uint32_t hist[256];
@@ -38,7 +39,9 @@ __global__ void __launch_bounds__(256) rz_radix_count_kernel(const uint32_t* key
         if (base + r * 256u < n) atomicAdd(&hist[(key[r] >> shift) & 255u], 1u);
     __syncthreads();
     counts[threadIdx.x * n_tiles + blockIdx.x] = hist[threadIdx.x];  // digit-major: the counts of one digit over the tiles are contiguous
-    if (hist[threadIdx.x]) atomicAdd(&digit_total[threadIdx.x], hist[threadIdx.x]);
+    // the digit totals in kTotalCopies interleaved copies (tile t adds to copy t % kTotalCopies): two thousand tiles adding to the same 256
+    // words serialise in L2 — the offsets kernel sums the copies
+    if (hist[threadIdx.x]) atomicAdd(&digit_total[(blockIdx.x % kTotalCopies) * 256u + threadIdx.x], hist[threadIdx.x]);
 }
 
 RZ_DEV uint32_t wave_inclusive_scan(uint32_t v) {
@@ -53,7 +56,9 @@ RZ_DEV uint32_t wave_inclusive_scan(uint32_t v) {
 __global__ void __launch_bounds__(256) rz_radix_offsets_kernel(uint32_t* counts, uint32_t n_tiles, const uint32_t* digit_total) {
     __shared__ uint32_t wave_total[4];
     const uint32_t digit = blockIdx.x, tid = threadIdx.x;
-    uint32_t below = tid < digit ? digit_total[tid] : 0u;
+    uint32_t below = 0u;
+    if (tid < digit)
+        for (uint32_t k = 0; k < kTotalCopies; ++k) below += digit_total[k * 256u + tid];
     for (int off = 32; off > 0; off >>= 1) below += __shfl_down(below, off);
     if ((tid & 63u) == 0u) wave_total[tid >> 6] = below;
     __syncthreads();
@@ -90,7 +95,7 @@ __global__ void __launch_bounds__(256) rz_radix_scatter_kernel(const uint32_t* k
         else val[r] = i < n ? vals_in[i] : 0u;
     }
     run[tid] = offsets[tid * n_tiles + blockIdx.x];
-    if (blockIdx.x == 0u) digit_total[tid] = 0u;  // consumed by rz_radix_offsets_kernel; the next pass's count kernel adds to zeros
+    if (blockIdx.x < kTotalCopies) digit_total[blockIdx.x * 256u + tid] = 0u;  // consumed by rz_radix_offsets_kernel; the next pass's count kernel adds to zeros
     for (uint32_t k = tid; k < 2048u; k += 256u) (&wcount[0][0][0])[k] = 0u;
     __syncthreads();
 #pragma unroll
@@ -154,8 +159,8 @@ int sort_workspace(hiprz_ctx* c, size_t n) {
         RZ_HIP(c, t.vals_a.resize(n));  // value buffers of the middle passes
         RZ_HIP(c, t.vals_b.resize(n));
         RZ_HIP(c, t.counts.resize(n_counts));
-        RZ_HIP(c, t.digit_total.resize(256));  // keys per digit of the pass being sorted (zeroed again by its scatter kernel)
-        RZ_HIP(c, hipMemsetAsync(t.digit_total.ptr, 0, 256 * sizeof(uint32_t), c->stream));
+        RZ_HIP(c, t.digit_total.resize(256u * kTotalCopies));  // keys per digit of the pass being sorted (zeroed again by its scatter kernel)
+        RZ_HIP(c, hipMemsetAsync(t.digit_total.ptr, 0, 256u * kTotalCopies * sizeof(uint32_t), c->stream));
     }
     c->perm_valid = false;
     return HIPRZ_OK;
