@@ -140,3 +140,25 @@ def test_builder_rejects_bad_input(built):
     d = big.desc()
     tris, attrs = np.zeros(200, _abi.tri_dtype), np.zeros(200, _abi.tri_attr_dtype)
     assert lib.hiprz_build_mesh_tree(C.byref(d), nodes.ctypes.data, 3, C.byref(n), tris.ctypes.data, attrs.ctypes.data) == _abi.ERR_INVALID  # node buffer too small
+
+
+@pytest.mark.parametrize("name", ["cube", "split_33", "sphere16_no_normals", "sphere80"])
+def test_fill_triangles_equals_what_the_mesh_builder_writes(built, name):
+    """hiprz_fill_triangles — for callers that bring a tree of their own (rayzath_adapter.hpp mirrors the reference's ComponentBVH) —
+    produces for the builder's leaf order exactly the builder's records, for a subset exactly that subset, and refuses bad indices."""
+    import ctypes as C
+    from rayzath_amd import _lib
+    lib = _lib.load()
+    mesh = MESHES[name]()
+    _, tris, attrs = HostBackend().mesh_tree(mesh)
+    order = np.ascontiguousarray(tris["source_index"], dtype=np.uint32)
+    d = mesh.desc()
+    out_t, out_a = np.zeros_like(tris), np.zeros_like(attrs)
+    assert lib.hiprz_fill_triangles(C.byref(d), order.ctypes.data, len(order), out_t.ctypes.data, out_a.ctypes.data) == 0
+    assert out_t.tobytes() == tris.tobytes() and out_a.tobytes() == attrs.tobytes()
+    part = np.ascontiguousarray(order[3:9])
+    assert lib.hiprz_fill_triangles(C.byref(d), part.ctypes.data, len(part), out_t.ctypes.data, out_a.ctypes.data) == 0
+    assert out_t[:len(part)].tobytes() == tris[3:9].tobytes() and out_a[:len(part)].tobytes() == attrs[3:9].tobytes()
+    bad = np.array([len(order)], dtype=np.uint32)
+    assert lib.hiprz_fill_triangles(C.byref(d), bad.ctypes.data, 1, out_t.ctypes.data, out_a.ctypes.data) != 0
+    assert lib.hiprz_fill_triangles(C.byref(d), None, 0, None, None) == 0
