@@ -68,7 +68,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40, help="steps per timed repeat (each step = 8 passes: >= 64 passes per repeat from 8 steps on)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are repeated this many times; the line reports the median repeat")
+    ap.add_argument("--repeats", type=int, default=5, help="the K timed steps are repeated at least this many times; the line reports the median repeat")
+    ap.add_argument("--min-seconds", type=float, default=5.0, help="keep repeating the K timed steps until the repeats add up to this much timed wall (SURVEY.md 8d: >= 5 s)")
     ap.add_argument("--config", default="B", help="scene preset of rayzath_amd/scenes.py (B = the quoted config)")
     ap.add_argument("--traversal", type=int, default=-1, help="-1 per-scene choice (default), 1 nested walk with LDS stack, 2 workgroup-binned, 3 skip links (front to back, cooperative triangle phase)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather on the render stream instead of overlapping it with the next step's rendering")
@@ -84,6 +85,19 @@ def main():
                     help="N ranks share GPU 0 and talk over gloo: exercises the sharded path where only one GPU exists")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: this process touches no GPU — it starts one rank per GPU (torch.distributed.run, the
+        # launcher the contract names) as a child, lets rank 0's JSON line through on stdout and leaves with the child's exit code.
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,7 +184,8 @@ def main():
     passes_before = ctx.pass_count()
     samples = []
     t_all0 = time.perf_counter()
-    for _ in range(max(args.repeats, 1)):
+    # every rank sees the same (max-reduced) samples, so all of them stop after the same repeat
+    while len(samples) < max(args.repeats, 1) or (sum(samples) < args.min_seconds and len(samples) < 4096):
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -262,13 +277,16 @@ def main():
         walk_order = args.walk_order if args.walk_order >= 0 else 1
         front_to_back = split and ctx.traversal_mode() == 3 and walk_order != 0
         trace_bytes = lambda c: (60 * c["segments"] + 32 * (c["box_tests"] - c["shadow_box_tests"]) + 36 * (c["tri_tests"] - c["shadow_tri_tests"])) / RPP
-        traversal_kernel = reference_algorithm = None
+        traversal_kernel = reference_algorithm = eager_kernel_us = None
         if pipeline == 2 and breakdown[2]:
             # dominant (only) kernel: the resident batch kernel — one launch takes every tile through the RPP passes of the
             # step.  Algorithmic bytes: SURVEY.md §8d's per-segment figure x the segments of the launch.  It walks in the
             # reference's order: executed work == the reference algorithm's work.
             kernel_name = "rz_batch_kernel (resident: all passes of a step)"
-            kernel_s = breakdown[0] / 1e3 / (breakdown[2] / RPP)
+            # duration: the hip events the context records on its stream around EVERY render batch of the timed repeats (the batch
+            # kernel + the one-thread kernel that advances the pass index) — the launches `value` was timed on, not a separate run
+            kernel_s = kernel_ms / 1e3 / max(launches // RPP, 1)
+            eager_kernel_us = breakdown[0] / (breakdown[2] / RPP) * 1e3  # the same kernel between its own two events, after the timed region
             kernel_bytes = algorithmic_bytes(counters)
             # the BVH-traversal kernel on its own (north_star's 30 % target): the same step through the split pipeline
             ctx.set_pipeline(1)
@@ -325,13 +343,17 @@ def main():
                        "traversal": {1: "lds-stack", 2: "workgroup-binned", 3: "skip-links"}[ctx.traversal_mode()],
                        "mesh_trees": "binned SAH, rebuilt at upload" if args.tree else "reference builder (scene snapshot)",
                        "pipeline": {0: "fused (one kernel per pass)", 1: "trace+shade (two kernels per pass)", 2: "resident (one kernel per step)"}[pipeline]},
-            "timing": {"protocol": f"{len(samples)} repeats of exactly {args.steps} steps ({args.steps * RPP} passes) between barrier + synchronize fences; value = median repeat",
-                       "repeat_seconds": samples, "passes_timed": passes_timed, "timed_wall_seconds": timed_wall},
+            "timing": {"protocol": f"{len(samples)} repeats of exactly {args.steps} steps ({args.steps * RPP} passes) between barrier + synchronize fences (repeated until >= {args.min_seconds:g} s of timed wall); value = median repeat",
+                       "repeat_seconds_min_median_max": [min(samples), elapsed, max(samples)], "repeats": len(samples), "timed_seconds": sum(samples),
+                       "passes_timed": passes_timed, "timed_wall_seconds": timed_wall},
             "spp_per_s": spp_per_s,
             "end_to_end": end_to_end,
             "several_streams": several_streams,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": traffic, "kernel": kernel_name, "avg_launch_us": kernel_s * 1e6,
+                         "duration_from": ("hip events around every render batch of the timed repeats (%d launches)" % (launches // RPP)) if pipeline == 2 else
+                                          "hip events around the kernel in an eager, event-instrumented batch after the timed region (a captured graph cannot be timed from inside)",
+                         "eager_avg_launch_us": eager_kernel_us,
                          "algorithmic_bytes_per_launch": kernel_bytes,
                          "priced_on": "tests executed by the timed kernel" + (" (front-to-back walk)" if front_to_back else " (= the reference algorithm's: same visiting order)"),
                          "segments_per_launch": counters["segments"] / (1 if pipeline == 2 else RPP),

@@ -420,8 +420,19 @@ int hiprz_untile_gathered(hiprz_ctx* ctx, const void* src_parts, uint32_t world,
 int hiprz_tonemap_image(hiprz_ctx* ctx, const void* src_device_image, void* dst_device_rgba8);
 void* hiprz_stream(hiprz_ctx* ctx); /* the hipStream_t all of the above are enqueued on */
 
-/* --- picking (Kernel::rayCast, cpu_engine_kernel.cpp:102-111, 483-501) --- */
-int hiprz_pick(hiprz_ctx* ctx, uint32_t x, uint32_t y, int32_t* instance_out, int32_t* material_out);
+/* --- picking (Kernel::rayCast, cpu_engine_kernel.cpp:102-111, 483-501; Cuda: cuda_render_kernel.cu:130-144) ---
+ * The reference casts one ray per camera and frame through the camera's ray-cast pixel (Camera::getRayCastPixel), in a thin shell
+ * around the first-hit depth of that pixel, and stores the instance and the instance's material slot it met in the host camera
+ * (m_raycasted_instance / m_raycasted_material, camera.hpp:55-56; writers cpu_engine_renderer.cpp:176, cuda_engine_core.cu:164-181).
+ * hiprz_ray_cast is that query for the selected camera's current frame; both engine hosts call it after every frame. */
+typedef struct hiprz_raycast {
+    int32_t instance;      /* index into hiprz_scene::instances, -1 = nothing met */
+    int32_t material_slot; /* the triangle's material id clamped to 0..63 = the slot Instance::material(slot) is asked for, -1 = nothing met */
+    int32_t material;      /* index into hiprz_scene::materials of that slot, -1 = slot unset (or nothing met) */
+    uint32_t triangle;     /* the triangle's source_index within its mesh */
+} hiprz_raycast;
+int hiprz_ray_cast(hiprz_ctx* ctx, uint32_t x, uint32_t y, hiprz_raycast* out);
+int hiprz_pick(hiprz_ctx* ctx, uint32_t x, uint32_t y, int32_t* instance_out, int32_t* material_out); /* instance + material of hiprz_ray_cast */
 
 /* Device self-test of the kernels' exact-arithmetic shortcuts (shared-reciprocal division must
  * equal the correctly rounded quotient): runs 262144 * cases_per_thread random cases. */

@@ -95,6 +95,10 @@ class MeshDesc(C.Structure):
     ]
 
 
+class RayCast(C.Structure):  # hiprz_raycast
+    _fields_ = [("instance", C.c_int32), ("material_slot", C.c_int32), ("material", C.c_int32), ("triangle", C.c_uint32)]
+
+
 # name -> (restype, argtypes) of every entry point include/hiprz.h declares
 P = C.c_void_p
 U32, U64, SZ, I32 = C.c_uint32, C.c_uint64, C.c_size_t, C.c_int32
@@ -148,6 +152,7 @@ ENTRY_POINTS = {
     "hiprz_tonemap_image": (C.c_int, [P, P, P]),
     "hiprz_stream": (P, [P]),
     "hiprz_pick": (C.c_int, [P, U32, U32, C.POINTER(I32), C.POINTER(I32)]),
+    "hiprz_ray_cast": (C.c_int, [P, U32, U32, C.POINTER(RayCast)]),
     "hiprz_selftest": (C.c_int, [P, U32, U32, C.POINTER(U64), C.POINTER(U64)]),
     "hiprz_timings": (C.c_int, [P, C.c_char_p, SZ]),
     "hiprz_time_kernels": (C.c_int, [P, C.c_int]),

@@ -324,13 +324,23 @@ void Engine::tree(uint32_t tree) {
     m_last_world = nullptr;  // takes effect at the next scene upload: force one
 }
 
-void Engine::readback(Camera& camera) {
+void Engine::readback(Camera& camera, const World& world) {
     const size_t n = size_t(camera.width) * camera.height;
     camera.image_buffer.resize(n * 4);
     camera.depth_buffer.resize(n);
     check(hiprz_read_rgba8(m_ctx, camera.image_buffer.data(), n * 4));
     check(hiprz_read_depth(m_ctx, camera.depth_buffer.data(), n * sizeof(float)));
     check(hiprz_ray_count(m_ctx, &camera.ray_count));
+    // Kernel::rayCast after every frame (cpu_engine_renderer.cpp:176; cuda_engine_core.cu:164-181): the instance and the instance's
+    // material slot the ray through the camera's ray-cast pixel meets at the first-hit depth
+    hiprz_raycast hit{};
+    check(hiprz_ray_cast(m_ctx, camera.ray_cast_pixel[0], camera.ray_cast_pixel[1], &hit));
+    camera.raycasted_instance.reset(), camera.raycasted_material.reset();
+    if (hit.instance >= 0 && size_t(hit.instance) < world.instances.size()) {
+        camera.raycasted_instance = world.instances[size_t(hit.instance)];
+        if (hit.material_slot >= 0 && uint32_t(hit.material_slot) < Instance::materialCapacity())
+            camera.raycasted_material = camera.raycasted_instance->materials[size_t(hit.material_slot)];
+    }
 }
 
 std::vector<Camera*> Engine::enabledCameras(World& world) const {  // cpu_engine_renderer.cpp:97-100: every enabled camera
@@ -370,7 +380,7 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
             for (Camera* cam : cameras)
                 if (cam == m_camera_slots[k]) {
                     check(hiprz_select_camera(m_ctx, uint32_t(k)));
-                    readback(*cam);
+                    readback(*cam, world);
                 }
     }
     // re-mirror what changed; any change restarts accumulation (cpu_engine_renderer.cpp:108-112)
@@ -398,6 +408,7 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
     if (slots_changed) {
         check(hiprz_set_camera_count(m_ctx, uint32_t(std::max<size_t>(cameras.size(), 1))));
         m_camera_slots.assign(cameras.begin(), cameras.end());
+        m_camera_records.assign(cameras.size(), hiprz_camera{});
         for (Camera* cam : cameras) cam->makeModified();
     }
     for (size_t k = 0; k < cameras.size(); ++k) {
@@ -405,13 +416,18 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
         check(hiprz_select_camera(m_ctx, uint32_t(k)));
         if (cam.isModified()) {
             const hiprz_camera rec = cameraRecord(cam);
-            check(hiprz_upload_camera(m_ctx, &rec));
+            // an upload restarts accumulation (cpu_engine_renderer.cpp:108-112); a camera that only moved its ray-cast pixel
+            // (Camera::rayCastPixel: MakeModified, not RequestUpdate) keeps accumulating in both reference engines
+            if (slots_changed || std::memcmp(&rec, &m_camera_records[k], sizeof rec) != 0) {
+                check(hiprz_upload_camera(m_ctx, &rec));
+                m_camera_records[k] = rec;
+            }
             check(hiprz_set_temporal_blend(m_ctx, cam.temporal_blend));
             cam.makeUnmodified();
         }
         check(hiprz_render(m_ctx, std::max(cfg.tracing.rpp, 1u)));
         check(hiprz_tonemap(m_ctx));
-        if (sync) readback(cam);
+        if (sync) readback(cam, world);
     }
     // not sync: nothing has been waited for — the buffers are filled by the next call, and a device fault would surface at that
     // call's first hip* return

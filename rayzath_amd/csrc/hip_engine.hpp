@@ -132,6 +132,15 @@ struct Camera : public Updatable {  // camera.hpp:127-161
     std::vector<uint8_t> image_buffer;  // RGBA8 W*H
     std::vector<float> depth_buffer;    // W*H
     uint64_t ray_count = 0;
+    // Kernel::rayCast (cpu_engine_kernel.cpp:102-111): after every frame, what the ray through this pixel meets — the editor's picking
+    void rayCastPixel(uint32_t x, uint32_t y) {  // camera.cpp:159-165: clamped, marks the camera modified (accumulation goes on: the record the
+                                                 // backend mirrors is unchanged, and neither reference engine restarts for MakeModified alone)
+        ray_cast_pixel[0] = x >= width ? width - 1 : x, ray_cast_pixel[1] = y >= height ? height - 1 : y;
+        makeModified();
+    }
+    uint32_t ray_cast_pixel[2] = {0, 0};
+    std::shared_ptr<Instance> raycasted_instance;  // camera.hpp:55-56 (m_raycasted_instance / m_raycasted_material)
+    std::shared_ptr<Material> raycasted_material;
 };
 
 struct World : public Updatable {  // world.hpp:64-76
@@ -220,7 +229,7 @@ public:
 
 private:
     void check(int rc);
-    void readback(Camera& camera);
+    void readback(Camera& camera, const World& world);
     std::vector<Camera*> enabledCameras(World& world) const;
 
     hiprz_ctx* m_ctx = nullptr;
@@ -233,6 +242,7 @@ private:
     std::unique_ptr<Exception> m_deferred;
     const World* m_last_world = nullptr;
     std::vector<const Camera*> m_camera_slots;  // camera k of the context mirrors this camera
+    std::vector<hiprz_camera> m_camera_records; // ... as this record (a modified camera whose record is unchanged is not uploaded again)
 };
 
 }  // namespace RayZath::Hip

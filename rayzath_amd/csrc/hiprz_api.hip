@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256) rz_untile_state_kernel(const float4* st0,
 }
 
 // Kernel::rayCast (cpu_engine_kernel.cpp:102-111, 483-501): one thread.
-__global__ void rz_pick_kernel(const DScene s, const DCamera cam, uint32_t x, uint32_t y, float depth, int32_t* out2) {
+__global__ void rz_pick_kernel(const DScene s, const DCamera cam, uint32_t x, uint32_t y, float depth, int32_t* out4) {
     Ray ray;
     generate_simple_ray(cam, ray, x, y);
     ray.near_ = depth * 0.99f;
@@ -94,15 +94,17 @@ __global__ void rz_pick_kernel(const DScene s, const DCamera cam, uint32_t x, ui
     Hit hit;
     hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
     Counters cnt;
-    out2[0] = out2[1] = -1;
+    out4[0] = out4[1] = out4[2] = -1, out4[3] = 0;
     if (s.n_instances != 0u && closest_hit_skip<false, false>(s, TopCache{nullptr, nullptr, 0u}, ray, hit, cnt) == 2) {
         const uint32_t inst = uint32_t(hit.instance);
         const uint32_t material_base = __float_as_uint(s.instances[7 * inst + 1].w);
         const uint32_t material_count = __float_as_uint(s.instances[7 * inst + 2].w);
         uint32_t slot = __float_as_uint(s.tris[3 * hit.triangle].w) & HIPRZ_TRI_MATERIAL_MASK;
         if (slot > 63u) slot = 63u;
-        out2[0] = hit.instance;
-        out2[1] = slot < material_count ? s.inst_materials[material_base + slot] : -1;
+        out4[0] = hit.instance;
+        out4[1] = int32_t(slot);
+        out4[2] = slot < material_count ? s.inst_materials[material_base + slot] : -1;
+        out4[3] = int32_t(__float_as_uint(s.tris[3 * hit.triangle + 1].w));  // hiprz_tri::source_index
     }
 }
 
@@ -872,7 +874,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->aux_join, hipEventDisableTiming);
     if (e == hipSuccess) e = c->pass_dev.resize(1);
     if (e == hipSuccess) e = c->counters_dev.resize(16);
-    if (e == hipSuccess) e = c->pick_dev.resize(2);
+    if (e == hipSuccess) e = c->pick_dev.resize(4);
     if (e == hipSuccess) e = hipMemsetAsync(c->pass_dev.ptr, 0, sizeof(uint32_t), c->stream);
     if (e != hipSuccess) {
         const std::string msg = std::string("context setup: ") + hipGetErrorString(e);
@@ -1620,20 +1622,23 @@ int hiprz_tonemap_image(hiprz_ctx* c, const void* src_image, void* dst_rgba8) {
 }
 void* hiprz_stream(hiprz_ctx* c) { return c ? reinterpret_cast<void*>(c->stream) : nullptr; }
 
-int hiprz_pick(hiprz_ctx* c, uint32_t x, uint32_t y, int32_t* instance_out, int32_t* material_out) {
+int hiprz_ray_cast(hiprz_ctx* c, uint32_t x, uint32_t y, hiprz_raycast* out) {
     if (!c) return HIPRZ_ERR_INVALID;
-    if (!c->have_scene || !c->have_camera) return fail(c, HIPRZ_ERR_STATE, "pick before scene and camera upload");
-    if (!instance_out || !material_out) return fail(c, HIPRZ_ERR_INVALID, "pick: null output");
-    // Camera::rayCastPixel clamps (camera.cpp:161-167)
+    if (!c->have_scene || !c->have_camera) return fail(c, HIPRZ_ERR_STATE, "ray cast before scene and camera upload");
+    if (!out) return fail(c, HIPRZ_ERR_INVALID, "ray cast: null output");
+    // Camera::rayCastPixel clamps (camera.cpp:159-165)
     if (x >= c->camera.width) x = c->camera.width - 1;
     if (y >= c->camera.height) y = c->camera.height - 1;
     (void)hipSetDevice(c->device);
     // depth of the pixel: only the shard that owns it can answer
     const uint32_t tile = (y / 8u) * c->tiles_x + (x / 32u);
-    *instance_out = *material_out = -1;
+    *out = hiprz_raycast{-1, -1, -1, 0u};
     if (tile % c->world != c->rank) {
         for (hiprz_ctx* p : c->peers)
-            if (tile % p->world == p->rank) return hiprz_pick(p, x, y, instance_out, material_out);
+            if (tile % p->world == p->rank) {
+                const int rc = hiprz_ray_cast(p, x, y, out);
+                return rc == HIPRZ_OK ? rc : fail(c, rc, "device " + std::to_string(p->device) + ": " + p->error);
+            }
         return HIPRZ_OK;
     }
     const uint32_t lt = tile / c->world, in_tile = ((x % 32u) / 8u) * 64u + (y % 8u) * 8u + (x % 8u);
@@ -1641,11 +1646,20 @@ int hiprz_pick(hiprz_ctx* c, uint32_t x, uint32_t y, int32_t* instance_out, int3
     RZ_HIP(c, hipMemcpyAsync(&depth, c->depth.ptr + size_t(lt) * 256u + in_tile, sizeof(float), hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));
     hipLaunchKernelGGL(rz_pick_kernel, dim3(1), dim3(1), 0, c->stream, c->dscene, c->dcamera, x, y, depth, c->pick_dev.ptr);
-    int32_t out2[2] = {-1, -1};
-    RZ_HIP(c, hipMemcpyAsync(out2, c->pick_dev.ptr, sizeof out2, hipMemcpyDeviceToHost, c->stream));
+    int32_t out4[4] = {-1, -1, -1, 0};
+    RZ_HIP(c, hipMemcpyAsync(out4, c->pick_dev.ptr, sizeof out4, hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));
-    *instance_out = out2[0], *material_out = out2[1];
+    out->instance = out4[0], out->material_slot = out4[1], out->material = out4[2], out->triangle = uint32_t(out4[3]);
     return HIPRZ_OK;
+}
+
+int hiprz_pick(hiprz_ctx* c, uint32_t x, uint32_t y, int32_t* instance_out, int32_t* material_out) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!instance_out || !material_out) return fail(c, HIPRZ_ERR_INVALID, "pick: null output");
+    hiprz_raycast r;
+    const int rc = hiprz_ray_cast(c, x, y, &r);
+    *instance_out = rc == HIPRZ_OK ? r.instance : -1, *material_out = rc == HIPRZ_OK ? r.material : -1;
+    return rc;
 }
 
 int hiprz_selftest(hiprz_ctx* c, uint32_t cases_per_thread, uint32_t seed, uint64_t* mismatches, uint64_t* tested) {

@@ -333,7 +333,7 @@ public:
             m_pending_readback = false;
             for (size_t k = 0; k < m_slots.size(); ++k)
                 for (uint32_t i : enabled)
-                    if (static_cast<const void*>(&*cameras[i]) == m_slots[k]) check(hiprz_select_camera(m_ctx, uint32_t(k))), readback(*cameras[i]);
+                    if (static_cast<const void*>(&*cameras[i]) == m_slots[k]) check(hiprz_select_camera(m_ctx, uint32_t(k))), readback(world, *cameras[i]);
         }
         switch (m_adapter.refresh(world)) {
             case WorldAdapter<Api>::Change::Scene: {
@@ -361,19 +361,25 @@ public:
         if (slots_changed) {
             check(hiprz_set_camera_count(m_ctx, uint32_t(std::max<size_t>(slots.size(), 1))));
             m_slots = slots;
+            m_records.assign(slots.size(), hiprz_camera{});
         }
         for (size_t k = 0; k < enabled.size(); ++k) {
             auto& cam = *cameras[enabled[k]];
             check(hiprz_select_camera(m_ctx, uint32_t(k)));
             if (slots_changed || cam.stateRegister().IsModified()) {
                 const hiprz_camera rec = WorldAdapter<Api>::cameraRecord(cam);
-                check(hiprz_upload_camera(m_ctx, &rec));
+                // an upload restarts accumulation; Camera::rayCastPixel only marks the camera modified (camera.cpp:159-165) and neither
+                // reference engine restarts for that, so an unchanged record is not uploaded again
+                if (slots_changed || std::memcmp(&rec, &m_records[k], sizeof rec) != 0) {
+                    check(hiprz_upload_camera(m_ctx, &rec));
+                    m_records[k] = rec;
+                }
                 check(hiprz_set_temporal_blend(m_ctx, cam.temporalBlend()));  // camera.hpp:111
                 cam.stateRegister().MakeUnmodified();
             }
             check(hiprz_render(m_ctx, std::max<uint32_t>(config.tracing().rpp(), 1u)));
             check(hiprz_tonemap(m_ctx));
-            if (sync) readback(cam);
+            if (sync) readback(world, cam);
         }
         if (!sync) m_pending_readback = true;
     }
@@ -382,8 +388,8 @@ private:
     void check(int rc) {
         if (rc != HIPRZ_OK) throw Exception(rc, hiprz_last_error(m_ctx));
     }
-    template <class RZCamera>
-    void readback(RZCamera& cam) {
+    template <class RZWorld, class RZCamera>
+    void readback(RZWorld& world, RZCamera& cam) {
         const uint32_t w = cam.width(), h = cam.height();
         m_rgba.resize(size_t(w) * h * 4), m_depth.resize(size_t(w) * h);
         check(hiprz_read_rgba8(m_ctx, m_rgba.data(), m_rgba.size()));
@@ -400,11 +406,28 @@ private:
         uint64_t rays = 0;
         check(hiprz_ray_count(m_ctx, &rays));
         cam.rayCount(rays);
+        // Kernel::rayCast after every frame (cpu_engine_renderer.cpp:176), stored as Cuda::EngineCore does (cuda_engine_core.cu:164-181):
+        // snapshot instance i IS instance i of the world's container (WorldAdapter::refresh flattens it in container order), and the
+        // slot is the one Instance::material(slot) is asked for
+        const auto pixel = cam.getRayCastPixel();
+        hiprz_raycast hit{};
+        check(hiprz_ray_cast(m_ctx, pixel.x, pixel.y, &hit));
+        auto& instances = world.template container<OT::Instance>();
+        if (hit.instance >= 0 && uint32_t(hit.instance) < instances.count()) {
+            const auto& instance = instances[uint32_t(hit.instance)];
+            cam.m_raycasted_instance = instance;
+            if (hit.material_slot >= 0 && uint32_t(hit.material_slot) < instance->materialCapacity()) cam.m_raycasted_material = instance->material(uint32_t(hit.material_slot));
+            else cam.m_raycasted_material.release();
+        } else {
+            cam.m_raycasted_instance.release();
+            cam.m_raycasted_material.release();
+        }
     }
 
     hiprz_ctx* m_ctx;
     WorldAdapter<Api> m_adapter;
     std::vector<const void*> m_slots;  // camera k of the context mirrors this camera object
+    std::vector<hiprz_camera> m_records;  // ... as this record
     std::vector<uint8_t> m_rgba;
     std::vector<float> m_depth;
     bool m_pending_readback = false;

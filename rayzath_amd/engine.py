@@ -215,6 +215,13 @@ class Context:
         self._check(self.lib.hiprz_pick(self._ctx, x, y, C.byref(i), C.byref(m)))
         return i.value, m.value
 
+    def ray_cast(self, x, y):
+        """Kernel::rayCast through pixel (x, y) of the selected camera's current frame: (instance, material slot, material, triangle's
+        index in its mesh), -1 where nothing was met / the slot is unset."""
+        r = _abi.RayCast()
+        self._check(self.lib.hiprz_ray_cast(self._ctx, x, y, C.byref(r)))
+        return r.instance, r.material_slot, r.material, r.triangle
+
     def selftest(self, cases_per_thread=64, seed=1):
         bad, n = C.c_uint64(), C.c_uint64()
         self._check(self.lib.hiprz_selftest(self._ctx, cases_per_thread, seed, C.byref(bad), C.byref(n)))
@@ -336,6 +343,12 @@ class Engine:
             cam.image_buffer = ctx.read_rgba8()  # synchronises
             cam.depth_buffer = ctx.read_depth()
             cam.ray_count = ctx.ray_count()
+            # Kernel::rayCast after every frame (cpu_engine_renderer.cpp:176): what the camera's ray-cast pixel looks at
+            px, py = getattr(cam, "ray_cast_pixel", (0, 0))
+            inst, slot, _, _ = ctx.ray_cast(int(px), int(py))
+            cam.raycasted_instance = world.instances[inst] if 0 <= inst < len(world.instances) else None
+            materials = getattr(cam.raycasted_instance, "materials", None) or []
+            cam.raycasted_material = materials[slot] if cam.raycasted_instance is not None and 0 <= slot < len(materials) else None
 
     def timingsString(self):
         return self.context.timings()

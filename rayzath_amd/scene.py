@@ -177,6 +177,11 @@ class Camera:
         self.focal_distance = max(float(focal_distance), eps)
         self.aperture = max(float(aperture), eps)
         self.exposure_time = max(float(exposure_time), eps)
+        self.ray_cast_pixel = (0, 0)   # Camera::getRayCastPixel; the engine fills raycasted_instance / raycasted_material after each frame
+
+    def ray_cast_at(self, x, y):
+        """Camera::rayCastPixel (camera.cpp:159-165): clamped to the frame.  Accumulation goes on (MakeModified, not RequestUpdate)."""
+        self.ray_cast_pixel = (min(max(int(x), 0), self.width - 1), min(max(int(y), 0), self.height - 1))
 
     def look_at(self, point):
         """Camera::lookAtPoint / lookInDirection, camera.cpp:68-80."""

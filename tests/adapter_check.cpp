@@ -47,6 +47,28 @@ static bool render_check(const char* scene_path) {
     Double::RenderConfig dcfg;
     dcfg.m_tracing.m_max_depth = 5, dcfg.m_tracing.m_rpp = 3, dcfg.m_light_sampling.m_spot = 2;
     bool ok = true;
+    // picking: both sides look through the same pixels (camera.hpp:90); what they meet must be the same object of their world
+    twin.camera.rayCastPixel(twin.camera.width / 2, twin.camera.height / 2), second->rayCastPixel(20, 30);
+    cams[0]->rayCastPixel({twin.camera.width / 2, twin.camera.height / 2}), cams[1]->rayCastPixel({20, 30});
+    auto& dinstances = world->container<Double::ObjectType::Instance>();
+    auto& dmaterials = world->container<Double::ObjectType::Material>();
+    auto ray_casts = [&](const char* what) {
+        Camera* tw[2] = {&twin.camera, second.get()};
+        for (int k = 0; k < 2; ++k) {
+            int ti = -1, di = -1, tm = -1, dm = -1;
+            for (size_t i = 0; i < twin.instances.size(); ++i)
+                if (twin.instances[i] == tw[k]->raycasted_instance) ti = int(i);
+            for (uint32_t i = 0; i < dinstances.count(); ++i)
+                if (cams[k]->m_raycasted_instance && dinstances[i].p == cams[k]->m_raycasted_instance.p) di = int(i);
+            for (size_t i = 0; i < twin.materials.size(); ++i)
+                if (tw[k]->raycasted_material && twin.materials[i] == tw[k]->raycasted_material) tm = int(i);
+            for (uint32_t i = 0; i < dmaterials.count(); ++i)
+                if (cams[k]->m_raycasted_material && dmaterials[i].p == cams[k]->m_raycasted_material.p) dm = int(i);
+            const bool eq = ti == di && tm == dm;
+            std::printf("%-28s camera %d ray cast %s (instance %d, material %d)\n", what, k, eq ? "equal" : "DIFFERENT", di, dm);
+            ok &= eq;
+        }
+    };
     auto compare = [&](const char* what) {
         Camera* tw[2] = {&twin.camera, second.get()};
         for (int k = 0; k < 2; ++k) {
@@ -64,6 +86,18 @@ static bool render_check(const char* scene_path) {
     };
     engine.renderWorld(twin, cfg), renderer.renderWorld(*world, dcfg);
     compare("first frame");
+    ray_casts("first frame");
+    ok &= bool(cams[0]->m_raycasted_instance);  // the centre of the frame looks at something
+    {   // the ray-cast pixel moves: another object, the same accumulation (ray counts go on)
+        const uint64_t before = cams[0]->rayCount();
+        twin.camera.rayCastPixel(3, twin.camera.height - 3), cams[0]->rayCastPixel({3, twin.camera.height - 3});
+        engine.renderWorld(twin, cfg), renderer.renderWorld(*world, dcfg);
+        compare("after moving the ray cast");
+        ray_casts("after moving the ray cast");
+        const bool went_on = cams[0]->rayCount() == before + 3ull * twin.camera.width * twin.camera.height;
+        std::printf("accumulation went on         %s\n", went_on ? "yes" : "DIFFERENT");
+        ok &= went_on;
+    }
     engine.renderWorld(twin, cfg, true, false), renderer.renderWorld(*world, dcfg, true, false);  // pipelined: buffers filled by the next call
     engine.renderWorld(twin, cfg), renderer.renderWorld(*world, dcfg);
     compare("after a pipelined frame");

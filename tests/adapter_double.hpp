@@ -44,6 +44,7 @@ struct Handle {
     explicit operator bool() const noexcept { return bool(p); }
     T* operator->() const noexcept { return p.get(); }
     T& operator*() const noexcept { return *p; }
+    void release() { p.reset(); }  // roho.hpp:201
 };
 
 struct vec3f { float x = 0, y = 0, z = 0; };
@@ -221,6 +222,18 @@ struct Camera : Updatable {
     float aperture() const { return m_aperture; }
     float exposureTime() const { return m_exposure; }
     float temporalBlend() const { return m_temporal_blend; }
+    // picking (camera.hpp:53-56, 90, 109)
+    struct vec2ui32 { uint32_t x = 0, y = 0; };
+    vec2ui32 m_ray_cast_pixel;
+    vec2ui32 getRayCastPixel() const { return m_ray_cast_pixel; }
+    void rayCastPixel(vec2ui32 pixel) {
+        if (pixel.x >= m_width) pixel.x = m_width - 1;
+        if (pixel.y >= m_height) pixel.y = m_height - 1;
+        m_ray_cast_pixel = pixel;
+        stateRegister().MakeModified();
+    }
+    Handle<Instance> m_raycasted_instance;
+    Handle<Material> m_raycasted_material;
 };
 
 template <class T>

@@ -48,4 +48,5 @@ def test_world_renderer_over_the_double_renders_like_the_engine_over_the_twin(bu
     scene, exe = _scene_and_exe(tmp_path)
     r = subprocess.run([exe, scene, "render"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ADAPTER OK" in r.stdout and "DIFFERENT" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-    assert r.stdout.count("camera 0 equal") == 3 and r.stdout.count("camera 1 equal") == 3
+    assert r.stdout.count("camera 0 equal") == 4 and r.stdout.count("camera 1 equal") == 4
+    assert r.stdout.count("ray cast equal") == 4 and "accumulation went on         yes" in r.stdout

@@ -96,6 +96,36 @@ def test_every_camera_has_its_own_frame(built):
     assert not hasattr(cams[2], "image_buffer") and cams[1].ray_count == 4 * 96 * 128
 
 
+def test_engine_ray_casts_every_camera_after_each_frame(built):
+    """Kernel::rayCast after every frame (cpu_engine_renderer.cpp:176): the camera's ray-cast pixel -> the instance and the instance's
+    material it looks at (camera.hpp:55-56), against the oracle's rzo_pick; moving the pixel does not restart accumulation."""
+    world = scenes.cornell_box(160, 96)
+    second = Camera(position=(0.6, 1.2, -3.2), rotation=(0.05, -0.1, 0.0), resolution=(96, 64), fov=1.3, focal_distance=4.0)
+    world.cameras = [second]
+    cfg = RenderConfig(tracing=Tracing(5, 3))
+    flat = flatten(world)
+    eng = Engine(0, streams=1)
+    seen = set()
+    rays = 0
+    for px, py in [(80, 48), (20, 80), (150, 10), (40, 40), (110, 60), (5000, 5000)]:
+        world.camera.ray_cast_at(px, py)
+        second.ray_cast_at(px // 2, py // 2)
+        eng.renderWorld(world, cfg)
+        rays += 3 * 160 * 96
+        assert world.camera.ray_count == rays                      # still the same accumulation
+        for cam in (world.camera, second):
+            x, y = cam.ray_cast_pixel
+            ref = oracle.OracleRenderer(flat, camera_struct(cam), cfg.struct())
+            ref.render(1, threads=1)
+            inst, mat = ref.pick(x, y)
+            got_inst = world.instances.index(cam.raycasted_instance) if cam.raycasted_instance is not None else -1
+            assert got_inst == inst, (x, y)
+            got_mat = 2 + world.materials.index(cam.raycasted_material) if cam.raycasted_material is not None else -1  # [0] world, [1] default
+            assert got_mat == mat, (x, y)
+            seen.add(got_inst)
+    assert len(seen) >= 4                                           # walls, boxes, lamp: the pixels really look at different things
+
+
 def test_update_shading_equals_a_full_upload(built):
     world = scenes.living_room(128, 80, 12)
     flat, cam = flatten(world), camera_struct(world.camera)

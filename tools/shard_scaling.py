@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Kernel-side scaling rehearsal on ONE GPU: time the work of shard 0 of N (N = 1, 2, 4, 8) — 8 passes + tone map +
-tile export, everything a rank does per bench step except the collective — and print t(1) / (N * t(N)).
-Tells how much of the 8-GPU scaling target is lost to small grids / launch overhead before any communication."""
+"""Kernel-side scaling rehearsal on ONE GPU: time the work of EVERY shard r of N (N = 1, 2, 4, 8) — 8 passes + tone map +
+tile export, everything a rank does per bench step except the collective — and print, per N, the slowest shard (what a job of N
+ranks waits for) and t(1) / (N * max_r t(N, r)).  Tells how much of the 8-GPU scaling target is lost to small grids, launch
+overhead and the slowest tile before any communication.  One JSON line per (config, N)."""
 import argparse, json, os, sys, time
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -12,38 +13,49 @@ from rayzath_amd.engine import Context, RenderConfig, Tracing
 from rayzath_amd.scene import camera_struct, flatten
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--config", default="B")
+ap.add_argument("--config", default="B", help="comma-separated presets of rayzath_amd/scenes.py")
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--shards", default="1,2,4,8")
 ap.add_argument("--traversal", type=int, default=-1)
 ap.add_argument("--pipeline", type=int, default=-1)
 args = ap.parse_args()
-preset = scenes.CONFIGS[args.config]
-world_scene = preset["build"]()
-flat, cam = flatten(world_scene), camera_struct(world_scene.camera)
-cfg = RenderConfig(tracing=Tracing(preset["max_depth"], 8)).struct()
 dev = torch.device("cuda", 0)
-base = None
-for n in (1, 2, 4, 8):
-    ctx = Context(0)
-    ctx.set_traversal_mode(args.traversal)
-    if args.pipeline >= 0:
-        ctx.set_pipeline(args.pipeline)
-    ctx.set_shard(0, n)
-    ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(cfg)
-    frame = ShardedFrame(ctx, 0, n, cam.width, cam.height, None, dev)
-    def step():
-        ctx.render(8)
-        ctx.tonemap()
-        ctx.export_rgba8_tiles(frame.local8.data_ptr(), frame.local8.numel() * 4)
-    for _ in range(3):
-        step()
-    ctx.sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    ctx.sync()
-    ms = (time.perf_counter() - t0) / args.steps * 1e3
-    base = base or ms
-    print(json.dumps({"config": args.config, "shard_of": n, "ms_per_step": round(ms, 4), "ideal_ms": round(base / n, 4),
-                      "kernel_side_efficiency": round(base / (n * ms), 3)}), flush=True)
-    ctx.close()
+for config in args.config.split(","):
+    preset = scenes.CONFIGS[config]
+    world_scene = preset["build"]()
+    flat, cam = flatten(world_scene), camera_struct(world_scene.camera)
+    cfg = RenderConfig(tracing=Tracing(preset["max_depth"], 8)).struct()
+    base = None
+    for n in [int(v) for v in args.shards.split(",")]:
+        per_shard, kernel_ms = [], []
+        for r in range(n):
+            ctx = Context(0)
+            ctx.set_traversal_mode(args.traversal)
+            if args.pipeline >= 0:
+                ctx.set_pipeline(args.pipeline)
+            ctx.set_shard(r, n)
+            ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(cfg)
+            frame = ShardedFrame(ctx, r, n, cam.width, cam.height, None, dev)
+
+            def step():
+                ctx.render(8)
+                ctx.tonemap()
+                ctx.export_rgba8_tiles(frame.local8.data_ptr(), frame.local8.numel() * 4)
+
+            for _ in range(3):
+                step()
+            ctx.sync()
+            ctx.kernel_time_ms()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            ctx.sync()
+            per_shard.append((time.perf_counter() - t0) / args.steps * 1e3)
+            k_ms, k_n = ctx.kernel_time_ms()  # hip events around every render batch (on the stream, no host gaps)
+            kernel_ms.append(k_ms / max(k_n, 1) * 8)
+            ctx.close()
+        worst = max(per_shard)
+        base = base or worst
+        print(json.dumps({"config": config, "shards": n, "ms_per_step_slowest_shard": round(worst, 4), "ms_per_step_mean": round(sum(per_shard) / n, 4),
+                          "ms_per_shard": [round(v, 4) for v in per_shard], "render_batch_ms_on_stream": [round(v, 4) for v in kernel_ms],
+                          "ideal_ms": round(base / n, 4), "kernel_side_speedup": round(base / worst, 3), "kernel_side_efficiency": round(base / (n * worst), 3)}), flush=True)
