@@ -332,6 +332,12 @@ def main():
         tpath = os.path.join(ROOT, "profiles", f"traffic_{args.config}.json")
         if os.path.exists(tpath) and world == 1:
             traffic = json.load(open(tpath)).get(kernel_name.split(" ")[0], {}).get("hbm_bytes_per_launch")
+        # compute side of the same kernel (SQ counter passes of tools/pmc_sq.sh, committed as profiles/sq_<config>.json): these walks
+        # are bound by vector-instruction issue at partial lane utilisation, not by HBM — the line says so next to the byte roofline
+        compute = {}
+        spath = os.path.join(ROOT, "profiles", f"sq_{args.config}.json")
+        if os.path.exists(spath) and world == 1:
+            compute = json.load(open(spath)).get(kernel_name.split(" ")[0], {})
         result = {
             "metric": "Mrays/s (path segments, primary+secondary) at 1920x1080 depth 8" if args.config == "B" else f"Mrays/s config {args.config}",
             "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -351,6 +357,9 @@ def main():
             "several_streams": several_streams,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": traffic, "kernel": kernel_name, "avg_launch_us": kernel_s * 1e6,
+                         "valu_busy": compute.get("valu_busy"), "lanes_active": compute.get("lanes_active"),
+                         "valu_instr_per_wave": compute.get("valu_instr_per_wave"),
+                         "bound_measured": "vector-instruction issue (valu_busy of the chip's VALU issue capacity at lanes_active of the lanes; SQ counters, profiles/)" if compute.get("valu_busy") else None,
                          "duration_from": ("hip events around every render batch of the timed repeats (%d launches)" % (launches // RPP)) if pipeline == 2 else
                                           "hip events around the kernel in an eager, event-instrumented batch after the timed region (a captured graph cannot be timed from inside)",
                          "eager_avg_launch_us": eager_kernel_us,

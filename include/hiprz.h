@@ -331,7 +331,9 @@ int hiprz_set_mode(hiprz_ctx* ctx, uint32_t compat_flags);
  * previous depth buffer agrees within 1 %, the previous accumulator * temporal blend is appended — colour sum and sample count alike,
  * so the tone map sees a frame that starts with blend * (old sample count) samples.  It changes what a restart starts from, not the
  * integrator: it combines with any other flag, also with none.  History is per camera and is dropped when the resolution or the
- * shard changes; in a sharded frame only history from tiles the same context owns is carried over.
+ * shard changes.  A context over several devices (hiprz_create_multi) assembles the whole previous frame from all of them at the restart,
+ * so the source pixel of a moved camera may come from any device; a frame the caller sharded over several CONTEXTS (hiprz_set_shard)
+ * carries over history from the tiles each context owns only.
  * hiprz_set_temporal_blend: Camera::temporalBlend of the selected camera (camera.cpp:154-156: clamped to [0, 1]; default 0.75). */
 int hiprz_set_temporal_blend(hiprz_ctx* ctx, float blend);
 

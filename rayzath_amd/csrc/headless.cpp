@@ -109,7 +109,10 @@ std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& r
             std::printf("Engine %s is not part of this host library: skipped.\n", engine_name.c_str());
             continue;
         }
-        Engine engine(devices);  // several ids: tiles interleaved over the GPUs, gathered inside the readback
+        // several ids: one context over those GPUs (tiles interleaved, gathered inside the readback); one id: the plain engine, which
+        // picks its stream count by the world like every other host (Hip::Engine::defaultStreams)
+        std::unique_ptr<Engine> engine_owner = devices.size() == 1 ? std::make_unique<Engine>(devices[0]) : std::make_unique<Engine>(devices);
+        Engine& engine = *engine_owner;
         RenderConfig config;
         config.tracing.max_depth = uint8_t(task.max_depth);
         config.tracing.rpp = 1;

@@ -140,6 +140,7 @@ FlatScene flatten(const World& world) {
         rec.sampling = t->sampling;
         f.texels.insert(f.texels.end(), t->bitmap.begin(), t->bitmap.end());
         f.textures.push_back(rec);
+        f.maps.push_back(t.get());
         return tex_index[t.get()] = int32_t(f.textures.size() - 1);
     };
     std::map<const Material*, int32_t> mat_index;
@@ -244,6 +245,7 @@ FlatScene flattenShading(const World& world) {
         auto it = tex_index.find(t.get());
         if (it != tex_index.end()) return it->second;
         const int32_t id = int32_t(tex_index.size());
+        f.maps.push_back(t.get());
         return tex_index[t.get()] = id;
     };
     auto add_material = [&](const Material& m) {
@@ -303,18 +305,7 @@ void Engine::check(int rc) {
 }
 void Engine::mode(uint32_t compat_flags) {
     std::lock_guard<std::mutex> lock(m_mutex);
-    if ((compat_flags & HIPRZ_COMPAT_REPROJECTION) && m_split_by_default) {
-        // history is carried over within a share only (hiprz.h): reprojection wants the frame in ONE context
-        hiprz_ctx* single = nullptr;
-        const int rc = hiprz_create(&single, m_device);
-        if (rc != HIPRZ_OK) throw Exception(rc, hiprz_last_error(nullptr));
-        hiprz_destroy(m_ctx);
-        m_ctx = single;
-        m_split_by_default = false;
-        m_last_world = nullptr, m_camera_slots.clear(), m_pending_readback = false;
-        check(hiprz_set_tree(m_ctx, m_tree));
-    }
-    check(hiprz_set_mode(m_ctx, compat_flags));
+    check(hiprz_set_mode(m_ctx, compat_flags));  // reprojection works over several streams / devices: the context assembles the whole previous frame
     m_mode = compat_flags;
 }
 void Engine::tree(uint32_t tree) {
@@ -360,14 +351,13 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
     }
     if (m_streams_pending) {  // the first world: as many streams on the GPU as suit it
         m_streams_pending = false;
-        const int streams = (m_mode & HIPRZ_COMPAT_REPROJECTION) ? 1 : defaultStreams(world);
+        const int streams = defaultStreams(world);
         if (streams > 1) {
             hiprz_ctx* several = nullptr;
             const std::vector<int> ids(size_t(streams), m_device);
             if (hiprz_create_multi(&several, ids.data(), streams) == HIPRZ_OK) {
                 hiprz_destroy(m_ctx);
                 m_ctx = several;
-                m_split_by_default = true;
                 check(hiprz_set_mode(m_ctx, m_mode));
                 check(hiprz_set_tree(m_ctx, m_tree));
             }
@@ -390,10 +380,21 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
         check(hiprz_upload_scene(m_ctx, &view));
         world.makeUnmodified(), world.makeShadingUnmodified();
         m_last_world = &world;
+        m_uploaded_maps = flat.maps;
     } else if (world.isShadingModified()) {  // materials / lights only: replaced in place, no tree is touched
-        const FlatScene flat = flattenShading(world);
-        check(hiprz_update_shading(m_ctx, flat.materials.data(), uint32_t(flat.materials.size()), flat.spot_lights.data(), uint32_t(flat.spot_lights.size()),
-                                   flat.direct_lights.data(), uint32_t(flat.direct_lights.size())));
+        const FlatScene shading = flattenShading(world);
+        // flattenShading numbers the maps in first-use order; those indices mean something only if they name the SAME map objects in
+        // the same order as the uploaded scene's (a material re-pointed at another uploaded map changes the first-use order, a new
+        // map has no texels on the device at all): otherwise the whole scene goes up again, as the adapter does (WorldAdapter::refresh)
+        if (shading.maps == m_uploaded_maps) {
+            check(hiprz_update_shading(m_ctx, shading.materials.data(), uint32_t(shading.materials.size()), shading.spot_lights.data(),
+                                       uint32_t(shading.spot_lights.size()), shading.direct_lights.data(), uint32_t(shading.direct_lights.size())));
+        } else {
+            const FlatScene flat = flatten(world);
+            const hiprz_scene view = flat.view();
+            check(hiprz_upload_scene(m_ctx, &view));
+            m_uploaded_maps = flat.maps;
+        }
         world.makeShadingUnmodified();
     }
     hiprz_config c{};

@@ -195,6 +195,7 @@ struct FlatScene {
     std::vector<uint8_t> texels;
     std::vector<hiprz_spot_light> spot_lights;
     std::vector<hiprz_direct_light> direct_lights;
+    std::vector<const void*> maps;  // the map objects behind `textures`, by identity, in texture-index order (host-side bookkeeping only)
     hiprz_scene view() const;
 };
 FlatScene flatten(const World& world);           // pure host
@@ -235,7 +236,6 @@ private:
     hiprz_ctx* m_ctx = nullptr;
     int m_device = 0;
     bool m_streams_pending = false;  // the context is still the single one of the constructor: the first world decides
-    bool m_split_by_default = false; // ... and it chose several streams
     uint32_t m_mode = 0, m_tree = 0;  // what mode() / tree() set, for the context that replaces it
     std::mutex m_mutex;  // renderWorld is serialised (cpu_engine_core.cpp:15)
     bool m_pending_readback = false;
@@ -243,6 +243,7 @@ private:
     const World* m_last_world = nullptr;
     std::vector<const Camera*> m_camera_slots;  // camera k of the context mirrors this camera
     std::vector<hiprz_camera> m_camera_records; // ... as this record (a modified camera whose record is unchanged is not uploaded again)
+    std::vector<const void*> m_uploaded_maps;   // the maps of the uploaded scene: hiprz_update_shading may only refer to these, by these indices
 };
 
 }  // namespace RayZath::Hip

@@ -57,15 +57,16 @@ __global__ void __launch_bounds__(256) rz_untile_kernel(const T* tiles, T* image
     if (x < width && y < height) image[size_t(y) * width + x] = tiles[size_t(blockIdx.x) * 256u + threadIdx.x];
 }
 // the gathered tiles of ALL shards (shard r at tiles + r * part_stride elements) -> row-major full frame, one launch
+// (slice blockIdx.y holds shard rank0 + blockIdx.y of `world`)
 template <typename T>
 __global__ void __launch_bounds__(256) rz_untile_gathered_kernel(const T* tiles, size_t part_stride, T* image, uint32_t width, uint32_t height,
-                                                                 uint32_t tiles_x, uint32_t n_tiles, uint32_t world) {
-    const uint32_t rank = blockIdx.y, tile = blockIdx.x * world + rank;
+                                                                 uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t rank0) {
+    const uint32_t part = blockIdx.y, tile = blockIdx.x * world + rank0 + part;
     if (tile >= n_tiles) return;
     const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
-    if (x < width && y < height) image[size_t(y) * width + x] = tiles[rank * part_stride + size_t(blockIdx.x) * 256u + threadIdx.x];
+    if (x < width && y < height) image[size_t(y) * width + x] = tiles[part * part_stride + size_t(blockIdx.x) * 256u + threadIdx.x];
 }
 __global__ void __launch_bounds__(256) rz_untile_state_kernel(const float4* st0, const float4* st1, const float2* st2, float* ray9,
                                                               uint32_t* md2, uint32_t width, uint32_t height, uint32_t tiles_x,
@@ -240,9 +241,9 @@ __global__ void __launch_bounds__(256) rz_reproject_kernel(const DFrame f, const
     const float fy = (((local_p.y / local_p.z) / (-prev.tan_half_fov / prev.aspect_ratio)) + 0.5f) * float(cam.height);
     if (fx < 0.0f || fx >= float(cam.width) || fy < 0.0f || fy >= float(cam.height)) return;  // outside the previous frustum
     const uint32_t sx = uint32_t(fx), sy = uint32_t(fy);
-    const uint32_t tile = (sy >> 3) * f.tiles_x + (sx >> 5);
-    if (tile % f.world != f.rank) return;  // the source pixel lives in another shard
-    const uint32_t from = (tile / f.world) * 256u + (((sx & 31u) >> 3) << 6) + ((sy & 7u) << 3) + (sx & 7u);
+    // the history is a row-major image of the WHOLE previous frame (keep_history): the source pixel of a moved camera may have been
+    // rendered by another device of the context.  Pixels no shard of this context owns hold depth 0 and never pass the test below.
+    const size_t from = size_t(sy) * cam.width + sx;
     const float point_dist = magnitude(rel), buffer_dist = prev_depth[from];
     if (fabsf(point_dist - buffer_dist) < 0.01f * point_dist) {
         const float4 a = f.accum[p.local], h = prev_accum[from];
@@ -251,15 +252,83 @@ __global__ void __launch_bounds__(256) rz_reproject_kernel(const DFrame f, const
 }
 
 // Called where a first pass is about to run.  Returns whether the finished first pass is to be followed by reproject_after_first_pass.
+// The frame a restart replaces is kept as row-major images of the whole frame (accumulator, first-hit depth).  A multi-device head has
+// assembled them from all its devices before the call fanned out (assemble_history, history_ready); a single context untiles its own
+// shard — pixels of shards rendered elsewhere (hiprz_set_shard by the caller: another process) stay zero and carry no history.
 bool keep_history(hiprz_ctx* c) {
     const bool reproject = (c->mode_flags & HIPRZ_COMPAT_REPROJECTION) && c->frame_started && c->n_local_tiles != 0u;
-    if (reproject) {
-        const size_t n = size_t(c->n_local_tiles) * 256u;
+    if (reproject && !c->history_ready) {
+        const size_t n = size_t(c->camera.width) * c->camera.height;
         if (c->prev_accum.resize(n) != hipSuccess || c->prev_depth.resize(n) != hipSuccess) return false;
-        (void)hipMemcpyAsync(c->prev_accum.ptr, c->accum.ptr, n * sizeof(float4), hipMemcpyDeviceToDevice, c->stream);
-        (void)hipMemcpyAsync(c->prev_depth.ptr, c->depth.ptr, n * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+        if (c->world > 1u) {
+            (void)hipMemsetAsync(c->prev_accum.ptr, 0, n * sizeof(float4), c->stream);
+            (void)hipMemsetAsync(c->prev_depth.ptr, 0, n * sizeof(float), c->stream);
+        }
+        hipLaunchKernelGGL((rz_untile_kernel<float4>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->accum.ptr, c->prev_accum.ptr, c->camera.width,
+                           c->camera.height, c->tiles_x, c->rank, c->world);
+        hipLaunchKernelGGL((rz_untile_kernel<float>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->depth.ptr, c->prev_depth.ptr, c->camera.width,
+                           c->camera.height, c->tiles_x, c->rank, c->world);
     }
+    c->history_ready = false;
     return reproject;
+}
+// Multi-device head, before a render call fans out to devices that are about to restart their frames: the whole previous frame —
+// every device's tiles over the peer-to-peer path of the readbacks — as row-major images on the head, then a copy to every peer.
+int assemble_history(hiprz_ctx* c) {
+    if (c->peers.empty() || !(c->mode_flags & HIPRZ_COMPAT_REPROJECTION) || !c->reset_pending || !c->frame_started || !c->have_camera) return HIPRZ_OK;
+    (void)hipSetDevice(c->device);
+    const size_t n = size_t(c->camera.width) * c->camera.height;
+    RZ_HIP(c, c->prev_accum.resize(n));
+    RZ_HIP(c, c->prev_depth.resize(n));
+    if (c->user_world > 1u) {
+        RZ_HIP(c, hipMemsetAsync(c->prev_accum.ptr, 0, n * sizeof(float4), c->stream));
+        RZ_HIP(c, hipMemsetAsync(c->prev_depth.ptr, 0, n * sizeof(float), c->stream));
+    }
+    const uint32_t n_parts = uint32_t(c->peers.size()) + 1u, n_tiles = c->tiles_x * c->tiles_y;
+    const size_t stride = size_t(c->n_local_tiles) * 256u;
+    RZ_HIP(c, c->gather.resize(stride * n_parts * (sizeof(float4) + sizeof(float))));
+    float4* parts_a = reinterpret_cast<float4*>(c->gather.ptr);
+    float* parts_d = reinterpret_cast<float*>(parts_a + stride * n_parts);
+    if (c->n_local_tiles) {
+        RZ_HIP(c, hipMemcpyAsync(parts_a, c->accum.ptr, stride * sizeof(float4), hipMemcpyDeviceToDevice, c->stream));
+        RZ_HIP(c, hipMemcpyAsync(parts_d, c->depth.ptr, stride * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    }
+    for (uint32_t r = 1; r < n_parts; ++r) {
+        hiprz_ctx* p = c->peers[r - 1u];
+        const size_t local = size_t(p->n_local_tiles) * 256u;
+        if (!local) continue;
+        (void)hipSetDevice(p->device);
+        RZ_HIP(c, hipMemcpyPeerAsync(parts_a + stride * r, c->device, p->accum.ptr, p->device, local * sizeof(float4), p->stream));
+        RZ_HIP(c, hipMemcpyPeerAsync(parts_d + stride * r, c->device, p->depth.ptr, p->device, local * sizeof(float), p->stream));
+        RZ_HIP(c, hipEventRecord(p->peer_done, p->stream));
+        (void)hipSetDevice(c->device);
+        RZ_HIP(c, hipStreamWaitEvent(c->stream, p->peer_done, 0));
+    }
+    if (c->n_local_tiles) {
+        hipLaunchKernelGGL((rz_untile_gathered_kernel<float4>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts_a, stride, c->prev_accum.ptr,
+                           c->camera.width, c->camera.height, c->tiles_x, n_tiles, c->world, c->rank);
+        hipLaunchKernelGGL((rz_untile_gathered_kernel<float>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts_d, stride, c->prev_depth.ptr,
+                           c->camera.width, c->camera.height, c->tiles_x, n_tiles, c->world, c->rank);
+    }
+    c->history_ready = true;
+    // every peer gets the same images; its stream waits for the copy before its first pass runs
+    if (!c->history_done) RZ_HIP(c, hipEventCreateWithFlags(&c->history_done, hipEventDisableTiming));
+    for (hiprz_ctx* p : c->peers) {
+        (void)hipSetDevice(p->device);
+        RZ_HIP(c, p->prev_accum.resize(n));
+        RZ_HIP(c, p->prev_depth.resize(n));
+        (void)hipSetDevice(c->device);
+        RZ_HIP(c, hipMemcpyPeerAsync(p->prev_accum.ptr, p->device, c->prev_accum.ptr, c->device, n * sizeof(float4), c->stream));
+        RZ_HIP(c, hipMemcpyPeerAsync(p->prev_depth.ptr, p->device, c->prev_depth.ptr, c->device, n * sizeof(float), c->stream));
+        p->history_ready = true;
+    }
+    RZ_HIP(c, hipEventRecord(c->history_done, c->stream));
+    for (hiprz_ctx* p : c->peers) {
+        (void)hipSetDevice(p->device);
+        RZ_HIP(c, hipStreamWaitEvent(p->stream, c->history_done, 0));
+    }
+    (void)hipSetDevice(c->device);
+    return HIPRZ_OK;
 }
 void reproject_after_first_pass(hiprz_ctx* c, const DFrame& f, const hiprz_camera& previous) {
     PrevCamera prev;
@@ -484,6 +553,26 @@ int finish_batch(hiprz_ctx* c, hipEvent_t e0, hipEvent_t e1, uint32_t n_passes, 
     return HIPRZ_OK;
 }
 
+// What a captured batch depends on, byte for byte: the arguments every kernel of the batch receives by value (scene, camera, config and
+// frame views: raw pointers into buffers the context owns, sizes, sharding), the workspaces the sorts use, and every setting that
+// selects a kernel instantiation or a grid size.  The graph holds kernel nodes and event fork / join nodes only — no memset, memcpy or
+// library nodes, no host pointers — so "same key" means a replay does what an eager batch would do now.
+std::vector<unsigned char> graph_key_of(hiprz_ctx* c, const DFrame& f, uint32_t n_passes) {
+    std::vector<unsigned char> key;
+    auto put = [&key](const void* p, size_t n) { key.insert(key.end(), static_cast<const unsigned char*>(p), static_cast<const unsigned char*>(p) + n); };
+    const DConfig cfg = make_config(c);
+    put(&c->dscene, sizeof(DScene)), put(&c->dcamera, sizeof(DCamera)), put(&cfg, sizeof cfg), put(&f, sizeof f);
+    for (const auto& t : c->sort_temp) {
+        const void* ptrs[5] = {t.keys_out.ptr, t.vals_a.ptr, t.vals_b.ptr, t.counts.ptr, t.digit_total.ptr};
+        put(ptrs, sizeof ptrs);
+    }
+    const int settings[] = {c->pipeline, effective_mode(c), c->walk_order, c->trace_waves, int(c->scene_tree), effective_sort_bits(c), int(defer_shadows(c)),
+                            int(use_lds_scene(c)), int(c->flat_world), c->nolight_kernels, int(c->n_textures), int(c->n_nodes), int(c->xcd_swizzle),
+                            int(sort_enabled(c)), c->shadow_sort, c->batch_waves, int(c->stack_entries), int(n_passes), int(c->n_local_tiles)};
+    put(settings, sizeof settings);
+    return key;
+}
+
 int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     if (!c->have_scene || !c->have_camera) return fail(c, HIPRZ_ERR_STATE, "render before scene and camera upload");
     if (n_passes == 0 || c->n_local_tiles == 0) return HIPRZ_OK;
@@ -533,8 +622,16 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     }
     if (c->use_graph && !c->time_kernels && !counted && !c->reset_pending && n_passes >= 2) {
         // steady state: one graph launch instead of 2 * n_passes kernel launches
-        if (!c->graph_valid || c->graph_passes != n_passes) {
+        std::vector<unsigned char> key = graph_key_of(c, f, n_passes);
+#ifdef RZ_GRAPH_ASSERT  // debug builds: a key that changed under a graph still marked valid is a missed invalidation — say so loudly
+        if (c->graph_valid && c->graph_passes == n_passes && key != c->graph_key) {
+            std::fprintf(stderr, "hiprz: captured graph marked valid although its launch arguments changed (a buffer was reallocated or a setting changed without invalidate_graphs)\n");
+            std::abort();
+        }
+#endif
+        if (!c->graph_valid || c->graph_passes != n_passes || key != c->graph_key) {
             drop_graph(c);
+            c->graph_key = std::move(key);
             hipGraph_t graph = nullptr;
             RZ_HIP(c, hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             enqueue_cumulative(c, f, n_passes);
@@ -602,24 +699,36 @@ int read_untiled(hiprz_ctx* c, const T* tiles, T* dst, size_t bytes, const char*
     if (!dst || bytes != n * sizeof(T)) return fail(c, HIPRZ_ERR_INVALID, std::string(what) + ": destination size mismatch");
     StageTimer timer;
     T* image = reinterpret_cast<T*>(c->image_f4.ptr);
-    RZ_HIP(c, hipMemsetAsync(image, 0, bytes, c->stream));
-    if (c->n_local_tiles)
-        hipLaunchKernelGGL((rz_untile_kernel<T>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, tiles, image,
-                           c->camera.width, c->camera.height, c->tiles_x, c->rank, c->world);
-    // multi-device head: every peer's tiles come over a peer-to-peer copy (xGMI between the GPUs of a node) on THIS stream, after
-    // the peer's stream has finished them, and are untiled into the same image
-    for (hiprz_ctx* p : c->peers) {
-        const T* peer_tiles = peer_tiles_of(p);
-        const size_t peer_bytes = size_t(p->n_local_tiles) * 256u * sizeof(T);
-        if (!peer_bytes) continue;
-        RZ_HIP(c, c->gather.resize(peer_bytes));
-        (void)hipSetDevice(p->device);
-        RZ_HIP(c, hipEventRecord(p->peer_done, p->stream));
-        (void)hipSetDevice(c->device);
-        RZ_HIP(c, hipStreamWaitEvent(c->stream, p->peer_done, 0));
-        RZ_HIP(c, hipMemcpyPeerAsync(c->gather.ptr, c->device, peer_tiles, p->device, peer_bytes, c->stream));
-        hipLaunchKernelGGL((rz_untile_kernel<T>), dim3(p->n_local_tiles), dim3(256), 0, c->stream, reinterpret_cast<const T*>(c->gather.ptr), image,
-                           c->camera.width, c->camera.height, c->tiles_x, p->rank, p->world);
+    // the shards of this context cover the whole frame unless the caller split it further (hiprz_set_shard): only then are there
+    // pixels nobody writes, and only then is the image cleared first
+    if (c->user_world > 1u) RZ_HIP(c, hipMemsetAsync(image, 0, bytes, c->stream));
+    if (c->peers.empty()) {
+        if (c->n_local_tiles)
+            hipLaunchKernelGGL((rz_untile_kernel<T>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, tiles, image,
+                               c->camera.width, c->camera.height, c->tiles_x, c->rank, c->world);
+    } else {
+        // multi-device head: every device's tiles land in a slice of their own of ONE staging buffer — each peer pushes its slice on
+        // ITS stream, behind its own rendering, so the copies of different peers cross their xGMI links side by side — and one launch
+        // on the head's stream, which waits for all of them, untiles every slice (shard rank0 + r of `world` in slice r)
+        const uint32_t n_parts = uint32_t(c->peers.size()) + 1u;
+        const size_t stride = size_t(c->n_local_tiles) * 256u;  // the head owns the lowest rank of the context: no shard has more tiles
+        RZ_HIP(c, c->gather.resize(stride * n_parts * sizeof(T)));
+        T* parts = reinterpret_cast<T*>(c->gather.ptr);
+        if (c->n_local_tiles) RZ_HIP(c, hipMemcpyAsync(parts, tiles, stride * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+        for (uint32_t r = 1; r < n_parts; ++r) {
+            hiprz_ctx* p = c->peers[r - 1u];
+            const size_t peer_bytes = size_t(p->n_local_tiles) * 256u * sizeof(T);
+            if (!peer_bytes) continue;
+            (void)hipSetDevice(p->device);
+            RZ_HIP(c, hipMemcpyPeerAsync(parts + stride * r, c->device, peer_tiles_of(p), p->device, peer_bytes, p->stream));
+            RZ_HIP(c, hipEventRecord(p->peer_done, p->stream));
+            (void)hipSetDevice(c->device);
+            RZ_HIP(c, hipStreamWaitEvent(c->stream, p->peer_done, 0));
+        }
+        const uint32_t n_tiles = c->tiles_x * c->tiles_y;
+        if (c->n_local_tiles)
+            hipLaunchKernelGGL((rz_untile_gathered_kernel<T>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts, stride, image, c->camera.width,
+                               c->camera.height, c->tiles_x, n_tiles, c->world, c->rank);
     }
     RZ_HIP(c, hipMemcpyAsync(dst, image, bytes, hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));
@@ -976,6 +1085,7 @@ int hiprz_destroy(hiprz_ctx* c) {
         c->parked[k].pass_dev.release();
     }
     if (c->peer_done) (void)hipEventDestroy(c->peer_done);
+    if (c->history_done) (void)hipEventDestroy(c->history_done);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream), (void)hipStreamDestroy(c->aux_stream);
     if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
     if (c->aux_join) (void)hipEventDestroy(c->aux_join);
@@ -1412,6 +1522,10 @@ int hiprz_reset(hiprz_ctx* c) {
 
 int hiprz_render(hiprz_ctx* c, uint32_t n_passes) {
     if (!c) return HIPRZ_ERR_INVALID;
+    if (!c->peers.empty() && n_passes) {
+        const int rc = assemble_history(c);
+        if (rc != HIPRZ_OK) return rc;
+    }
     RZ_FANOUT(c, hiprz_render(p, n_passes));
     (void)hipSetDevice(c->device);
     return render_impl(c, n_passes, false);
@@ -1586,10 +1700,10 @@ int hiprz_untile_gathered(hiprz_ctx* c, const void* src_parts, uint32_t world, s
         const dim3 grid(per_rank, world);
         if (element_bytes == 4u)
             hipLaunchKernelGGL((rz_untile_gathered_kernel<uint32_t>), grid, dim3(256), 0, st, reinterpret_cast<const uint32_t*>(src_parts),
-                               part_stride_bytes / 4u, reinterpret_cast<uint32_t*>(dst_image), c->camera.width, c->camera.height, c->tiles_x, n_tiles, world);
+                               part_stride_bytes / 4u, reinterpret_cast<uint32_t*>(dst_image), c->camera.width, c->camera.height, c->tiles_x, n_tiles, world, 0u);
         else
             hipLaunchKernelGGL((rz_untile_gathered_kernel<float4>), grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src_parts),
-                               part_stride_bytes / 16u, reinterpret_cast<float4*>(dst_image), c->camera.width, c->camera.height, c->tiles_x, n_tiles, world);
+                               part_stride_bytes / 16u, reinterpret_cast<float4*>(dst_image), c->camera.width, c->camera.height, c->tiles_x, n_tiles, world, 0u);
     }
     RZ_HIP(c, hipGetLastError());
     return HIPRZ_OK;

@@ -12,7 +12,8 @@
 //   HIPRZ_COMPAT_TEXTURE_MULT  a texture multiplies the material colour, an emission map the emission (cuda_material.cuh:75-123)
 //   HIPRZ_COMPAT_FILTERING     the maps' filter mode (point / linear) and address mode (wrap / clamp / mirror / border) are
 //                              honoured (cuda_buffer.cuh:364-438: CUDA texture objects, normalised coordinates)
-// Not built: temporal reprojection (cuda_camera.cuh:390-426) — it only acts while the camera moves.
+// HIPRZ_COMPAT_REPROJECTION (cuda_camera.cuh:390-426) is not an integrator flag: rz_reproject_kernel (hiprz_api.hip) acts on the frame
+// state after the first pass of a restarted frame, whichever kernels render it.
 #pragma once
 #include "hiprz_device.hpp"
 

@@ -113,6 +113,9 @@ struct hiprz_frame_state {
     hipGraphExec_t graph_exec = nullptr;
     uint32_t graph_passes = 0;
     bool graph_valid = false;
+    // every byte the captured launches were given (kernel arguments, grid sizes, the settings that pick a kernel instantiation): a
+    // graph is replayed only while an eager launch would pass exactly the same — whatever invalidation a code path may have missed
+    std::vector<unsigned char> graph_key;
     // ray reordering between passes (split pipeline, hiprz_sort.hip): keys from the shade kernel -> radix sort -> the permutation the
     // next trace kernel follows
     hiprz::DeviceArray<uint32_t> sort_keys, sort_perm;
@@ -129,6 +132,7 @@ struct hiprz_frame_state {
     hiprz::DeviceArray<float> prev_depth;
     hiprz_camera frame_camera{};  // camera of the frame being accumulated
     bool frame_started = false;   // a first pass ran since the frame buffers were (re)allocated
+    bool history_ready = false;   // prev_accum / prev_depth already hold the whole previous frame (a multi-device head assembled it)
     float temporal_blend = 0.75f;
     hiprz::DeviceArray<uint8_t> gather;  // multi-device head: the peers' tile buffers land here before one launch untiles them all
 };
@@ -146,6 +150,7 @@ struct hiprz_ctx : hiprz_frame_state {
     // readbacks gather the peers' tiles over P2P copies.  Peers have no peers.
     std::vector<hiprz_ctx*> peers;
     hipEvent_t peer_done = nullptr;  // peer side: recorded on its stream when its tiles are ready, awaited by the head's stream
+    hipEvent_t history_done = nullptr;  // head side: the assembled history of a restarted frame has reached every peer
     uint32_t user_rank = 0, user_world = 1;  // hiprz_set_shard as the caller sees it; peers refine it: (rank * n + r, world * n)
 
     // cameras (hiprz_set_camera_count / hiprz_select_camera)

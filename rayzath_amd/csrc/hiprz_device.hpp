@@ -1231,12 +1231,26 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
                         fetch_node_ordered(s, m, oct, m0, m1, mlink);
                         RZ_PHASE(3);
                         RZ_COUNT(box_tests);
-                        if (box_hit_unpacked<RCP>(m0, m1, lr)) {
+                        bool bh = box_hit_unpacked<RCP>(m0, m1, lr);
+#ifdef RZ_EXP_DOUBLE_VALU  // sensitivity experiment: the node step's arithmetic twice, its fetches once
+                        {
+                            float4 m0b = m0;
+                            asm volatile("" : "+v"(m0b.x), "+v"(m0b.y), "+v"(m0b.z), "+v"(m0b.w));
+                            bh = bh & box_hit_unpacked<RCP>(m0b, m1, lr);
+                        }
+#endif
+                        if (bh) {
                             const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                             if (!(mmeta & HIPRZ_NODE_LEAF)) mlink = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);  // enter the nearer child first
                             else tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
                         }
                         m = mlink;
+#ifdef RZ_EXP_EXTRA_FETCH  // sensitivity experiment: one more DEPENDENT fetch per node step (the next node's record, waited for), same arithmetic
+                        if (m != RZ_END) {
+                            float probe = reinterpret_cast<const volatile float*>(s.nodes64 + 4 * size_t(m))[7];
+                            asm volatile("" : "+v"(m) : "v"(probe));
+                        }
+#endif
                     }
                 }
                 if (!__any(tj != tj_end)) continue;

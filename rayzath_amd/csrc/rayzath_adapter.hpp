@@ -54,6 +54,13 @@ public:
         const bool geometry = !m_valid || modified<OT::Mesh>(world) || modified<OT::Instance>(world) || modified<OT::Group>(world) ||
                               modified<OT::Texture>(world) || modified<OT::NormalMap>(world) || modified<OT::MetalnessMap>(world) ||
                               modified<OT::RoughnessMap>(world) || modified<OT::EmissionMap>(world);
+        // the world's flag is the OR of all its containers' (updatable.cpp:23-27): a camera that moved its ray-cast pixel, say, sets it
+        // too, and is none of the scene mirror's business
+        const bool shading_modified = modified<OT::Material>(world) || modified<OT::SpotLight>(world) || modified<OT::DirectLight>(world);
+        if (!geometry && !shading_modified) {
+            world.stateRegister().MakeUnmodified();
+            return Change::None;
+        }
         Change change = Change::Scene;
         if (!geometry) {
             // materials and lights only — unless a material now points at a map the uploaded scene does not hold

@@ -85,8 +85,12 @@ class Context:
         self.width, self.height = self._sizes.get(index, (0, 0))
 
     def update_shading(self, flat_scene):
-        """Materials and lights of `flat_scene` replace those of the uploaded scene in place (same material count); no tree work."""
+        """Materials and lights of `flat_scene` replace those of the uploaded scene in place (same material count); no tree work.
+        Map indices are positions in the UPLOADED scene's texture list: when `flat_scene` numbers other map objects, or the same ones in
+        another order (a material re-pointed at another uploaded map changes the first-use order), the whole scene is uploaded instead."""
         f = flat_scene
+        if getattr(f, "map_ids", None) != getattr(self, "_uploaded_map_ids", None) or f.map_ids is None:
+            return self.upload_scene(f)
         self._check(self.lib.hiprz_update_shading(self._ctx, f.materials.ctypes.data, len(f.materials), f.spot_lights.ctypes.data, len(f.spot_lights),
                                                   f.direct_lights.ctypes.data, len(f.direct_lights)))
 
@@ -108,6 +112,7 @@ class Context:
     # --- uploads ---
     def upload_scene(self, flat_scene):
         self._check(self.lib.hiprz_upload_scene(self._ctx, C.byref(flat_scene.struct)))
+        self._uploaded_map_ids = getattr(flat_scene, "map_ids", None)
 
     def upload_camera(self, camera_struct_):
         self._check(self.lib.hiprz_upload_camera(self._ctx, C.byref(camera_struct_)))
@@ -303,17 +308,15 @@ class Engine:
         return self._context
 
     def set_mode(self, compat_flags):
-        """Context.set_mode for the engine's context; COMPAT_REPROJECTION keeps the frame in ONE context (history is carried over within
-        a share only)."""
+        """Context.set_mode for the engine's context (COMPAT_REPROJECTION works over several streams / devices too: the context assembles
+        the whole previous frame at a restart)."""
         self._mode = compat_flags
-        if compat_flags & COMPAT_REPROJECTION and self._context is not None and self._streams is None and self._context.device_count() > 1:
-            self._context.close()
-            self._context, self._world_key, self._camera_key, self._camera_ids = Context(self._device), None, {}, None
-        self.context.set_mode(compat_flags)
+        if self._context is not None:
+            self._context.set_mode(compat_flags)
 
     def renderWorld(self, world, render_config, block=True, sync=True):
         if self._context is None and not isinstance(self._device, (list, tuple)):
-            k = self._streams or (1 if getattr(self, "_mode", 0) & COMPAT_REPROJECTION else default_streams(len(world.spot_lights) + len(world.direct_lights)))
+            k = self._streams or default_streams(len(world.spot_lights) + len(world.direct_lights))
             self._context = Context([self._device] * k) if k > 1 else Context(self._device)
             if getattr(self, "_mode", 0):
                 self._context.set_mode(self._mode)

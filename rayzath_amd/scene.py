@@ -382,6 +382,8 @@ class FlatScene:
         for k in self.FIELDS:
             setattr(self, k, np.ascontiguousarray(arrays[k]))
         self.tlas_root = int(arrays.get("tlas_root", 0))
+        # the map objects behind `textures`, by identity, in texture-index order (None: unknown, e.g. a snapshot loaded from a file)
+        self.map_ids = arrays.get("map_ids")
         s = _abi.Scene()
         s.n_nodes, s.nodes = len(self.nodes), self.nodes.ctypes.data
         s.tlas_root = self.tlas_root
@@ -437,7 +439,7 @@ def flatten(world, backend=None):
     """World -> FlatScene (the arrays `hiprz_upload_scene` copies)."""
     backend = backend or HostBackend()
     # textures, deduplicated by identity
-    tex_index, tex_records, pool = {}, [], bytearray()
+    tex_index, tex_records, pool, map_ids = {}, [], bytearray(), []
 
     def tex_id(t):
         if t is None:
@@ -454,6 +456,7 @@ def flatten(world, backend=None):
             pool.extend(t.bitmap.tobytes())
             tex_index[id(t)] = len(tex_records)
             tex_records.append(rec)
+            map_ids.append(id(t))
         return tex_index[id(t)]
 
     mats = [world.material, world.default_material] + list(world.materials)
@@ -527,7 +530,7 @@ def flatten(world, backend=None):
         instances=instances, inst_materials=np.array(inst_materials, dtype=np.int32), materials=materials,
         textures=np.array(tex_records, dtype=_abi.texture_dtype) if tex_records else np.zeros(0, _abi.texture_dtype),
         texels=np.frombuffer(bytes(pool), dtype=np.uint8).copy() if pool else np.zeros(0, np.uint8),
-        spot_lights=spots, direct_lights=directs)
+        spot_lights=spots, direct_lights=directs, map_ids=tuple(map_ids))
 
 
 def camera_struct(cam, backend=None):

@@ -57,6 +57,26 @@ def test_multi_device_context_equals_single_device(built, scene, devices):
     assert (halves[0][..., 3] > 0).sum() + (halves[1][..., 3] > 0).sum() == (one.read_accum()[..., 3] > 0).sum()
 
 
+def test_multi_device_context_over_two_physical_gpus(built):
+    """hiprz_create_multi with two DISTINCT devices (peer access, cross-device event waits, hipMemcpyPeerAsync gather): the frame of one
+    device, bit for bit.  Needs a box with two GPUs; the one-GPU boxes of this pool skip it (the [0, 0] variants above run the same code
+    with both shards on one device)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    world = scenes.living_room(160, 96, 16)
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(LightSampling(2, 1), Tracing(5, 4)).struct()
+    one, two = Context(0), Context([0, 1])
+    for c in (one, two):
+        c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+        c.render(1), c.render(4), c.render(4)
+    _same(_all(one), _all(two))
+    assert one.ray_count() == two.ray_count()
+    for xy in [(10, 10), (100, 60), (150, 90)]:
+        assert one.pick(*xy) == two.pick(*xy)
+
+
 def test_every_camera_has_its_own_frame(built):
     world = scenes.cornell_sphere(160, 96, resolution=24)
     flat = flatten(world)
@@ -147,6 +167,31 @@ def test_update_shading_equals_a_full_upload(built):
     assert a.pass_count() == 5                               # the change restarted accumulation
     with pytest.raises(Exception):
         a.update_shading(flatten(scenes.cornell_box(64, 64)))  # another material count: refused
+
+
+def test_update_shading_with_repointed_maps_falls_back_to_a_full_upload(built):
+    """Two materials swap their uploaded textures: the first-use numbering of the maps changes, so the indices of the in-place path
+    would name the wrong texels.  Context.update_shading notices (identity list of the uploaded maps) and uploads the scene."""
+    world = scenes.shading_inputs_scene(96, 64)
+    textured = [m for m in world.materials if m.texture is not None]
+    assert len(textured) >= 2
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(LightSampling(1, 1), Tracing(5, 4)).struct()
+    a = Context(0)
+    a.upload_scene(flat), a.upload_camera(cam), a.set_config(cfg)
+    a.render(5)
+    textured[0].texture, textured[1].texture = textured[1].texture, textured[0].texture
+    changed = flatten(world)
+    assert changed.map_ids != flat.map_ids and sorted(changed.map_ids) == sorted(flat.map_ids)
+    a.update_shading(changed)
+    a.render(5)
+    b = Context(0)
+    b.upload_scene(changed), b.upload_camera(cam), b.set_config(cfg)
+    b.render(5)
+    _same(_all(a), _all(b))
+    ref = oracle.OracleRenderer(changed, cam, cfg)
+    ref.render(5, threads=2)
+    assert np.array_equal(a.read_depth(), ref.depth) and np.array_equal(a.read_accum()[..., 3], ref.accum[..., 3])
 
 
 def _grouped_world(mode):

@@ -79,3 +79,11 @@ def test_cpp_engine_renders_like_the_python_host(built, tmp_path):
     assert d["image"] == ctx.read_rgba8().tobytes() and d["depth"] == ctx.read_depth().tobytes()
     assert struct.unpack("<Q", d["ray_count"])[0] == ctx.ray_count() == 3 * (calls + 1) * 96 * 64
     assert d["threw"] == b"\x01"            # broken world -> Hip::Exception(HIPRZ_ERR_INVALID), no device fault
+
+
+@pytest.mark.gpu
+def test_cpp_engine_reuploads_when_a_material_is_repointed_at_another_uploaded_map(built):
+    """World::makeShadingModified() after two materials swapped their (already uploaded) textures: the map indices of the in-place path
+    are positions in the uploaded texture list, so the engine has to notice that the first-use order changed and upload the scene again."""
+    proc = subprocess.run([EXE, "swapmaps", "-"], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0 and "swapped maps equal, colour change equal" in proc.stdout, proc.stdout + proc.stderr

@@ -290,8 +290,10 @@ def test_reprojection_of_an_unchanged_view_adds_the_blended_history(pipeline):
     assert np.array_equal(plain.read_accum(), first)
 
 
-def test_reprojection_follows_a_moved_camera():
-    """The camera steps sideways and turns a little: history comes from where the surface WAS on the previous screen, and only where
+@pytest.mark.parametrize("devices", [0, [0, 0], [0, 0, 0]])
+def test_reprojection_follows_a_moved_camera(devices):
+    """(Also over several shards of one multi-device context: the history is the WHOLE previous frame, assembled from every device, so the
+    result is that of one device bit for bit.)  The camera steps sideways and turns a little: history comes from where the surface WAS on the previous screen, and only where
     the previous depth buffer holds the same surface.  Against a numpy restatement of Camera::reproject on the frames read back."""
     from rayzath_amd.engine import COMPAT_REPROJECTION
     world = scenes.cornell_sphere(128, 96, 12)
@@ -303,7 +305,7 @@ def test_reprojection_follows_a_moved_camera():
                    focal_distance=world.camera.focal_distance, aperture=world.camera.aperture, exposure_time=world.camera.exposure_time)
     cam_now = camera_struct(moved)
     cfg = RenderConfig(tracing=Tracing(5, 4)).struct()
-    ctx = Context(0)
+    ctx = Context(devices)
     ctx.set_mode(COMPAT_REPROJECTION)
     ctx.upload_scene(flat), ctx.upload_camera(cam_prev), ctx.set_config(cfg)
     ctx.render(1), ctx.render(5)
@@ -323,3 +325,11 @@ def test_reprojection_follows_a_moved_camera():
     close = np.abs(got - want) <= 1e-4 * np.maximum(np.abs(want), 1.0)
     assert close[safe].all(-1).mean() >= 0.999
     assert (got[took][..., 3] > first[took][..., 3]).mean() > 0.9 and (got[~took][..., 3] <= 1.0).all()   # sample counts travel with the colour
+    if devices != 0:                                                     # the same frame as ONE device renders, history included
+        one = Context(0)
+        one.set_mode(COMPAT_REPROJECTION)
+        one.upload_scene(flat), one.upload_camera(cam_prev), one.set_config(cfg)
+        one.render(1), one.render(5)
+        one.upload_camera(cam_now)
+        one.render(1)
+        assert np.array_equal(one.read_accum(), got)

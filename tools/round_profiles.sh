@@ -1,9 +1,10 @@
 #!/bin/bash
 # On the GPU box: the round's profile set — for every config the bench line, the rocprofv3 kernel stats of the same command, the HBM
-# traffic from the FETCH_SIZE / WRITE_SIZE passes, and SQ counter passes.  Summaries land in gpurun_out/r02/.
+# traffic from the FETCH_SIZE / WRITE_SIZE passes, and SQ counter passes.  Summaries land in gpurun_out/$ROUND/ (ROUND=r03 by default).
+# usage: [ROUND=r03] tools/round_profiles.sh [configs...]
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r02; mkdir -p $OUT
+OUT=$R/gpurun_out/${ROUND:-r03}; mkdir -p $OUT
 for c in ${@:-B C D E}; do
   echo "== config $c"
   bash $R/tools/profile_gpu.sh $c --config $c > $OUT/profile_$c.log 2>&1 || { tail -5 $OUT/profile_$c.log; exit 1; }
