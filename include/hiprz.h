@@ -345,7 +345,29 @@ int hiprz_set_temporal_blend(hiprz_ctx* ctx, float blend);
  * (the scene is not staged in LDS), and the work counters are those of the rebuilt tree.  Takes effect at the next hiprz_upload_scene. */
 #define HIPRZ_TREE_REFERENCE 0u
 #define HIPRZ_TREE_SAH 1u
+/* HIPRZ_TREE_DEVICE: the trees are built ON THE DEVICE at upload (the reference rebuilds them on the host at every change,
+ * bvh_tree_node.hpp:117-215, component_container.hpp:259-363, cuda_engine_core.cu:58-60): every mesh tree by kernels — Morton order of
+ * the triangle centroids, a binary radix tree, boxes bottom-up, leaves of at most 4 triangles, the skip links of all 8 ray octants —
+ * and the world tree over the instances by the reference's own top-down builder run on the device (the order in which a ray meets the
+ * instances is part of its arithmetic, so that tree must be the reference's: it is, node for node).  Frames are those of the reference
+ * trees bit for bit.  Afterwards hiprz_update_triangles and hiprz_update_instances change geometry without a host-side tree build. */
+#define HIPRZ_TREE_DEVICE 2u
 int hiprz_set_tree(hiprz_ctx* ctx, uint32_t tree);
+/* Scenes uploaded under HIPRZ_TREE_DEVICE only.  New records for the triangles [first, first + n) of the uploaded snapshot's order
+ * (vertices moved, normals / texture coordinates / face normals as the caller computed them; materials and source indices are taken
+ * from the new records): the device copies are rewritten and the boxes of the mesh trees that hold them are fitted again, bottom-up,
+ * on the device — the topology of the trees stays.  Restarts accumulation.  Follow with hiprz_update_instances when a mesh's extent
+ * changed (the instances' world-space boxes are the caller's, Instance::calculateBoundingBox, instance.cpp:117-155). */
+int hiprz_update_triangles(hiprz_ctx* ctx, uint32_t first, uint32_t n, const hiprz_tri* tris, const hiprz_tri_attr* attrs);
+/* Scenes uploaded under HIPRZ_TREE_DEVICE only.  New transformations and world-space boxes for ALL instances (n = the uploaded count;
+ * position, scale, axes and box are taken from the records, mesh and material tables stay as uploaded): the world tree is rebuilt on
+ * the device.  Restarts accumulation. */
+int hiprz_update_instances(hiprz_ctx* ctx, const hiprz_instance* instances, uint32_t n);
+/* The trees the context walks now, as a snapshot would hold them (for validation and tests): node records with plain boxes, the world
+ * tree's root and leaf order, every instance's mesh root, and for every triangle of the device order its position in the uploaded
+ * order.  Any output may be NULL. */
+int hiprz_download_trees(hiprz_ctx* ctx, hiprz_node* nodes_out, uint32_t max_nodes, uint32_t* n_nodes_out, uint32_t* tlas_root_out,
+                         uint32_t* tlas_order_out, uint32_t* blas_roots_out, uint32_t* tri_refpos_out);
 /* The rebuild itself (pure host): new node array (world tree copied, mesh trees rebuilt; at most max_nodes = n_nodes + 2 * n_tris +
  * n_instances), tri_order_out[new index] = index in scene->tris, blas_roots_out[instance] = its mesh root in the new array. */
 int hiprz_rebuild_mesh_trees(const hiprz_scene* scene, uint32_t tree, hiprz_node* nodes_out, uint32_t max_nodes, uint32_t* n_nodes_out,

@@ -124,6 +124,9 @@ ENTRY_POINTS = {
     "hiprz_update_shading": (C.c_int, [P, P, U32, P, U32, P, U32]),
     "hiprz_set_tree": (C.c_int, [P, U32]),
     "hiprz_rebuild_mesh_trees": (C.c_int, [C.POINTER(Scene), U32, P, U32, C.POINTER(U32), P, P, C.POINTER(U32)]),
+    "hiprz_update_triangles": (C.c_int, [P, U32, U32, P, P]),
+    "hiprz_update_instances": (C.c_int, [P, P, U32]),
+    "hiprz_download_trees": (C.c_int, [P, P, U32, C.POINTER(U32), C.POINTER(U32), P, P, P]),
     "hiprz_set_lds_scene": (C.c_int, [P, C.c_int]),
     "hiprz_set_pipeline": (C.c_int, [P, C.c_int]),
     "hiprz_traversal_mode": (C.c_int, [P, C.POINTER(C.c_int)]),

@@ -443,11 +443,25 @@ bool defer_shadows(const hiprz_ctx* c) {
            c->config.spot_samples + c->config.direct_samples <= 30u;
 }
 
+// the resident pipeline on a scene that is not staged in LDS: per-wave chains of passes (rz_wave_batch_kernel); needs the front-to-back
+// walk (mode 3) and a scene without lights (shadow rays are deferred to a kernel of their own otherwise)
+bool wave_resident(const hiprz_ctx* c) {
+    return c->pipeline == 2 && !use_lds_scene(c) && c->dscene.n_spot_lights + c->dscene.n_direct_lights == 0u && c->nolight_kernels && c->walk_order != 0 &&
+           (c->traversal_mode == -1 || c->traversal_mode == 3);
+}
+
 void resolve_pipeline(hiprz_ctx* c) {
     const int before = c->pipeline;
+    // a shard small enough to be ONE round of waves on the chip pays the slowest wave of every kernel of every pass in the split
+    // pipeline; without lights it runs per-wave chains of passes instead (hiprz_kernels.hpp: rz_wave_batch_kernel)
+    const bool dark_capable = c->have_scene && !c->lds_scene && c->dscene.n_spot_lights + c->dscene.n_direct_lights == 0u && c->nolight_kernels && c->walk_order != 0 &&
+                              (c->traversal_mode == -1 || c->traversal_mode == 3);
+    const bool small_dark_shard = dark_capable && c->have_camera && c->n_local_tiles != 0u && c->n_local_tiles * 4u <= c->wave_resident_max;
     if (c->mode_flags & kIntegratorFlags) c->pipeline = 0;  // CUDA-compat mode: the fused compat kernel
-    else if (c->scene_tree != HIPRZ_TREE_REFERENCE) c->pipeline = 1;
+    else if (c->scene_tree != HIPRZ_TREE_REFERENCE)  // rebuilt trees: the front-to-back cooperative walks only (split, or per-wave resident)
+        c->pipeline = dark_capable && (c->pipeline_setting == 2 || (c->pipeline_setting < 0 && small_dark_shard)) ? 2 : 1;
     else if (c->pipeline_setting >= 0) c->pipeline = c->pipeline_setting;
+    else if (small_dark_shard) c->pipeline = 2;
     else {
         // resident needs blob + walk workspace + 8 KiB of parked state per workgroup, four workgroups per CU
         const size_t lds = size_t(c->dscene.hot_bytes) + size_t(c->stack_entries) * 1024u + BinnedLds::kFixedBytes + 8u * 1024u;
@@ -480,7 +494,7 @@ PassGeometry pass_geometry(const hiprz_ctx* c) {
     g.lds_scene = use_lds_scene(c);
     g.blob = g.lds_scene ? c->dscene.hot_bytes : 0u;
     g.mode = effective_mode(c);
-    if (g.mode >= 3 && (g.lds_scene || c->pipeline != 1)) g.mode = 1;  // skip links are for scenes that are not staged whole, in the trace kernel
+    if (g.mode >= 3 && (g.lds_scene || (c->pipeline != 1 && !wave_resident(c)))) g.mode = 1;  // skip links are for scenes that are not staged whole: trace kernel, wave batch kernel
     g.stack_lds = size_t(c->stack_entries) * 256u * sizeof(uint32_t);
     g.walk_lds = g.mode == 2 ? size_t(BinnedLds::bytes_host(c->dscene.world_stack_entries, c->dscene.mesh_stack_entries)) : g.mode == 1 ? g.stack_lds : 0u;
     return g;
@@ -493,7 +507,7 @@ namespace {
 // one pass on the stream: trace + shade (split pipeline) or the fused kernel
 void launch_pass(hiprz_ctx* c, const DFrame& f, bool first, bool counted, hipEvent_t between_trace_and_shade = nullptr) {
     c->sorted_this_pass = false;
-    if (c->pipeline == 1) {
+    if (c->pipeline == 1 || wave_resident(c)) {  // (the first pass of a wave-resident frame: the split kernels)
         launch_trace(c, f, first, counted);
         if (between_trace_and_shade) (void)hipEventRecord(between_trace_and_shade, c->stream);
         launch_shade(c, f, first, counted);
@@ -576,6 +590,7 @@ std::vector<unsigned char> graph_key_of(hiprz_ctx* c, const DFrame& f, uint32_t 
 int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
     if (!c->have_scene || !c->have_camera) return fail(c, HIPRZ_ERR_STATE, "render before scene and camera upload");
     if (n_passes == 0 || c->n_local_tiles == 0) return HIPRZ_OK;
+    resolve_pipeline(c);  // the choice depends on the selected camera's shard size too
     StageTimer timer;
     if (defer_shadows(c)) {  // hand-over buffers of the deferred shadow rays: (4 + 2 * samples) float4 per owned pixel
         const size_t n = size_t(c->n_local_tiles) * 256u, k = c->config.spot_samples + c->config.direct_samples;
@@ -741,6 +756,7 @@ int read_untiled(hiprz_ctx* c, const T* tiles, T* dst, size_t bytes, const char*
 // the world-tree leaves and the tree depths the upload needs.
 struct SceneCheck {
     std::string error;
+    std::vector<uint8_t> reachable;  // nodes some walk can get to (a snapshot may hold others: they are never followed)
     std::vector<uint32_t> skip;
     std::vector<uint32_t> world_leaves;
     uint32_t world_depth = 0, mesh_depth = 0;
@@ -802,6 +818,7 @@ int check_scene(const hiprz_scene* sc, SceneCheck& out) {
         }
     }
     out.skip = std::move(skip);
+    out.reachable = std::move(check.visited);
     out.world_leaves = std::move(check.world_leaves);
     out.world_depth = world_depth, out.mesh_depth = mesh_depth;
     return HIPRZ_OK;
@@ -830,15 +847,24 @@ int derive_tables(const hiprz_scene* sc, SceneCheck& chk, DerivedTables& out) {
     };
     if (sc->n_instances) enqueue(sc->tlas_root);
     for (uint32_t i = 0; i < sc->n_tlas_order; ++i) enqueue(sc->instances[sc->tlas_order[i]].blas_root);
+    // Child pairs follow the roots.  A 64-byte record pair is one 128-byte cache line when it starts at an even index: one empty slot
+    // behind an odd number of roots puts every pair on a line of its own, so that the second child — visited after the first one's
+    // subtree, or probed together with it — is on the line the first one brought in.
+    const uint32_t pad_at = (bfs.size() & 1u) ? uint32_t(bfs.size()) : RZ_END;
+    if (pad_at != RZ_END) bfs.push_back(RZ_END);
     for (size_t q = 0; q < bfs.size(); ++q) {
+        if (bfs[q] == RZ_END) continue;
         const hiprz_node& n = sc->nodes[bfs[q]];
         if (!(n.meta & HIPRZ_NODE_LEAF)) enqueue(n.begin), enqueue(n.begin + 1);
     }
     for (uint32_t old = 0; old < sc->n_nodes; ++old) enqueue(old);  // nodes no instance reaches keep a slot
+    const size_t n_total = bfs.size();  // the scene's nodes + the padding slot
     std::vector<hiprz_node>& dnodes = out.dnodes;
     std::vector<uint32_t>& dskip = out.dskip;
-    dnodes.assign(sc->n_nodes, hiprz_node{});
-    dskip.assign(sc->n_nodes ? sc->n_nodes : 1, RZ_END);
+    hiprz_node empty{};
+    empty.meta = HIPRZ_NODE_LEAF;  // no triangles, reached by nothing
+    dnodes.assign(n_total ? n_total : 0, empty);
+    dskip.assign(n_total ? n_total : 1, RZ_END);
     for (uint32_t old = 0; old < sc->n_nodes; ++old) {
         hiprz_node n = sc->nodes[old];
         if (!(n.meta & HIPRZ_NODE_LEAF)) n.begin = new_index[n.begin];
@@ -852,12 +878,12 @@ int derive_tables(const hiprz_scene* sc, SceneCheck& chk, DerivedTables& out) {
     // parent's link.  Parents precede their children in the breadth-first numbering, so one ascending sweep fills all tables;
     // roots end their walks (RZ_END).  Octant 0 reproduces dskip.
     std::vector<uint32_t>& dskip8 = out.dskip8;
-    dskip8.assign(size_t(sc->n_nodes ? sc->n_nodes : 1) * 8u, RZ_END);
-    for (uint32_t n = 0; n < sc->n_nodes; ++n) {
+    dskip8.assign((n_total ? n_total : 1) * 8u, RZ_END);
+    for (uint32_t n = 0; n < n_total; ++n) {
         const hiprz_node& nd = dnodes[n];
         if (nd.meta & HIPRZ_NODE_LEAF) continue;
         const uint32_t ptype = (nd.meta >> HIPRZ_NODE_PTYPE_SHIFT) & 3u, c0 = nd.begin;
-        if (c0 <= n || size_t(c0) + 1 >= sc->n_nodes) continue;  // cannot happen after check_scene + the BFS relayout; keeps the sweep safe
+        if (c0 <= n || size_t(c0) + 1 >= n_total) continue;  // cannot happen after check_scene + the BFS relayout; keeps the sweep safe
         for (uint32_t o = 0; o < 8u; ++o) {
             const uint32_t flip = (o >> ptype) & 1u;  // ptype 3 reads bit 3 = 0
             dskip8[size_t(c0 + flip) * 8u + o] = c0 + 1u - flip;
@@ -898,10 +924,11 @@ int derive_tables(const hiprz_scene* sc, SceneCheck& chk, DerivedTables& out) {
             }
             return false;
         };
-        for (uint32_t n = 0; ok && n < sc->n_nodes; ++n) ok = dskip8[size_t(n) * 8u] == dskip[n];
+        for (uint32_t old = 0; ok && old < sc->n_nodes; ++old)  // octant 0 is the reference's order (nodes no walk reaches have no links to compare)
+            if (old < chk.reachable.size() && chk.reachable[old]) ok = dskip8[size_t(new_index[old]) * 8u] == dskip[new_index[old]];
         if (ok && sc->n_instances) ok = terminates8(new_index[sc->tlas_root], 0u);
         {
-            std::vector<uint8_t> seen(sc->n_nodes ? sc->n_nodes : 1, 0);
+            std::vector<uint8_t> seen(n_total ? n_total : 1, 0);
             for (uint32_t i = 0; ok && i < sc->n_tlas_order; ++i) {
                 const uint32_t root = new_index[sc->instances[sc->tlas_order[i]].blas_root];
                 if (seen[root]) continue;
@@ -974,6 +1001,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     if (const char* w = std::getenv("HIPRZ_NOLIGHT_KERNELS")) c->nolight_kernels = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SORT_BITS")) c->sort_bits = std::min(24, std::max(0, std::atoi(w)));
     if (const char* w = std::getenv("HIPRZ_SHADOW_SORT")) c->shadow_sort = std::atoi(w) != 0;
+    if (const char* w = std::getenv("HIPRZ_WAVE_RESIDENT_MAX")) c->wave_resident_max = uint32_t(std::max(0, std::atoi(w)));
     c->device = device_id;
     c->parked.resize(1);  // one camera; its state lives in the context itself
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -1097,6 +1125,9 @@ int hiprz_destroy(hiprz_ctx* c) {
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     for (auto e : c->kernel_events) (void)hipEventDestroy(e);
     c->hot.release(), c->node_skip.release(), c->nodes64.release(), c->textures.release();
+    c->dev_nodes.release(), c->has_mesh.release(), c->build_temp.release(), c->slot_parent.release(), c->ref_to_dev.release(), c->refit_visit.release();
+    c->world_items.release(), c->update_tris.release(), c->update_attrs.release();
+    c->build_sort.keys_out.release(), c->build_sort.vals_a.release(), c->build_sort.vals_b.release(), c->build_sort.counts.release(), c->build_sort.digit_total.release();
     c->texels.release(), c->spot_lights.release(), c->direct_lights.release();
     release_frame(c);
     c->pass_dev.release(), c->counters_dev.release(), c->pick_dev.release();
@@ -1222,10 +1253,47 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     if (blob.size() > 0xFFFFFFF0ull) return fail(c, HIPRZ_ERR_INVALID, "scene geometry exceeds 4 GiB");
     d.hot_bytes = uint32_t(blob.size());
 
+    // HIPRZ_TREE_DEVICE: the node arrays get room behind the uploaded prefix for the world tree (2 * instances + 1 slots) and for every
+    // mesh tree (2 * triangles - 1 slots) the device is going to build; regions start at odd slots, their child pairs at even ones
+    const bool device_trees = own_trees && c->tree_mode == HIPRZ_TREE_DEVICE;
+    std::vector<DeviceMesh> device_meshes;
+    std::vector<uint32_t> instance_mesh(sc->n_instances, RZ_END);
+    uint32_t node_capacity = uint32_t(dnodes.size()), world_region = 0u;
+    if (device_trees) {
+        std::vector<uint32_t> mesh_of_root(sc->n_nodes, RZ_END);
+        for (uint32_t i = 0; i < sc->n_instances; ++i) {
+            const uint32_t root = sc->instances[i].blas_root;
+            if (root >= sc->n_nodes) continue;
+            if (mesh_of_root[root] == RZ_END) {
+                const hiprz_node& leaf = sc->nodes[root];  // the placeholder of hiprz_rebuild_mesh_trees(.., HIPRZ_TREE_DEVICE, ..): one leaf per mesh
+                DeviceMesh m;
+                m.tri_first = leaf.begin, m.n_tris = leaf.meta & HIPRZ_NODE_COUNT_MASK;
+                m.ref_first = m.n_tris ? sc->tris[leaf.begin].pad0 : 0u;
+                std::memcpy(m.bb_min, leaf.bb_min, 12), std::memcpy(m.bb_max, leaf.bb_max, 12);
+                mesh_of_root[root] = uint32_t(device_meshes.size());
+                device_meshes.push_back(m);
+            }
+            instance_mesh[i] = mesh_of_root[root];
+        }
+        uint32_t cursor = uint32_t(dnodes.size());
+        if (!(cursor & 1u)) cursor += 1u;
+        world_region = cursor;
+        cursor += 2u * sc->n_instances + 1u;
+        node_capacity = device_build_regions(device_meshes, cursor);
+        dskip.resize(node_capacity, RZ_END);
+    }
     RZ_HIP(c, c->hot.assign(blob.data(), blob.size(), c->stream));
     RZ_HIP(c, c->node_skip.assign(dskip.data(), dskip.size(), c->stream));
+    if (device_trees) {
+        hiprz_node unused{};
+        unused.meta = HIPRZ_NODE_LEAF;  // slots no build fills stay empty leaves nothing links to
+        std::vector<hiprz_node> all(node_capacity, unused);
+        std::copy(dnodes.begin(), dnodes.end(), all.begin());
+        RZ_HIP(c, c->dev_nodes.assign(reinterpret_cast<const uint8_t*>(all.data()), all.size() * sizeof(hiprz_node), c->stream));
+        RZ_HIP(c, hipStreamSynchronize(c->stream));
+    }
     // front-to-back walk: 64-B records, node (interleaved box) + the 8 octant links
-    std::vector<uint32_t> nodes64(size_t(dnodes.size() ? dnodes.size() : 1) * 16u, RZ_END);
+    std::vector<uint32_t> nodes64(size_t(node_capacity ? node_capacity : 1) * 16u, RZ_END);
     for (size_t n = 0; n < dnodes.size(); ++n) {
         std::memcpy(&nodes64[n * 16u], &dnodes[n], sizeof(hiprz_node));
         std::memcpy(&nodes64[n * 16u + 8u], &derived.dskip8[n * 8u], 32);
@@ -1258,7 +1326,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
         d.bounds_min[a] = lo;
         d.bounds_scale[a] = hi > lo ? 32.0f / (hi - lo) : 0.0f;
     }
-    d.top_count = std::min<uint32_t>(sc->n_nodes, kTopCacheNodes);
+    d.top_count = std::min<uint32_t>(uint32_t(dnodes.size()), kTopCacheNodes);
     d.nodes64 = reinterpret_cast<const float4*>(c->nodes64.ptr);
     c->n_nodes = sc->n_nodes;
     c->flat_world = sc->n_instances != 0u && (sc->nodes[sc->tlas_root].meta & HIPRZ_NODE_LEAF) && (sc->nodes[sc->tlas_root].meta & HIPRZ_NODE_COUNT_MASK) <= 8u;
@@ -1283,6 +1351,33 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     c->lds_scene = size_t(d.hot_bytes) + size_t(c->stack_entries) * 1024u + BinnedLds::kFixedBytes <= kLdsSceneLimit;
     c->scene_tree = own_trees ? c->tree_mode : HIPRZ_TREE_REFERENCE;
     if (own_trees) c->lds_scene = false;  // rebuilt trees are walked front to back on skip links only (ties by reference position)
+    c->n_tris = sc->n_tris, c->n_tlas_order = sc->n_tlas_order;
+    c->device_meshes.clear(), c->instance_mesh.clear();
+    if (device_trees) {
+        const bool validate = !std::getenv("HIPRZ_TRUST_DEVICE_TREES");
+        d.nodes = reinterpret_cast<const float4*>(c->dev_nodes.ptr);
+        c->node_capacity = node_capacity, c->world_region = world_region;
+        c->device_instances = dinstances;
+        std::vector<uint8_t> has_mesh(sc->n_instances ? sc->n_instances : 1u, 0);
+        for (uint32_t i = 0; i < sc->n_instances; ++i) has_mesh[i] = instance_mesh[i] != RZ_END ? 1 : 0;
+        RZ_HIP(c, c->has_mesh.assign(has_mesh.data(), has_mesh.size(), c->stream));
+        RZ_HIP(c, hipStreamSynchronize(c->stream));
+        RZ_HIP(c, c->slot_parent.resize(node_capacity));
+        int rc = HIPRZ_OK;
+        if (sc->n_tlas_order) {
+            rc = device_build_world_tree(c, validate);
+            if (rc != HIPRZ_OK) return rc;
+            d.tlas_root = world_region;
+        }
+        rc = device_build_mesh_trees(c, device_meshes, instance_mesh, validate);
+        if (rc != HIPRZ_OK) return rc;
+        c->instance_mesh = instance_mesh;
+        for (uint32_t i = 0; i < sc->n_instances; ++i)
+            if (instance_mesh[i] != RZ_END && c->device_meshes[instance_mesh[i]].region != RZ_END) c->device_instances[i].blas_root = c->device_meshes[instance_mesh[i]].region;
+        uint32_t emitted = c->world_slots;
+        for (const auto& m : c->device_meshes) emitted += m.n_slots;
+        c->n_nodes = emitted;
+    }
     c->have_scene = true;
     resolve_pipeline(c);
     c->reset_pending = true;  // world changed => accumulation restarts (cpu_engine_renderer.cpp:108-112), for every camera
@@ -1326,6 +1421,98 @@ int hiprz_update_shading(hiprz_ctx* c, const hiprz_material* materials, uint32_t
     invalidate_graphs(c);
     c->reset_pending = true;  // the world changed: accumulation restarts (cpu_engine_renderer.cpp:108-112), for every camera
     for (auto& f : c->parked) f.reset_pending = true;
+    return HIPRZ_OK;
+}
+
+// ---- geometry changes without a host-side tree build (scenes uploaded under HIPRZ_TREE_DEVICE; hiprz_build.hip) ----
+namespace {
+int restart_after_geometry_change(hiprz_ctx* c) {
+    c->reset_pending = true;  // the world changed: accumulation restarts (cpu_engine_renderer.cpp:108-112), for every camera
+    for (auto& f : c->parked) f.reset_pending = true;
+    return HIPRZ_OK;
+}
+}  // namespace
+
+int hiprz_update_triangles(hiprz_ctx* c, uint32_t first, uint32_t n, const hiprz_tri* tris, const hiprz_tri_attr* attrs) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_update_triangles(p, first, n, tris, attrs));
+    if (!c->have_scene || c->scene_tree != HIPRZ_TREE_DEVICE) return fail(c, HIPRZ_ERR_STATE, "update_triangles: the scene was not uploaded under HIPRZ_TREE_DEVICE");
+    if (n == 0u) return HIPRZ_OK;
+    if (!tris || !attrs || uint64_t(first) + n > c->n_tris) return fail(c, HIPRZ_ERR_INVALID, "update_triangles: range outside the uploaded triangles");
+    for (uint32_t k = 0; k < n; ++k)  // the walks divide by nothing here, but the shading indexes material slots
+        if ((tris[k].material_flags & HIPRZ_TRI_MATERIAL_MASK) > 0xFFFFFFu) return fail(c, HIPRZ_ERR_INVALID, "update_triangles: bad material id");
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    const int rc = device_update_triangles(c, first, n, tris, attrs);
+    if (rc != HIPRZ_OK) return rc;
+    return restart_after_geometry_change(c);
+}
+
+int hiprz_update_instances(hiprz_ctx* c, const hiprz_instance* instances, uint32_t n) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT(c, hiprz_update_instances(p, instances, n));
+    if (!c->have_scene || c->scene_tree != HIPRZ_TREE_DEVICE) return fail(c, HIPRZ_ERR_STATE, "update_instances: the scene was not uploaded under HIPRZ_TREE_DEVICE");
+    if (!instances || n != c->dscene.n_instances || n != c->device_instances.size()) return fail(c, HIPRZ_ERR_INVALID, "update_instances: the scene was uploaded with " + std::to_string(c->dscene.n_instances) + " instances");
+    bool fast_div = c->dscene.fast_div != 0u;
+    auto coord_ok = [](float x) {
+        uint32_t b;
+        std::memcpy(&b, &x, 4);
+        const uint32_t e = (b >> 23) & 0xFFu;
+        return (b & 0x7FFFFFFFu) == 0u || (e >= 127u - 60u && e < 127u + 40u);
+    };
+    for (uint32_t i = 0; i < n; ++i) {
+        hiprz_instance& d = c->device_instances[i];  // keeps blas_root (the device-built root), the material table and the padding flags
+        const hiprz_instance& in = instances[i];
+        std::memcpy(d.position, in.position, 12), std::memcpy(d.scale, in.scale, 12);
+        std::memcpy(d.x_axis, in.x_axis, 12), std::memcpy(d.y_axis, in.y_axis, 12), std::memcpy(d.z_axis, in.z_axis, 12);
+        d.pad0 = (in.scale[0] == 1.0f && in.scale[1] == 1.0f && in.scale[2] == 1.0f) ? 1u : 0u;
+        const float v[6] = {in.bb_min[0], in.bb_max[0], in.bb_min[1], in.bb_max[1], in.bb_min[2], in.bb_max[2]};  // interleaved like nodes
+        d.bb_min[0] = v[0], d.bb_min[1] = v[1], d.bb_min[2] = v[2];
+        std::memcpy(&d.pad2, &v[3], 4);
+        d.bb_max[0] = v[4], d.bb_max[1] = v[5], d.bb_max[2] = 0.0f;
+        for (float x : v) fast_div = fast_div && coord_ok(x);
+    }
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    RZ_HIP(c, hipMemcpy(c->hot.ptr + c->dscene.off_instances, c->device_instances.data(), sizeof(hiprz_instance) * n, hipMemcpyHostToDevice));
+    if (!fast_div && c->dscene.fast_div) c->dscene.fast_div = 0u, invalidate_graphs(c);
+    if (c->n_tlas_order) {
+        const int rc = device_build_world_tree(c, !std::getenv("HIPRZ_TRUST_DEVICE_TREES"));
+        if (rc != HIPRZ_OK) return rc;
+    }
+    return restart_after_geometry_change(c);
+}
+
+int hiprz_download_trees(hiprz_ctx* c, hiprz_node* nodes_out, uint32_t max_nodes, uint32_t* n_nodes_out, uint32_t* tlas_root_out, uint32_t* tlas_order_out,
+                         uint32_t* blas_roots_out, uint32_t* tri_refpos_out) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (!c->have_scene) return fail(c, HIPRZ_ERR_STATE, "download_trees before upload_scene");
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    const bool device_trees = c->scene_tree == HIPRZ_TREE_DEVICE;
+    const uint32_t n_nodes = device_trees ? c->node_capacity : uint32_t((c->dscene.off_tlas_order - c->dscene.off_nodes) / sizeof(hiprz_node));
+    if (n_nodes_out) *n_nodes_out = n_nodes;
+    if (tlas_root_out) *tlas_root_out = c->dscene.tlas_root;
+    if (nodes_out) {
+        if (max_nodes < n_nodes) return fail(c, HIPRZ_ERR_INVALID, "download_trees: " + std::to_string(n_nodes) + " nodes");
+        RZ_HIP(c, hipMemcpy(nodes_out, c->dscene.nodes, sizeof(hiprz_node) * n_nodes, hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < n_nodes; ++k) {  // the device keeps boxes interleaved: (min.x, max.x, min.y, max.y, min.z, max.z)
+            hiprz_node& nd = nodes_out[k];
+            const float v[6] = {nd.bb_min[0], nd.bb_min[1], nd.bb_min[2], nd.bb_max[0], nd.bb_max[1], nd.bb_max[2]};
+            nd.bb_min[0] = v[0], nd.bb_max[0] = v[1], nd.bb_min[1] = v[2], nd.bb_max[1] = v[3], nd.bb_min[2] = v[4], nd.bb_max[2] = v[5];
+        }
+    }
+    if (tlas_order_out && c->n_tlas_order) RZ_HIP(c, hipMemcpy(tlas_order_out, c->hot.ptr + c->dscene.off_tlas_order, 4u * c->n_tlas_order, hipMemcpyDeviceToHost));
+    if (blas_roots_out && c->dscene.n_instances) {
+        std::vector<hiprz_instance> inst(c->dscene.n_instances);
+        RZ_HIP(c, hipMemcpy(inst.data(), c->hot.ptr + c->dscene.off_instances, sizeof(hiprz_instance) * inst.size(), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < inst.size(); ++i) blas_roots_out[i] = inst[i].blas_root;
+    }
+    if (tri_refpos_out && c->n_tris) {
+        std::vector<hiprz_tri> tris(c->n_tris);
+        RZ_HIP(c, hipMemcpy(tris.data(), c->hot.ptr + c->dscene.off_tris, sizeof(hiprz_tri) * tris.size(), hipMemcpyDeviceToHost));
+        for (size_t t = 0; t < tris.size(); ++t) tri_refpos_out[t] = tris[t].pad0;
+    }
     return HIPRZ_OK;
 }
 
@@ -1442,7 +1629,7 @@ int hiprz_set_temporal_blend(hiprz_ctx* c, float blend) {
 int hiprz_set_tree(hiprz_ctx* c, uint32_t tree) {
     if (!c) return HIPRZ_ERR_INVALID;
     RZ_FANOUT(c, hiprz_set_tree(p, tree));
-    if (tree > HIPRZ_TREE_SAH) return fail(c, HIPRZ_ERR_INVALID, "set_tree: HIPRZ_TREE_REFERENCE or HIPRZ_TREE_SAH");
+    if (tree > HIPRZ_TREE_DEVICE) return fail(c, HIPRZ_ERR_INVALID, "set_tree: HIPRZ_TREE_REFERENCE, HIPRZ_TREE_SAH or HIPRZ_TREE_DEVICE");
     c->tree_mode = tree;
     return HIPRZ_OK;
 }

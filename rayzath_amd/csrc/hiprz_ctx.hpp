@@ -82,6 +82,17 @@ struct DeviceArray {
 
 }  // namespace hiprz
 
+namespace hiprz {
+// one mesh of a scene whose trees are built on the device (hiprz_build.hip)
+struct DeviceMesh {
+    uint32_t tri_first = 0, n_tris = 0;  // its triangles in the device order
+    uint32_t ref_first = 0;              // ... and in the uploaded snapshot's order (a mesh's triangles are contiguous in both)
+    uint32_t region = 0xFFFFFFFFu;       // slot of its root in the node arrays (RZ_END: too small to build, stays one leaf)
+    uint32_t n_slots = 0;                // nodes emitted
+    float bb_min[3] = {0, 0, 0}, bb_max[3] = {0, 0, 0};
+};
+}  // namespace hiprz
+
 // What belongs to ONE camera of the world: its record, the per-pixel path state and accumulators, the device-resident pass index, the
 // ray-order and shadow hand-over buffers sized for its resolution, the graph that was captured over these pointers.  The reference
 // renders every enabled camera per call (cpu_engine_renderer.cpp:97-117); a context keeps one of these per camera and the calls
@@ -178,7 +189,20 @@ struct hiprz_ctx : hiprz_frame_state {
     // 8 passes, and 0.34 vs 0.45 ms on an eighth of it — per-pass launch/ramp/tail costs vanish), else split (10-20 % faster
     // than fused on configs C, D; the resident kernel has no LDS room for the tree-top cache).
     int pipeline_setting = -1;
-    int pipeline = 1;  // resolved by resolve_pipeline() at upload / set time
+    int pipeline = 1;  // resolved by resolve_pipeline() at upload / set time and before a render call
+    uint32_t wave_resident_max = 4608u;  // HIPRZ_WAVE_RESIDENT_MAX: scenes without lights that are not staged in LDS run the resident pipeline
+                                         // (rz_wave_batch_kernel) while a shard has at most this many waves (about one round of the chip)
+    // device-built trees (hiprz_set_tree(HIPRZ_TREE_DEVICE), hiprz_build.hip): the 32-byte node records of the whole scene in a buffer of
+    // their own (the hot blob's node section only holds the uploaded prefix), the workspaces of build and refit, the meshes
+    hiprz::DeviceArray<uint8_t> dev_nodes, has_mesh, build_temp;
+    hiprz::DeviceArray<uint32_t> slot_parent, ref_to_dev, refit_visit, world_items;
+    hiprz::DeviceArray<hiprz_tri> update_tris;
+    hiprz::DeviceArray<hiprz_tri_attr> update_attrs;
+    hiprz_frame_state::SortTemp build_sort;
+    std::vector<hiprz::DeviceMesh> device_meshes;
+    std::vector<uint32_t> instance_mesh;          // instance -> index into device_meshes (RZ_END: no mesh)
+    std::vector<hiprz_instance> device_instances; // the instance records as the device holds them (hiprz_update_instances keeps what it does not replace)
+    uint32_t node_capacity = 0, n_tris = 0, n_tlas_order = 0, world_region = 0, world_slots = 0;
     hiprz::DeviceArray<unsigned long long> counters_dev;
     hiprz::DeviceArray<int32_t> pick_dev;
 
@@ -230,6 +254,7 @@ int effective_mode(const hiprz_ctx* c);
 bool defer_shadows(const hiprz_ctx* c);
 bool use_lds_scene(const hiprz_ctx* c);
 bool sort_enabled(const hiprz_ctx* c);
+bool wave_resident(const hiprz_ctx* c);  // resident pipeline on a scene that is not staged in LDS: rz_wave_batch_kernel
 int effective_sort_bits(const hiprz_ctx* c);
 DConfig make_config(const hiprz_ctx* c);
 // launch geometry of the 256-thread pass kernels: one workgroup per owned 32x8 tile
@@ -253,6 +278,13 @@ void launch_sort(hiprz_ctx* c, bool beside = false);  // keys of the next rays -
 void join_sort(hiprz_ctx* c);
 void launch_shadow_sort(hiprz_ctx* c);  // keys of the pass's shadow rays -> the order the shadow kernel follows
 void launch_sort_identity(hiprz_ctx* c);  // the identity order (no sort has run on this frame's rays yet)
+// device-side tree build and refit (hiprz_build.hip)
+uint32_t device_build_regions(std::vector<DeviceMesh>& meshes, uint32_t first_free_slot);
+int device_build_mesh_trees(hiprz_ctx* c, std::vector<DeviceMesh>& meshes, const std::vector<uint32_t>& instance_mesh, bool validate);
+int device_build_world_tree(hiprz_ctx* c, bool validate);
+int device_update_triangles(hiprz_ctx* c, uint32_t first, uint32_t n, const hiprz_tri* tris, const hiprz_tri_attr* attrs);
 int sort_workspace(hiprz_ctx* c, size_t n);  // (re)allocates the sort's buffers for n keys
+int sort_temp_resize(hiprz_ctx* c, hiprz_frame_state::SortTemp& t, size_t n);
+void sort_u32(hipStream_t stream, uint32_t* keys, uint32_t n, int key_bits, uint32_t* perm, uint32_t* sorted_keys, hiprz_frame_state::SortTemp& t);  // keys destroyed
 
 }  // namespace hiprz

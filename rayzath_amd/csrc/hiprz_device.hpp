@@ -32,6 +32,9 @@ namespace hiprz {
 #ifndef RZ_TRACE_MIN_WAVES
 #define RZ_TRACE_MIN_WAVES 5
 #endif
+#ifndef RZ_WALK_PREFETCH  // the cooperative mesh walk touches the lines of its possible next records before it tests the current box
+#define RZ_WALK_PREFETCH 1
+#endif
 #define RZ_PI_F 3.14159265358979323846f
 #define RZ_END 0xFFFFFFFFu
 // Termination of every walk is proven on the host before anything is launched (hiprz_api.hip: check_scene walks the
@@ -1175,6 +1178,7 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
     const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? (s.walk_l < 8u ? s.walk_l : 8u) : 8u, hmin = s.walk_h;
     uint32_t n = active ? s.tlas_root : RZ_END, guard = 0u;
     bool root_missed = false;
+    float probe_sink = 0.0f;  // RZ_WALK_PREFETCH: where the probe loads of the mesh walk end up
     while (__any(n != RZ_END)) {
         RZ_GUARD(guard);
         uint32_t i = 0u, end = 0u, link = RZ_END;
@@ -1231,25 +1235,25 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
                         fetch_node_ordered(s, m, oct, m0, m1, mlink);
                         RZ_PHASE(3);
                         RZ_COUNT(box_tests);
-                        bool bh = box_hit_unpacked<RCP>(m0, m1, lr);
-#ifdef RZ_EXP_DOUBLE_VALU  // sensitivity experiment: the node step's arithmetic twice, its fetches once
-                        {
-                            float4 m0b = m0;
-                            asm volatile("" : "+v"(m0b.x), "+v"(m0b.y), "+v"(m0b.z), "+v"(m0b.w));
-                            bh = bh & box_hit_unpacked<RCP>(m0b, m1, lr);
-                        }
+                        const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
+                        const bool mleaf = (mmeta & HIPRZ_NODE_LEAF) != 0u;
+                        const uint32_t near_child = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);  // the nearer child is entered first
+#if RZ_WALK_PREFETCH
+                        // The walk is a chain of dependent record fetches, each followed by ~45 instructions of box test (measured on the
+                        // 301 k-triangle mesh: one more dependent fetch per step +20 %, the test's arithmetic twice +19 %).  Whatever the test
+                        // says, the next record is the nearer child's, the skip link's, or this leaf's first triangle: touch those lines now,
+                        // so that they travel while the test runs.  The probes are ordinary loads whose values end in `probe_sink`.
+                        const float4* after = mlink != RZ_END ? s.nodes64 + 4 * size_t(mlink) : s.nodes64;
+                        const float4* inside = mleaf ? s.tris + 3 * size_t(mbegin) : s.nodes64 + 4 * size_t(near_child);
+                        const float probe_a = reinterpret_cast<const float*>(after)[0], probe_b = reinterpret_cast<const float*>(inside)[0];
 #endif
-                        if (bh) {
-                            const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
-                            if (!(mmeta & HIPRZ_NODE_LEAF)) mlink = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);  // enter the nearer child first
+                        if (box_hit_unpacked<RCP>(m0, m1, lr)) {
+                            if (!mleaf) mlink = near_child;
                             else tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
                         }
                         m = mlink;
-#ifdef RZ_EXP_EXTRA_FETCH  // sensitivity experiment: one more DEPENDENT fetch per node step (the next node's record, waited for), same arithmetic
-                        if (m != RZ_END) {
-                            float probe = reinterpret_cast<const volatile float*>(s.nodes64 + 4 * size_t(m))[7];
-                            asm volatile("" : "+v"(m) : "v"(probe));
-                        }
+#if RZ_WALK_PREFETCH
+                        probe_sink += probe_a + probe_b;
 #endif
                     }
                 }
@@ -1268,6 +1272,10 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
         if (n != RZ_END && !descended) n = link;
     }
     ray.near_ = g.near_, ray.far_ = g.far_;
+#if RZ_WALK_PREFETCH
+    // a value no box coordinate or vertex sum takes keeps the probes' results "used" without ever changing anything
+    if (__float_as_uint(probe_sink) == 0x7FC12345u) ray.far_ = probe_sink;
+#endif
     if (!active || root_missed) return 0;
     return hit.instance >= 0 ? 2 : 1;
 }
@@ -1362,6 +1370,7 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
     const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? (s.walk_l < 8u ? s.walk_l : 8u) : 8u, hmin = s.walk_h;
     uint32_t n = active ? s.tlas_root : RZ_END, guard = 0u;
     bool occluded = false;
+    float probe_sink = 0.0f;
     while (__any(n != RZ_END)) {
         RZ_GUARD(guard);
         uint32_t i = 0u, end = 0u, link = RZ_END;
@@ -1412,12 +1421,22 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
                         fetch_node_ordered(s, m, oct, m0, m1, mlink);
                         RZ_COUNT(box_tests);
                         RZ_COUNT(shadow_box_tests);
+                        const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
+                        const bool mleaf = (mmeta & HIPRZ_NODE_LEAF) != 0u;
+                        const uint32_t near_child = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);
+#if RZ_WALK_PREFETCH  // as in closest_hit_coop: the lines of the possible next records travel while the box is tested
+                        const float4* after = mlink != RZ_END ? s.nodes64 + 4 * size_t(mlink) : s.nodes64;
+                        const float4* inside = mleaf ? s.tris + 3 * size_t(mbegin) : s.nodes64 + 4 * size_t(near_child);
+                        const float probe_a = reinterpret_cast<const float*>(after)[0], probe_b = reinterpret_cast<const float*>(inside)[0];
+#endif
                         if (box_hit_unpacked<RCP>(m0, m1, lr)) {
-                            const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
-                            if (!(mmeta & HIPRZ_NODE_LEAF)) mlink = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);
+                            if (!mleaf) mlink = near_child;
                             else tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
                         }
                         m = mlink;
+#if RZ_WALK_PREFETCH
+                        probe_sink += probe_a + probe_b;
+#endif
                     }
                 }
                 if (!__any(tj != tj_end)) continue;
@@ -1468,6 +1487,9 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
         }
         if (n != RZ_END && !descended) n = link;
     }
+#if RZ_WALK_PREFETCH
+    if (__float_as_uint(probe_sink) == 0x7FC12345u) return probe_sink;  // never: keeps the probes' results "used"
+#endif
     return occluded ? 0.0f : 1.0f;
 }
 

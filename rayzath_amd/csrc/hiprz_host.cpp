@@ -515,7 +515,7 @@ struct SahBuilder {
 
 extern "C" int hiprz_rebuild_mesh_trees(const hiprz_scene* sc, uint32_t method, hiprz_node* nodes_out, uint32_t max_nodes, uint32_t* n_nodes_out,
                                         uint32_t* tri_order_out, uint32_t* blas_roots_out, uint32_t* tlas_root_out) {
-    if (!sc || !nodes_out || !n_nodes_out || !tri_order_out || !blas_roots_out || !tlas_root_out || method != 1u) return HIPRZ_ERR_INVALID;
+    if (!sc || !nodes_out || !n_nodes_out || !tri_order_out || !blas_roots_out || !tlas_root_out || (method != 1u && method != 2u)) return HIPRZ_ERR_INVALID;
     std::vector<hiprz_node> nodes;
     // the world tree is copied as it is (breadth-first, children adjacent)
     *tlas_root_out = 0u;
@@ -568,9 +568,17 @@ extern "C" int hiprz_rebuild_mesh_trees(const hiprz_scene* sc, uint32_t method, 
                     if (tri_seen[t]) return HIPRZ_ERR_INVALID;  // the leaves of a mesh must tile one contiguous range
                     tri_seen[t] = 1;
                 }
-                hiprz_trees::SahBuilder builder(sc->tris + lo, total, nodes, tri_cursor);
-                new_root[root] = builder.build();
-                for (uint32_t k = 0; k < total; ++k) tri_order_out[tri_cursor + k] = lo + builder.idx[k];
+                if (method == 2u) {  // HIPRZ_TREE_DEVICE: one leaf over the whole mesh — what the device build starts from
+                    new_root[root] = uint32_t(nodes.size());
+                    hiprz_node leaf = sc->nodes[root];
+                    leaf.begin = tri_cursor, leaf.meta = HIPRZ_NODE_LEAF | total;
+                    nodes.push_back(leaf);
+                    for (uint32_t k = 0; k < total; ++k) tri_order_out[tri_cursor + k] = lo + k;
+                } else {
+                    hiprz_trees::SahBuilder builder(sc->tris + lo, total, nodes, tri_cursor);
+                    new_root[root] = builder.build();
+                    for (uint32_t k = 0; k < total; ++k) tri_order_out[tri_cursor + k] = lo + builder.idx[k];
+                }
                 tri_cursor += total;
             }
         }

@@ -352,6 +352,50 @@ __global__ void __launch_bounds__(256, WAVES) rz_batch_kernel(const DScene scene
     flush_counters<COUNT>(f, p.active ? n_passes : 0u, cnt);
 }
 
+// ---- resident pipeline for scenes that are not staged in LDS (no lights): one WAVE takes its 64 pixels through all the passes ----
+// The split pipeline puts a barrier over the whole shard behind every kernel of every pass, and a launch lasts as long as its slowest
+// wave: the one whose rays graze the big mesh.  While the grid oversubscribes the chip that tail hides behind other workgroups; an
+// eighth of a frame on each of 8 GPUs is ONE round of waves, and every pass then costs its slowest wave (config D, shard of 8: 250-490 us
+// per pass against 130 us of work).  Here the passes of a wave follow each other without any barrier — a slow pass of one wave runs
+// beside the fast passes of the others, and the launch lasts as long as the slowest SUM of passes.  Per pixel the arithmetic is that of
+// the split kernels (cooperative front-to-back walk, then shade_segment), the accumulator grows by the same additions in the same order.
+template <bool COUNT, int SHADING, int MINW>
+__global__ void __launch_bounds__(64, MINW) rz_wave_batch_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f, uint32_t n_passes) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
+    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+    const PixelId p = pixel_of_local(f, cam, slot);
+    Counters cnt;
+    PathState ps;
+    load_path<false>(f, cam, p, ps);
+    float4 acc = p.active ? f.accum[p.local] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const uint32_t pass0 = *f.pass;
+    for (uint32_t i = 0; i < n_passes; ++i) {
+        if (i != 0u && p.active) {  // what load_path does with the state the previous pass stored
+            ps.ray.d = normalized(ps.ray.d);
+            ps.ray.near_ = 0.0f, ps.ray.far_ = RZ_FLT_MAX;
+            if (ps.depth == 0u) ps.ray.near_ = cam.near_, ps.ray.far_ = cam.far_;
+        }
+        Hit hit;
+        hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
+        int found = 0;
+        if (s.n_instances != 0u) found = closest_hit_coop<COUNT, RZ_TRACE_SHARED_RCP != 0>(s, CoopLds(rz_lds), p.active, ps.ray, hit, cnt);
+        if (p.active) {
+            col4 final_color;
+            bool path_continues;
+            shade_segment<COUNT, SHADING>(s, cam, cfg, p, ps, pass0 + i, found, hit, ShadowCtx{nullptr, TopCache{nullptr, nullptr, 0u}}, cnt, final_color, path_continues);
+            acc = make_float4(acc.x + final_color.r, acc.y + final_color.g, acc.z + final_color.b, acc.w + float(!path_continues));
+        }
+    }
+    if (p.active) {
+        f.accum[p.local] = acc;
+        f.st0[p.local] = make_float4(ps.ray.o.x, ps.ray.o.y, ps.ray.o.z, ps.ray.d.x);
+        f.st1[p.local] = make_float4(ps.ray.d.y, ps.ray.d.z, ps.color.r, ps.color.g);
+        f.st2[p.local] = make_float2(ps.color.b, __uint_as_float((ps.material & 0xFFFFu) | (ps.depth << 16)));
+        f.rgba8[p.local] = tonemap(col4{acc.x, acc.y, acc.z, acc.w}, cam.aperture, cam.exposure_time);
+    }
+    flush_counters<COUNT>(f, p.active ? n_passes : 0u, cnt);
+}
+
 // ---- split pipeline ----
 // hit record: hit0 = (far, b1, b2, bits(triangle)), hit1 = instance | found << 29 | external << 31
 template <bool FIRST, bool COUNT, int MODE, bool LDS_SCENE>

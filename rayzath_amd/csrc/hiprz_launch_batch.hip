@@ -28,8 +28,18 @@ void launch_fused_t(hiprz_ctx* c, const DFrame& f) {
 
 template <bool COUNT>
 void launch_batch_t(hiprz_ctx* c, const DFrame& f, uint32_t n) {
-    const PassGeometry g = pass_geometry(c);
+    PassGeometry g = pass_geometry(c);
     const DConfig cfg = make_config(c);
+    // counted renders report the work of the reference's visiting order unless asked otherwise (hiprz_set_walk_order): those keep the
+    // workgroup kernel with its stack walk in that order
+    const bool reference_counters = COUNT && c->walk_order != 2 && c->scene_tree == HIPRZ_TREE_REFERENCE;
+    if (wave_resident(c) && reference_counters) g.mode = 1, g.walk_lds = g.stack_lds;
+    if (wave_resident(c) && !reference_counters) {  // scenes that are not staged in LDS, without lights: single-wave workgroups walk cooperatively, pass after pass
+        const dim3 wgrid(c->n_local_tiles * 4u), wblock(64);
+        if (c->n_textures == 0u) hipLaunchKernelGGL((rz_wave_batch_kernel<COUNT, RZ_SHADOW_PLAIN, 4>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
+        else hipLaunchKernelGGL((rz_wave_batch_kernel<COUNT, RZ_SHADOW_NONE, 4>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
+        return;
+    }
     const dim3 grid = g.grid, block = g.block;
     const size_t park = 8u * 1024u;
     const size_t lds = g.blob + g.walk_lds + park;

@@ -130,17 +130,18 @@ __global__ void __launch_bounds__(256) rz_sort_identity_kernel(uint32_t n, uint3
     if (i < n) perm[i] = i;
 }
 
-// keys (destroyed) -> perm
-void radix_sort(hiprz_ctx* c, uint32_t* keys, uint32_t* perm, hiprz_frame_state::SortTemp& t, hipStream_t stream) {
-    const uint32_t n = c->n_local_tiles * 256u, n_tiles = (n + kTile - 1u) / kTile;
-    const int passes = (effective_sort_bits(c) + 7) / 8;
+// keys (destroyed) -> perm: least significant digit first, `passes` digits of 8 bits from bit `first_shift` up; `sorted_keys` (may be
+// null) receives the keys in sorted order
+void radix_sort_n(hipStream_t stream, uint32_t* keys, uint32_t n, uint32_t first_shift, int passes, uint32_t* perm, uint32_t* sorted_keys,
+                  hiprz_frame_state::SortTemp& t) {
+    const uint32_t n_tiles = (n + kTile - 1u) / kTile;
     uint32_t* key_buf[2] = {keys, t.keys_out.ptr};
     uint32_t* val_buf[2] = {t.vals_a.ptr, t.vals_b.ptr};
     for (int p = 0; p < passes; ++p) {
-        const uint32_t shift = uint32_t(24 - 8 * (passes - p));
+        const uint32_t shift = first_shift + 8u * uint32_t(p);
         const bool last = p + 1 == passes;
         const uint32_t* kin = key_buf[p & 1];
-        uint32_t* kout = last ? nullptr : key_buf[(p + 1) & 1];
+        uint32_t* kout = last ? sorted_keys : key_buf[(p + 1) & 1];
         const uint32_t* vin = val_buf[p & 1];
         uint32_t* vout = last ? perm : val_buf[(p + 1) & 1];
         hipLaunchKernelGGL(rz_radix_count_kernel, dim3(n_tiles), dim3(256), 0, stream, kin, n, shift, t.counts.ptr, n_tiles, t.digit_total.ptr);
@@ -149,21 +150,34 @@ void radix_sort(hiprz_ctx* c, uint32_t* keys, uint32_t* perm, hiprz_frame_state:
         else hipLaunchKernelGGL((rz_radix_scatter_kernel<false>), dim3(n_tiles), dim3(256), 0, stream, kin, vin, kout, vout, n, shift, t.counts.ptr, n_tiles, t.digit_total.ptr);
     }
 }
+void radix_sort(hiprz_ctx* c, uint32_t* keys, uint32_t* perm, hiprz_frame_state::SortTemp& t, hipStream_t stream) {
+    const int passes = (effective_sort_bits(c) + 7) / 8;
+    radix_sort_n(stream, keys, c->n_local_tiles * 256u, uint32_t(24 - 8 * passes), passes, perm, nullptr, t);
+}
 
 }  // namespace
 
-int sort_workspace(hiprz_ctx* c, size_t n) {
+int sort_temp_resize(hiprz_ctx* c, hiprz_frame_state::SortTemp& t, size_t n) {
     const size_t n_tiles = (n + kTile - 1u) / kTile, n_counts = 256u * n_tiles;
+    RZ_HIP(c, t.keys_out.resize(n));
+    RZ_HIP(c, t.vals_a.resize(n));  // value buffers of the middle passes
+    RZ_HIP(c, t.vals_b.resize(n));
+    RZ_HIP(c, t.counts.resize(n_counts));
+    RZ_HIP(c, t.digit_total.resize(256u * kTotalCopies));  // keys per digit of the pass being sorted (zeroed again by its scatter kernel)
+    RZ_HIP(c, hipMemsetAsync(t.digit_total.ptr, 0, 256u * kTotalCopies * sizeof(uint32_t), c->stream));
+    return HIPRZ_OK;
+}
+int sort_workspace(hiprz_ctx* c, size_t n) {
     for (auto& t : c->sort_temp) {
-        RZ_HIP(c, t.keys_out.resize(n));
-        RZ_HIP(c, t.vals_a.resize(n));  // value buffers of the middle passes
-        RZ_HIP(c, t.vals_b.resize(n));
-        RZ_HIP(c, t.counts.resize(n_counts));
-        RZ_HIP(c, t.digit_total.resize(256u * kTotalCopies));  // keys per digit of the pass being sorted (zeroed again by its scatter kernel)
-        RZ_HIP(c, hipMemsetAsync(t.digit_total.ptr, 0, 256u * kTotalCopies * sizeof(uint32_t), c->stream));
+        const int rc = sort_temp_resize(c, t, n);
+        if (rc != HIPRZ_OK) return rc;
     }
     c->perm_valid = false;
     return HIPRZ_OK;
+}
+// any n keys of up to 32 bits on a stream of the caller's (the device-side tree build sorts Morton codes with it)
+void sort_u32(hipStream_t stream, uint32_t* keys, uint32_t n, int key_bits, uint32_t* perm, uint32_t* sorted_keys, hiprz_frame_state::SortTemp& t) {
+    radix_sort_n(stream, keys, n, 0u, (key_bits + 7) / 8, perm, sorted_keys, t);
 }
 
 // The keys the shade kernel just wrote -> the order of the next pass's rays.  `beside`: on the auxiliary stream, after everything the

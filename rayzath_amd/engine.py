@@ -140,8 +140,31 @@ class Context:
         self._check(self.lib.hiprz_set_temporal_blend(self._ctx, blend))
 
     def set_tree(self, tree):
-        """0 = the uploaded (reference) mesh trees, 1 = rebuilt with a binned SAH at the next upload_scene (same frames, fewer tests)."""
+        """0 = the uploaded (reference) mesh trees, 1 = rebuilt with a binned SAH at the next upload_scene (same frames, fewer tests),
+        2 = all trees built on the device at upload (same frames; update_triangles / update_instances afterwards)."""
         self._check(self.lib.hiprz_set_tree(self._ctx, tree))
+
+    def update_triangles(self, first, tris, attrs):
+        """New records (numpy arrays of _abi.tri_dtype / tri_attr_dtype) for triangles [first, first + len) of the uploaded order; the device
+        refits the mesh trees that hold them.  Scenes uploaded under set_tree(2) only."""
+        tris, attrs = np.ascontiguousarray(tris), np.ascontiguousarray(attrs)
+        assert len(tris) == len(attrs)
+        self._check(self.lib.hiprz_update_triangles(self._ctx, first, len(tris), tris.ctypes.data, attrs.ctypes.data))
+
+    def update_instances(self, instances):
+        """New transformations and world boxes of ALL instances (array of _abi.instance_dtype); the device rebuilds the world tree."""
+        instances = np.ascontiguousarray(instances)
+        self._check(self.lib.hiprz_update_instances(self._ctx, instances.ctypes.data, len(instances)))
+
+    def download_trees(self, n_instances, n_tris, n_tlas_order):
+        """(nodes, tlas_root, tlas_order, blas_roots, tri_refpos) of the trees the context walks now."""
+        n = C.c_uint32()
+        self._check(self.lib.hiprz_download_trees(self._ctx, None, 0, C.byref(n), None, None, None, None))
+        nodes = np.zeros(n.value, dtype=_abi.node_dtype)
+        root = C.c_uint32()
+        order, roots, refpos = np.zeros(max(n_tlas_order, 1), np.uint32), np.zeros(max(n_instances, 1), np.uint32), np.zeros(max(n_tris, 1), np.uint32)
+        self._check(self.lib.hiprz_download_trees(self._ctx, nodes.ctypes.data, len(nodes), C.byref(n), C.byref(root), order.ctypes.data, roots.ctypes.data, refpos.ctypes.data))
+        return nodes, root.value, order[:n_tlas_order], roots[:n_instances], refpos[:n_tris]
 
     def set_pipeline(self, pipeline):
         self._check(self.lib.hiprz_set_pipeline(self._ctx, pipeline))

@@ -1,0 +1,174 @@
+"""Trees built, refitted and rebuilt ON THE DEVICE (hiprz_set_tree(HIPRZ_TREE_DEVICE), rayzath_amd/csrc/hiprz_build.hip; SURVEY.md §8 f4 —
+the reference rebuilds on the host at every change: bvh_tree_node.hpp:117-215, component_container.hpp:259-363):
+
+  * frames with device-built trees == frames with the reference trees == frames with the host SAH trees, bit for bit, on a deep textured
+    mesh, an instanced scene with lights, and a scene made of exact ties;
+  * the downloaded device output passes the host's scene validation (every index in range, trees disjoint, every walk terminates);
+  * the device-built WORLD tree is the host builder's, node for node (the order of the instances is part of a ray's arithmetic);
+  * hiprz_update_triangles (refit) and hiprz_update_instances (world-tree rebuild) == a fresh upload of the changed scene.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rayzath_amd import _abi, _lib, scenes
+from rayzath_amd.engine import Context, LightSampling, RenderConfig, Tracing
+from rayzath_amd.scene import FlatScene, Instance, Material, camera_struct, flatten
+from test_trees_gpu import _ties_world
+
+pytestmark = pytest.mark.gpu
+DEVICE = 2
+
+
+def _render(flat, cam, cfg, tree, passes=(1, 5, 4)):
+    c = Context(0)
+    c.set_tree(tree)
+    c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+    for n in passes:
+        c.render(n)
+    return c
+
+
+def _same_frames(a, b):
+    assert np.array_equal(a.read_accum(), b.read_accum()) and np.array_equal(a.read_depth(), b.read_depth())
+    sa, sb = a.read_state(), b.read_state()
+    for k in sa:
+        assert np.array_equal(sa[k], sb[k]), k
+
+
+def _worlds(name):
+    return {
+        "textured": (lambda: scenes.textured_sphere_scene(200, 120, resolution=160, map_size=64), (1, 1)),
+        "living room": (lambda: scenes.living_room(128, 80, 16), (2, 2)),
+        "shading inputs": (lambda: scenes.shading_inputs_scene(160, 96), (2, 1)),
+        "exact ties": (_ties_world, (1, 1)),
+    }[name]
+
+
+@pytest.mark.parametrize("name", ["textured", "living room", "shading inputs", "exact ties"])
+def test_device_built_trees_give_the_same_frames_and_pass_validation(built, name):
+    build, samples = _worlds(name)
+    world = build()
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(LightSampling(*samples), Tracing(6, 4)).struct()
+    ref, sah, dev = (_render(flat, cam, cfg, t) for t in (0, 1, DEVICE))
+    _same_frames(ref, dev)
+    _same_frames(sah, dev)
+    for xy in [(10, 10), (100, 60), (60, 70)]:
+        assert ref.pick(*xy) == dev.pick(*xy)
+    print(dev.timings())
+    # the device's output as a snapshot: the host's validation (hiprz_validate_scene = check_scene + the walk-table proofs) accepts it
+    nodes, root, order, roots, refpos = dev.download_trees(len(flat.instances), len(flat.tris), len(flat.tlas_order))
+    assert sorted(refpos.tolist()) == list(range(len(flat.tris)))           # a permutation of the uploaded triangles
+    inst = flat.instances.copy()
+    inst["blas_root"] = roots
+    snap = FlatScene(nodes=nodes, tlas_root=root, tlas_order=order, tris=flat.tris[refpos], tri_attrs=flat.tri_attrs[refpos], instances=inst,
+                     inst_materials=flat.inst_materials, materials=flat.materials, textures=flat.textures, texels=flat.texels,
+                     spot_lights=flat.spot_lights, direct_lights=flat.direct_lights)
+    msg = C.create_string_buffer(256)
+    rc = _lib.load().hiprz_validate_scene(C.byref(snap.struct), msg, 256)
+    if rc != _abi.OK:  # keep the refused snapshot for a look on the host
+        import os
+        os.makedirs("gpurun_out/r03", exist_ok=True)
+        np.savez_compressed("gpurun_out/r03/refused_snapshot_%s.npz" % name.replace(" ", "_"), **snap.to_npz_dict())
+    assert rc == _abi.OK, msg.value
+    # ... and rendered from that snapshot with the plain (reference-order, stack / skip-link) walks it is the same frame again
+    again = _render(snap, cam, cfg, 0)
+    assert np.array_equal(again.read_depth(), dev.read_depth())
+    if name != "exact ties":   # (a re-uploaded snapshot ranks equally distant triangles by ITS order: another twin may win a tie)
+        assert (again.read_accum()[..., 3] == dev.read_accum()[..., 3]).all()
+
+
+def _world_tree_of(nodes, root, order):
+    """The world tree as a nested tuple: (box, ptype, children) / (box, instances of the leaf)."""
+    out = []
+    def walk(i):
+        n = nodes[i]
+        box = (tuple(n["bb_min"].tolist()), tuple(n["bb_max"].tolist()))
+        if n["meta"] & _abi.NODE_LEAF:
+            count = int(n["meta"] & 0x1FFFFFFF)
+            return (box, tuple(order[int(n["begin"]):int(n["begin"]) + count].tolist()))
+        return (box, int(n["meta"] >> 29) & 3, walk(int(n["begin"])), walk(int(n["begin"]) + 1))
+    return walk(root)
+
+
+@pytest.mark.parametrize("n_instances", [5, 46, 400])
+def test_device_built_world_tree_is_the_host_builders(built, n_instances):
+    """The reference's top-down builder run by one device thread: the same nodes, partition types and leaf order as
+    hiprz_build_world_tree on the host (the snapshot's own world tree), bit for bit."""
+    rng = np.random.default_rng(n_instances)
+    world = scenes.living_room(96, 64, min(n_instances, 40))
+    cube = world.instances[-1].mesh
+    paint = world.materials[0]
+    for _ in range(max(0, n_instances - len(world.instances))):
+        world.add(Instance(cube, [paint], position=tuple(rng.uniform(-1.8, 1.8, 3) + np.array([0, 1, 0])), rotation=tuple(rng.uniform(0, 1, 3)),
+                           scale=tuple(rng.uniform(0.02, 0.3, 3))))
+    flat, cam = flatten(world), camera_struct(world.camera)
+    dev = Context(0)
+    dev.set_tree(DEVICE)
+    dev.upload_scene(flat), dev.upload_camera(cam)
+    nodes, root, order, _, _ = dev.download_trees(len(flat.instances), len(flat.tris), len(flat.tlas_order))
+    assert _world_tree_of(nodes, root, order) == _world_tree_of(flat.nodes, flat.tlas_root, flat.tlas_order)
+    assert np.array_equal(order, flat.tlas_order)
+
+
+def test_refit_and_world_rebuild_equal_a_fresh_upload(built):
+    """A mesh is deformed and an instance moved: hiprz_update_triangles + hiprz_update_instances on the device against a fresh upload of the
+    changed world (host trees)."""
+    def build(deformed):
+        world = scenes.textured_sphere_scene(200, 120, resolution=96, map_size=64)
+        if deformed:
+            inst = next(i for i in world.instances if i.name == "bugatti stand-in")
+            v = inst.mesh.vertices
+            inst.mesh.vertices = np.ascontiguousarray(v * np.array([1.0, 1.25, 0.9], dtype=np.float32) + np.sin(v[:, [1, 2, 0]] * 7.0).astype(np.float32) * np.float32(0.03), dtype=np.float32)
+            inst.position = (inst.position + np.array([0.25, -0.1, 0.2], dtype=np.float32)).astype(np.float32)
+            inst.rotation = (inst.rotation + np.array([0.1, 0.4, 0.0], dtype=np.float32)).astype(np.float32)
+        return world
+    before, after = build(False), build(True)
+    flat0, flat1, cam = flatten(before), flatten(after), camera_struct(before.camera)
+    cfg = RenderConfig(tracing=Tracing(6, 4)).struct()
+    dev = _render(flat0, cam, cfg, DEVICE)
+    # the changed triangles in the order they were uploaded in: a mesh's triangles are identified by their index before leaf reordering
+    sphere = next(k for k, i in enumerate(before.instances) if i.name == "bugatti stand-in")
+    def mesh_range(flat):
+        roots = flat.instances["blas_root"]
+        # triangles of the sphere's mesh: the leaves of its tree tile one range
+        stack, lo, hi = [int(roots[sphere])], 1 << 62, 0
+        while stack:
+            n = flat.nodes[stack.pop()]
+            if n["meta"] & _abi.NODE_LEAF:
+                c = int(n["meta"] & 0x1FFFFFFF)
+                if c:
+                    lo, hi = min(lo, int(n["begin"])), max(hi, int(n["begin"]) + c)
+            else:
+                stack += [int(n["begin"]), int(n["begin"]) + 1]
+        return lo, hi
+    (lo0, hi0), (lo1, hi1) = mesh_range(flat0), mesh_range(flat1)
+    assert hi0 - lo0 == hi1 - lo1 > 1000
+    src0, src1 = flat0.tris["source_index"][lo0:hi0], flat1.tris["source_index"][lo1:hi1]
+    pos1 = np.empty(hi1 - lo1, dtype=np.int64)
+    pos1[src1] = np.arange(hi1 - lo1)
+    pick = lo1 + pos1[src0]                                       # flat1's record of the triangle flat0 holds at lo0 + k
+    dev.update_triangles(lo0, flat1.tris[pick], flat1.tri_attrs[pick])
+    dev.update_instances(flat1.instances)
+    print(dev.timings())
+    for n in (1, 5, 4):
+        dev.render(n)
+    fresh = _render(flat1, cam, cfg, 0)
+    _same_frames(fresh, dev)
+    assert not np.array_equal(fresh.read_depth(), _render(flat0, cam, cfg, 0).read_depth())   # the change is visible
+
+
+def test_config_d_built_on_the_device(built):
+    """BASELINE config D (301 400 triangles): tree built on the device, the frame of the reference trees; build and refit times printed."""
+    preset = scenes.CONFIGS["D"]
+    world = preset["build"]()
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(tracing=Tracing(preset["max_depth"], 4)).struct()
+    ref, dev = _render(flat, cam, cfg, 0, passes=(1, 2)), _render(flat, cam, cfg, DEVICE, passes=(1, 2))
+    _same_frames(ref, dev)
+    dev.update_triangles(0, flat.tris, flat.tri_attrs)            # a refit of every triangle (to the same place): the frame does not change
+    dev.render(1), dev.render(2)
+    _same_frames(ref, dev)
+    print(dev.timings())

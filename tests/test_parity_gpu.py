@@ -200,6 +200,31 @@ def test_resident_pipeline_equals_split(built, mode):
                 assert np.array_equal(out[0][2][k], out[1][2][k]), k
 
 
+def test_wave_resident_pipeline_equals_split(built):
+    """Scenes that are not staged in LDS, without lights: ONE launch per batch in which every wave takes its 64 pixels through all the
+    passes with the cooperative front-to-back walk (rz_wave_batch_kernel; what a shard of an 8-GPU job runs) == trace + shade kernels per
+    pass, bit for bit — accumulator, RGBA8, path state, executed-work counters; also sharded, also chosen automatically for a small shard."""
+    for world, depth in ((scenes.cornell_sphere(128, 72, 32), 6), (scenes.textured_sphere_scene(120, 80, resolution=48, map_size=32), 5)):
+        flat, cam = flatten(world), camera_struct(world.camera)
+        cfg = RenderConfig(LightSampling(1, 1), Tracing(depth, 4)).struct()
+        for shard in ((0, 1), (1, 3)):
+            out = []
+            for pipeline in (1, 2, -1):
+                c = Context(0)
+                c.set_traversal_mode(3), c.set_lds_scene(0), c.set_pipeline(pipeline), c.set_shard(*shard), c.set_walk_order(2)
+                c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+                counters = [c.render_counted(3), c.render_counted(2)]
+                c.render(5), c.render(1), c.render(4)
+                c.tonemap()
+                out.append((c.read_accum(), c.read_rgba8(), c.read_state(), counters, c.pipeline()))
+            assert [o[4] for o in out] == [1, 2, 2]                    # a shard this small runs resident by default
+            for other in out[1:]:
+                assert out[0][3] == other[3]
+                assert np.array_equal(out[0][0], other[0]) and np.array_equal(out[0][1], other[1])
+                for k in out[0][2]:
+                    assert np.array_equal(out[0][2][k], other[2][k]), k
+
+
 def test_ray_reordering_changes_nothing_but_the_order(built):
     """Sorted walk order (keys from the shade kernel, radix sort, permutation) == pixel order, bit for bit."""
     for world, depth, mode in ((scenes.cornell_sphere(160, 90, 40), 6, 3), (scenes.living_room(96, 64, 16), 5, 3), (scenes.cornell_box(100, 60), 4, 1)):
