@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--ray-sort", type=int, default=-1, help="-1 auto, 0 off, 1 on")
     ap.add_argument("--walk-order", type=int, default=-1, help="mesh child order of the skip-link walk: 0 reference order, 1 front to back (-1: library default)")
     ap.add_argument("--streams", type=int, default=-1, help="N = 1, after the main measurement: the same steps with the frame split over this many contexts-with-a-stream on the GPU (what the Engine hosts do by default for scenes without lights), reported as `several_streams`; -1 = the hosts' choice (rayzath_amd.engine.default_streams), 1 = skip")
+    ap.add_argument("--mode", type=int, default=0, help="hiprz_set_mode flags: 0 = the CPU kernel (the parity-checked default), 63 = every behaviour of the reference's CUDA engine")
     ap.add_argument("--tree", type=int, default=0, help="0 the scene's (reference) mesh trees, 1 rebuilt with a binned SAH (hiprz_set_tree; same frames, fewer tests; not the default)")
     ap.add_argument("--no-xcd-swizzle", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -138,6 +139,8 @@ def main():
     if args.no_xcd_swizzle:
         ctx.set_xcd_swizzle(False)
     ctx.set_tree(args.tree)
+    if args.mode:
+        ctx.set_mode(args.mode)
     ctx.set_shard(rank, world)
     ctx.upload_scene(flat)
     ctx.upload_camera(cam)
@@ -244,6 +247,8 @@ def main():
         if args.no_xcd_swizzle:
             fast.set_xcd_swizzle(False)
         fast.set_tree(args.tree)
+        if args.mode:
+            fast.set_mode(args.mode)
         fast.upload_scene(flat), fast.upload_camera(cam), fast.set_config(cfg)
         fast.render(1)
         for _ in range(args.warmup):
@@ -275,7 +280,7 @@ def main():
         pipeline = ctx.pipeline()
         split = pipeline == 1
         walk_order = args.walk_order if args.walk_order >= 0 else 1
-        front_to_back = split and ctx.traversal_mode() == 3 and walk_order != 0
+        front_to_back = split and ctx.traversal_mode() == 3 and (walk_order != 0 or bool(args.mode & 31))
         trace_bytes = lambda c: (60 * c["segments"] + 32 * (c["box_tests"] - c["shadow_box_tests"]) + 36 * (c["tri_tests"] - c["shadow_tri_tests"])) / RPP
         traversal_kernel = reference_algorithm = eager_kernel_us = None
         if pipeline == 2 and breakdown[2]:
@@ -306,11 +311,11 @@ def main():
             # dominant kernel = the BVH-traversal kernel.  Its algorithmic bytes: the ray it reads (40 B of path state) and
             # the hit record it writes (20 B) per segment + 32 B per box test + 36 B per triangle test of the closest-hit
             # walk (shadow-ray tests run in their own kernel and are not counted here).
-            mode3 = "rz_trace_coop_kernel" if front_to_back else "rz_trace_skip_kernel"
+            mode3 = ("rz_trace_coop_compat_kernel" if args.mode & 31 else "rz_trace_coop_kernel") if front_to_back else "rz_trace_skip_kernel"
             kernel_name = {3: mode3}.get(ctx.traversal_mode(), "rz_trace_kernel") + " (closest-hit walk)"
             kernel_s = breakdown[0] / 1e3 / breakdown[2]
             kernel_bytes = trace_bytes(counters)
-            if front_to_back:
+            if front_to_back and not (args.mode & 31):
                 # `counters` walked in the reference's child order (they equal the CPU kernel's).  The timed kernel walks front to
                 # back and reaches the same hits with fewer tests: the roofline is priced on the tests it EXECUTED; the reference
                 # algorithm's figure is kept beside it as context.
@@ -348,6 +353,7 @@ def main():
                        "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
                        "traversal": {1: "lds-stack", 2: "workgroup-binned", 3: "skip-links"}[ctx.traversal_mode()],
                        "mesh_trees": "binned SAH, rebuilt at upload" if args.tree else "reference builder (scene snapshot)",
+                       "integrator": "CPU kernel (parity-checked)" if not (args.mode & 31) else f"CUDA-compat flags {args.mode} (hiprz_set_mode)",
                        "pipeline": {0: "fused (one kernel per pass)", 1: "trace+shade (two kernels per pass)", 2: "resident (one kernel per step)"}[pipeline]},
             "timing": {"protocol": f"{len(samples)} repeats of exactly {args.steps} steps ({args.steps * RPP} passes) between barrier + synchronize fences (repeated until >= {args.min_seconds:g} s of timed wall); value = median repeat",
                        "repeat_seconds_min_median_max": [min(samples), elapsed, max(samples)], "repeats": len(samples), "timed_seconds": sum(samples),

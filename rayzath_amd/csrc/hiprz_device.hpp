@@ -32,9 +32,6 @@ namespace hiprz {
 #ifndef RZ_TRACE_MIN_WAVES
 #define RZ_TRACE_MIN_WAVES 5
 #endif
-#ifndef RZ_WALK_PREFETCH  // the cooperative mesh walk touches the lines of its possible next records before it tests the current box
-#define RZ_WALK_PREFETCH 1
-#endif
 #define RZ_PI_F 3.14159265358979323846f
 #define RZ_END 0xFFFFFFFFu
 // Termination of every walk is proven on the host before anything is launched (hiprz_api.hip: check_scene walks the
@@ -457,6 +454,39 @@ RZ_DEV bool box_hit_unpacked(float4 b0, float4 b1, const WalkRay& r) {
     float tmin, tmax;
     box_range_unpacked<SHARED_RCP>(b0, b1, r, tmin, tmax);
     return !(tmax < r.near_ || tmin > tmax || tmin > r.far_);
+}
+// The same verdict for less arithmetic (the mesh-level node test of the cooperative walks, their most frequent operation).  The six
+// quotients only matter through three comparisons.  One multiplication by the ray's refined reciprocal gives each quotient to within
+// 2^-21 of its correctly rounded value (the numerator is the exact path's own: one rounded subtraction; the reciprocal is within an ulp,
+// the product adds a rounding), and max / min of values that are each within a relative band are within the same band (x -> x +- e|x|
+// is monotone).  So bounds that are 2^-20 wide decide the verdict whenever no comparison falls inside them — certainly hit, or
+// certainly missed — and only when a lane of the wave cannot tell does the wave run the exact sequence (hiprz_selftest compares the
+// verdicts on random boxes and counts how often that happens).
+#ifndef RZ_FILTERED_BOX_TEST
+#define RZ_FILTERED_BOX_TEST 1
+#endif
+RZ_DEV void box_filter(float4 b0, float4 b1, const WalkRay& r, bool& missed, bool& hit) {  // r.fast lanes only
+    const float a1 = (b0.x - r.o.x) * r.y.x, a2 = (b0.y - r.o.x) * r.y.x;
+    const float a3 = (b0.z - r.o.y) * r.y.y, a4 = (b0.w - r.o.y) * r.y.y;
+    const float a5 = (b1.x - r.o.z) * r.y.z, a6 = (b1.y - r.o.z) * r.y.z;
+    const float tmin = vmax3(vmin(a1, a2), vmin(a3, a4), vmin(a5, a6));
+    const float tmax = vmin3(vmax(a1, a2), vmax(a3, a4), vmax(a5, a6));
+    const float e = 9.5367431640625e-07f;  // 2^-20
+    const float dmin = e * fabsf(tmin), dmax = e * fabsf(tmax);
+    const float lo_min = tmin - dmin, hi_min = tmin + dmin, lo_max = tmax - dmax, hi_max = tmax + dmax;
+    missed = hi_max < r.near_ || lo_min > hi_max || lo_min > r.far_;
+    hit = lo_max >= r.near_ && hi_min <= lo_max && hi_min <= r.far_;
+}
+template <bool SHARED_RCP>
+RZ_DEV bool box_hit_filtered(float4 b0, float4 b1, const WalkRay& r) {
+#if RZ_FILTERED_BOX_TEST
+    if (SHARED_RCP && __all(r.fast)) {  // wave-uniform branch
+        bool missed, hit;
+        box_filter(b0, b1, r, missed, hit);
+        if (__all(missed || hit)) return hit;
+    }
+#endif
+    return box_hit_unpacked<SHARED_RCP>(b0, b1, r);
 }
 template <bool SHARED_RCP>
 RZ_DEV bool box_hit(float4 b0, float4 b1, const WalkRay& r) {
@@ -1178,7 +1208,6 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
     const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? (s.walk_l < 8u ? s.walk_l : 8u) : 8u, hmin = s.walk_h;
     uint32_t n = active ? s.tlas_root : RZ_END, guard = 0u;
     bool root_missed = false;
-    float probe_sink = 0.0f;  // RZ_WALK_PREFETCH: where the probe loads of the mesh walk end up
     while (__any(n != RZ_END)) {
         RZ_GUARD(guard);
         uint32_t i = 0u, end = 0u, link = RZ_END;
@@ -1238,23 +1267,11 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
                         const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                         const bool mleaf = (mmeta & HIPRZ_NODE_LEAF) != 0u;
                         const uint32_t near_child = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);  // the nearer child is entered first
-#if RZ_WALK_PREFETCH
-                        // The walk is a chain of dependent record fetches, each followed by ~45 instructions of box test (measured on the
-                        // 301 k-triangle mesh: one more dependent fetch per step +20 %, the test's arithmetic twice +19 %).  Whatever the test
-                        // says, the next record is the nearer child's, the skip link's, or this leaf's first triangle: touch those lines now,
-                        // so that they travel while the test runs.  The probes are ordinary loads whose values end in `probe_sink`.
-                        const float4* after = mlink != RZ_END ? s.nodes64 + 4 * size_t(mlink) : s.nodes64;
-                        const float4* inside = mleaf ? s.tris + 3 * size_t(mbegin) : s.nodes64 + 4 * size_t(near_child);
-                        const float probe_a = reinterpret_cast<const float*>(after)[0], probe_b = reinterpret_cast<const float*>(inside)[0];
-#endif
-                        if (box_hit_unpacked<RCP>(m0, m1, lr)) {
+                        if (box_hit_filtered<RCP>(m0, m1, lr)) {
                             if (!mleaf) mlink = near_child;
                             else tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
                         }
                         m = mlink;
-#if RZ_WALK_PREFETCH
-                        probe_sink += probe_a + probe_b;
-#endif
                     }
                 }
                 if (!__any(tj != tj_end)) continue;
@@ -1272,10 +1289,6 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
         if (n != RZ_END && !descended) n = link;
     }
     ray.near_ = g.near_, ray.far_ = g.far_;
-#if RZ_WALK_PREFETCH
-    // a value no box coordinate or vertex sum takes keeps the probes' results "used" without ever changing anything
-    if (__float_as_uint(probe_sink) == 0x7FC12345u) ray.far_ = probe_sink;
-#endif
     if (!active || root_missed) return 0;
     return hit.instance >= 0 ? 2 : 1;
 }
@@ -1370,7 +1383,6 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
     const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? (s.walk_l < 8u ? s.walk_l : 8u) : 8u, hmin = s.walk_h;
     uint32_t n = active ? s.tlas_root : RZ_END, guard = 0u;
     bool occluded = false;
-    float probe_sink = 0.0f;
     while (__any(n != RZ_END)) {
         RZ_GUARD(guard);
         uint32_t i = 0u, end = 0u, link = RZ_END;
@@ -1424,19 +1436,11 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
                         const uint32_t mbegin = __float_as_uint(m1.z), mmeta = __float_as_uint(m1.w);
                         const bool mleaf = (mmeta & HIPRZ_NODE_LEAF) != 0u;
                         const uint32_t near_child = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);
-#if RZ_WALK_PREFETCH  // as in closest_hit_coop: the lines of the possible next records travel while the box is tested
-                        const float4* after = mlink != RZ_END ? s.nodes64 + 4 * size_t(mlink) : s.nodes64;
-                        const float4* inside = mleaf ? s.tris + 3 * size_t(mbegin) : s.nodes64 + 4 * size_t(near_child);
-                        const float probe_a = reinterpret_cast<const float*>(after)[0], probe_b = reinterpret_cast<const float*>(inside)[0];
-#endif
-                        if (box_hit_unpacked<RCP>(m0, m1, lr)) {
+                        if (box_hit_filtered<RCP>(m0, m1, lr)) {
                             if (!mleaf) mlink = near_child;
                             else tj = mbegin, tj_end = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
                         }
                         m = mlink;
-#if RZ_WALK_PREFETCH
-                        probe_sink += probe_a + probe_b;
-#endif
                     }
                 }
                 if (!__any(tj != tj_end)) continue;
@@ -1487,9 +1491,6 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
         }
         if (n != RZ_END && !descended) n = link;
     }
-#if RZ_WALK_PREFETCH
-    if (__float_as_uint(probe_sink) == 0x7FC12345u) return probe_sink;  // never: keeps the probes' results "used"
-#endif
     return occluded ? 0.0f : 1.0f;
 }
 
@@ -1515,6 +1516,11 @@ RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit
 // MODE 8 ("compat"): the CUDA engine's behaviours selected by DConfig::flags (hiprz_compat.hpp): shadow rays inline on skip links,
 // opaque as in the CPU kernel or — HIPRZ_COMPAT_SHADOW_COLOR — through triangles with a coloured mask.
 #define RZ_SHADOW_COMPAT 8
+// MODE 9: the compat shading with the shadow rays DEFERRED like MODE 4 (the opaque shadow rays of the CPU kernel; the coloured mask of
+// HIPRZ_COMPAT_SHADOW_COLOR needs a texture fetch per crossed triangle and stays inline, MODE 8)
+#define RZ_SHADOW_COMPAT_DEFER 9
+constexpr bool shadow_mode_defers(int mode) { return mode == RZ_SHADOW_DEFER || mode == RZ_SHADOW_COMPAT_DEFER; }
+constexpr bool shadow_mode_compat(int mode) { return mode == RZ_SHADOW_COMPAT || mode == RZ_SHADOW_COMPAT_DEFER; }
 template <bool COUNT>
 RZ_DEV col4 compat_shadow_mask(const DScene& s, const Ray& ray, bool filtering, Counters& cnt);  // hiprz_compat.hpp
 template <bool COUNT>
@@ -1861,7 +1867,7 @@ RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const Shado
             Ray sr;
             sr.o = point, sr.d = normalized(vPL), sr.near_ = 0.0f, sr.far_ = RZ_FLT_MAX;
             const col4 term = (from_u8(__float_as_uint(l1.x)) * bc) * radiance;
-            if constexpr (MODE == RZ_SHADOW_DEFER) {
+            if constexpr (shadow_mode_defers(MODE)) {
                 defer_sample(lds_column, i, sr, term);
             } else {
                 col4 V_PL;
@@ -1920,7 +1926,7 @@ RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const Shado
             Ray sr;
             sr.o = point, sr.d = normalized(vPL), sr.near_ = 0.0f, sr.far_ = dPL;
             const col4 term = (from_u8(__float_as_uint(l2.x)) * bc) * radiance;
-            if constexpr (MODE == RZ_SHADOW_DEFER) {
+            if constexpr (shadow_mode_defers(MODE)) {
                 defer_sample(lds_column, cfg.direct_samples + i, sr, term);
             } else {
                 col4 V_PL;

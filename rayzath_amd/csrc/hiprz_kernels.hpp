@@ -88,7 +88,7 @@ template <bool COUNT, int SHADOW = 1>
 RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cfg, const PixelId& p, PathState& ps, uint32_t pass,
                           int found, const Hit& hit, const ShadowCtx& lds_column, Counters& cnt, col4& final_color, bool& path_continues,
                           Rng* shared_rng = nullptr) {
-    constexpr bool COMPAT = SHADOW == RZ_SHADOW_COMPAT;  // the CUDA engine's behaviours by cfg.flags; `found == 3`: the medium scattered the ray
+    constexpr bool COMPAT = shadow_mode_compat(SHADOW);  // the CUDA engine's behaviours by cfg.flags; `found == 3`: the medium scattered the ray
     Ray& ray = ps.ray;
     col4& ray_color = ps.color;
     uint32_t& ray_material = ps.material;
@@ -156,7 +156,7 @@ RZ_DEV void shade_segment(const DScene& s, const DCamera& cam, const DConfig& cf
         point = (ray.o + ray.d * ray.far_) + sf.normal * (0.0001f * ray.far_);
 
         const col4 direct = direct_illumination<SHADOW, COUNT>(s, cfg, lds_column, ray.d, ray_material, point, next_direction, sf, rng, cnt);
-        if constexpr (SHADOW == RZ_SHADOW_DEFER) {  // rz_shadow_kernel adds (direct * a) * b once it knows the shadow masks
+        if constexpr (shadow_mode_defers(SHADOW)) {  // rz_shadow_kernel adds (direct * a) * b once it knows the shadow masks
             lds_column.defer_done = true;
             lds_column.defer_a = ray_color, lds_column.defer_b = lerp(splat(1.0f), sf.color, sf.metalness);
         } else if constexpr (SHADOW == RZ_SHADOW_NONE || SHADOW == RZ_SHADOW_PLAIN) {
@@ -195,7 +195,7 @@ RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& 
 
     // ---- accumulate ----
     if constexpr (FIRST) f.depth[p.local] = hit_distance;
-    if constexpr (SHADOW == RZ_SHADOW_DEFER) {
+    if constexpr (shadow_mode_defers(SHADOW)) {
         // the radiance so far + what rz_shadow_kernel needs to finish it; it also does the accumulation
         const uint32_t bits = (path_continues ? 1u : 0u) | (lds_column.defer_done ? 2u : 0u) | (lds_column.defer_mask << 2);
         float4* rec = f.nee + size_t(p.local) * f.nee_quads;
@@ -220,7 +220,7 @@ RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& 
     f.st1[p.local] = make_float4(ray.d.y, ray.d.z, ray_color.r, ray_color.g);
     f.st2[p.local] = make_float2(ray_color.b, __uint_as_float((ray_material & 0xFFFFu) | (depth << 16)));
     if (f.sort_key) f.sort_key[p.local] = ray_sort_key(s, ray.o, ray.d, s.sort_variant);
-    if constexpr (SHADOW == RZ_SHADOW_DEFER) {
+    if constexpr (shadow_mode_defers(SHADOW)) {
         // the shadow rays of this pixel start at the hit point and point at the light the (last) sample chose: rays from one cell to
         // one light walk the same instances.  Pixels without a sample have nothing to walk and sort to the end.
         if (f.shadow_key)
@@ -485,6 +485,39 @@ __global__ void __launch_bounds__(64, MINW) rz_trace_coop_kernel(const DScene s,
     flush_counters<COUNT>(f, 0u, cnt);
 }
 
+// The same walk for the CUDA-compat integrator (hiprz_set_mode): with HIPRZ_COMPAT_SCATTERING the medium the ray travels in may end the
+// segment before any surface does (Material::applyScattering, cuda_material.cuh:141-159) — the distance is the FIRST draw of the
+// segment's random stream (cuda_world.cuh:91-100), taken here as the walk's range and taken again by the shade kernel.
+template <bool FIRST, bool COUNT>
+__global__ void __launch_bounds__(64, 4) rz_trace_coop_compat_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
+    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+    Counters cnt;
+    const PixelId p = pixel_of_local(f, cam, (!FIRST && f.perm) ? f.perm[slot] : slot);
+    PathState ps;
+    load_path<FIRST>(f, cam, p, ps);
+    bool scattered = false;
+    if (p.active && (cfg.flags & HIPRZ_COMPAT_SCATTERING)) {
+        const float sigma = material_scattering(s, ps.material);
+        if (sigma > 1.0e-4f) {
+            const uint32_t pass = FIRST ? 0u : *f.pass, pixel_idx = p.y * cam.width + p.x;
+            Rng rng(float(p.x) / float(cam.width), float(p.y) / float(cam.height), seed_value(cfg.seed, pass, (pixel_idx + ps.depth) & 255u));
+            const float distance = (-logf(rng.unsignedUniform() + 1.0e-4f)) / sigma;
+            if (distance < ps.ray.far_) ps.ray.far_ = distance, scattered = true;
+        }
+    }
+    Hit hit;
+    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
+    int found = 0;
+    if (s.n_instances != 0u) found = closest_hit_coop<COUNT, RZ_TRACE_SHARED_RCP != 0>(s, CoopLds(rz_lds), p.active, ps.ray, hit, cnt);
+    if (scattered && found != 2) found = 3;
+    if (p.active) {
+        f.hit0[p.local] = make_float4(ps.ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
+        f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
+    }
+    flush_counters<COUNT>(f, 0u, cnt);
+}
+
 // SHADOW: the shadow-ray walk — 1 = nested loops with the per-lane LDS stack (scenes staged in LDS), 3 = skip links with the
 // tree tops staged in LDS instead of a stack (everything else; `top_n` nodes).
 template <bool FIRST, bool COUNT, bool LDS_SCENE, int SHADOW>
@@ -493,7 +526,7 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScen
     DScene s = scene_in;
     unsigned char* workspace = rz_lds + stage_scene<LDS_SCENE>(s, rz_lds);
     ShadowCtx shadow{stack_column<1>(workspace), TopCache{nullptr, nullptr, 0u}};
-    if constexpr (SHADOW == RZ_SHADOW_DEFER) {
+    if constexpr (shadow_mode_defers(SHADOW) || shadow_mode_compat(SHADOW)) {
         shadow.lds_column = nullptr;
     }
     if constexpr (SHADOW == 3) {
@@ -513,13 +546,22 @@ __global__ void __launch_bounds__(256, RZ_MIN_WAVES) rz_shade_kernel(const DScen
         const float4 h0 = f.hit0[p.local];
         const uint32_t h1 = f.hit1[p.local];
         Hit hit;
-        const int found = int((h1 >> 29) & 3u);
+        const int found = int((h1 >> 29) & 3u);  // 3 (compat): the medium scattered the ray before it met a surface
         ps.ray.far_ = h0.x;
         hit.bx = h0.y, hit.by = h0.z, hit.triangle = __float_as_uint(h0.w);
         hit.instance = found == 2 ? int32_t(h1 & 0x1FFFFFFFu) : -1;
         hit.external = (h1 & 0x80000000u) != 0u;
         shadow.nee = f.nee + size_t(p.local) * f.nee_quads;
-        shade_and_store<FIRST, COUNT, SHADOW>(s, cam, cfg, f, p, ps, found, hit, shadow, cnt);
+        if constexpr (shadow_mode_compat(SHADOW)) {
+            // the CUDA engine's stream of draws: the scattering distance of the medium first (the compat trace kernel drew the same number
+            // for the same pixel, pass and depth), then whatever the shading draws
+            const uint32_t pass = FIRST ? 0u : *f.pass, pixel_idx = p.y * cam.width + p.x;
+            Rng rng(float(p.x) / float(cam.width), float(p.y) / float(cam.height), seed_value(cfg.seed, pass, (pixel_idx + ps.depth) & 255u));
+            if ((cfg.flags & HIPRZ_COMPAT_SCATTERING) && material_scattering(s, ps.material) > 1.0e-4f) (void)rng.unsignedUniform();
+            shade_and_store<FIRST, COUNT, SHADOW>(s, cam, cfg, f, p, ps, found, hit, shadow, cnt, &rng);
+        } else {
+            shade_and_store<FIRST, COUNT, SHADOW>(s, cam, cfg, f, p, ps, found, hit, shadow, cnt);
+        }
     } else if (f.sort_key && p.local < f.n_local_tiles * 256u) {
         f.sort_key[p.local] = 0x00FFFFFFu;  // slots outside the frame sort to the end
         if (f.shadow_key) f.shadow_key[p.local] = 0x00FFFFFFu;

@@ -13,6 +13,21 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
     const DConfig cfg = make_config(c);
     const dim3 grid = g.grid, block = g.block;
     const bool lights = c->dscene.n_spot_lights + c->dscene.n_direct_lights != 0u;
+    if (c->mode_flags & kIntegratorFlags) {
+        // CUDA-compat integrator: the same packaging as below — shading, then (scenes with lights) the pass's shadow rays in the lean
+        // cooperative kernel in their own sorted order.  Only the coloured shadow mask (HIPRZ_COMPAT_SHADOW_COLOR: a texture fetch per
+        // crossed triangle, no early out at the first hit) walks inside the shade kernel.
+        if (lights && defer_shadows(c) && !(c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR)) {
+            hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_COMPAT_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+            launch_sort(c, f.shadow_key != nullptr);
+            if (f.shadow_key) launch_shadow_sort(c);
+            hipLaunchKernelGGL((rz_shadow_coop_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
+            join_sort(c);
+        } else {
+            hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_COMPAT>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        }
+        return;
+    }
     if (!lights && c->nolight_kernels && c->n_textures == 0u) {  // no lights, no maps
         if (g.lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_PLAIN>), grid, block, g.blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
         else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_PLAIN>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);

@@ -10,6 +10,10 @@ namespace {
 template <bool FIRST, bool COUNT>
 void launch_trace_t(hiprz_ctx* c, const DFrame& f) {
     const PassGeometry g = pass_geometry(c);
+    if (c->mode_flags & kIntegratorFlags) {  // CUDA-compat integrator on the split pipeline: the cooperative walk + the medium's scattering distance
+        hipLaunchKernelGGL((rz_trace_coop_compat_kernel<FIRST, COUNT>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, make_config(c), f);
+        return;
+    }
     if (g.mode == 3) {
         // one wave per workgroup: a workgroup's slot is free as soon as ITS slowest ray is done
         const dim3 grid(c->n_local_tiles * 4u), block(64);

@@ -333,3 +333,29 @@ def test_reprojection_follows_a_moved_camera(devices):
         one.upload_camera(cam_now)
         one.render(1)
         assert np.array_equal(one.read_accum(), got)
+
+
+@pytest.mark.parametrize("flags", [COMPAT_BEER_LAMBERT | COMPAT_SCATTERING, COMPAT_TEXTURE_MULT | COMPAT_FILTERING, 31, 31 & ~COMPAT_SHADOW_COLOR])
+def test_compat_integrator_on_the_split_pipeline_equals_the_fused_kernel(flags):
+    """The compat integrator runs by default through the packaging of the default mode — rays in sorted order, the cooperative front-to-back
+    walk (with the medium's scattering distance drawn before it), shading, and — without the coloured shadow mask — the pass's shadow rays
+    deferred to the lean cooperative kernel.  hiprz_set_pipeline(0) keeps the one fused kernel per pass: the same frames, bit for bit."""
+    for world, samples in ((scenes.living_room(96, 64, 16), (2, 1)), (scenes.shading_inputs_scene(96, 64), (1, 2)), (scenes.cornell_box(80, 48), (1, 1))):
+        for m in world.materials[:3]:                        # give the media something to scatter and absorb with
+            m.scattering = max(m.scattering, 0.0)
+        world.material.scattering = 0.15                     # the room's air scatters: every segment draws a distance first
+        flat, cam = flatten(world), camera_struct(world.camera)
+        cfg = RenderConfig(LightSampling(*samples), Tracing(5, 4)).struct()
+        out = []
+        for pipeline in (0, -1):
+            c = Context(0)
+            c.set_mode(flags), c.set_pipeline(pipeline)
+            c.upload_scene(flat), c.upload_camera(cam), c.set_config(cfg)
+            c.render(1), c.render(5), c.render(4)
+            out.append((c.read_accum(), c.read_depth(), c.read_state(), c.pipeline()))
+            c.close()
+        assert [o[3] for o in out] == [0, 1]
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+        for k in out[0][2]:
+            assert np.array_equal(out[0][2][k], out[1][2][k]), k
+        assert out[0][0][..., 3].sum() > 0

@@ -271,12 +271,14 @@ def test_pick(built):
 
 def test_shared_reciprocal_division_is_exact(built):
     """The walk's box test divides with one refined reciprocal per ray axis; the device self-test
-    compares it with the correctly rounded `/` over the operand range the kernel allows it in."""
+    compares it with the correctly rounded `/` over the operand range the kernel allows it in — and the filtered box test of the
+    cooperative walks (a verdict from one multiplication per quotient wherever no comparison is closer than 2^-20) with the exact one."""
     ctx = Context(0)
     for seed in (1, 2, 3):
         bad, n = ctx.selftest(256, seed)
-        assert n == 2 * 1024 * 256 * 256
-        assert bad == 0, f"{bad} of {n} quotients differ"
+        assert 2 * 1024 * 256 * 256 <= n <= 3 * 1024 * 256 * 256     # two quotients per case + (rays in the fast range) one filtered box test
+        assert bad == 0, f"{bad} of {n} quotients / box verdicts differ"
+    print(ctx.timings())
 
 
 @pytest.mark.parametrize("name", ["cornell_128", "living_room_96x64", "sphere_160x90", "textured_80x48"])

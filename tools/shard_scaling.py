@@ -18,6 +18,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--shards", default="1,2,4,8")
 ap.add_argument("--traversal", type=int, default=-1)
 ap.add_argument("--pipeline", type=int, default=-1)
+ap.add_argument("--tree", type=int, default=0, help="0 the snapshot's mesh trees, 1 host SAH rebuild, 2 built on the device")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 for config in args.config.split(","):
@@ -34,6 +35,7 @@ for config in args.config.split(","):
             if args.pipeline >= 0:
                 ctx.set_pipeline(args.pipeline)
             ctx.set_shard(r, n)
+            ctx.set_tree(args.tree)
             ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(cfg)
             frame = ShardedFrame(ctx, r, n, cam.width, cam.height, None, dev)
 
