@@ -1,0 +1,4 @@
+#!/bin/bash
+set -o pipefail
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+bash tools/round_profiles.sh "$@"
