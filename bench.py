@@ -7,7 +7,9 @@ every pass traces one path segment per pixel), a tone map, and — for N > 1 —
 of the accumulators to rank 0 over RCCL.  rays = path segments, exactly the reference's own
 counter (`traced_rays += W*H` per pass, cpu_engine_renderer.cpp:173; shadow rays are not
 counted).  value = steps * rpp * W * H / seconds / 1e6 over the whole job; the frame is
-fixed, so more GPUs split the same work ("strong" scaling).
+fixed, so more GPUs split the same work ("strong" scaling).  `value` is measured on the packaging the
+Engine hosts use by default — for scenes without lights every GPU's share runs on two streams (one scene
+copy) — and `single_stream` beside it on one stream per GPU: whole-frame launches, the ones `roofline` prices.
 
 Extra objects on the JSON line:
   roofline      HBM roofline of the pass kernel: algorithmic bytes per launch (SURVEY.md §8d
@@ -76,7 +78,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=-1, help="0 fused pass kernel, 1 trace + shade kernels, 2 resident batch kernel (-1: chosen per scene)")
     ap.add_argument("--ray-sort", type=int, default=-1, help="-1 auto, 0 off, 1 on")
     ap.add_argument("--walk-order", type=int, default=-1, help="mesh child order of the skip-link walk: 0 reference order, 1 front to back (-1: library default)")
-    ap.add_argument("--streams", type=int, default=-1, help="N = 1, after the main measurement: the same steps with the frame split over this many contexts-with-a-stream on the GPU (what the Engine hosts do by default for scenes without lights), reported as `several_streams`; -1 = the hosts' choice (rayzath_amd.engine.default_streams), 1 = skip")
+    ap.add_argument("--streams", type=int, default=-1, help="streams per GPU of the packaging `value` is measured on: every rank's tiles interleaved over this many contexts-with-a-stream on its GPU sharing one scene copy (-1 = the Engine hosts' default, rayzath_amd.engine.default_streams: 2 for scenes without lights, else 1); the single-stream figure is always measured too (`single_stream`, `roofline`)")
     ap.add_argument("--mode", type=int, default=0, help="hiprz_set_mode flags: 0 = the CPU kernel (the parity-checked default), 63 = every behaviour of the reference's CUDA engine")
     ap.add_argument("--tree", type=int, default=0, help="0 the scene's (reference) mesh trees, 1 rebuilt with a binned SAH (hiprz_set_tree; same frames, fewer tests; not the default)")
     ap.add_argument("--no-xcd-swizzle", action="store_true")
@@ -129,22 +131,26 @@ def main():
     cfg = RenderConfig(tracing=Tracing(preset["max_depth"], RPP)).struct()
     W, H = cam.width, cam.height
 
-    ctx = Context(local_rank)
-    ctx.set_traversal_mode(args.traversal)
-    if args.pipeline >= 0:
-        ctx.set_pipeline(args.pipeline)
-    ctx.set_ray_sort(args.ray_sort)
-    if args.walk_order >= 0:
-        ctx.set_walk_order(args.walk_order)
-    if args.no_xcd_swizzle:
-        ctx.set_xcd_swizzle(False)
-    ctx.set_tree(args.tree)
-    if args.mode:
-        ctx.set_mode(args.mode)
-    ctx.set_shard(rank, world)
-    ctx.upload_scene(flat)
-    ctx.upload_camera(cam)
-    ctx.set_config(cfg)
+    def make_context(devices):
+        c = Context(devices)
+        c.set_traversal_mode(args.traversal)
+        if args.pipeline >= 0:
+            c.set_pipeline(args.pipeline)
+        c.set_ray_sort(args.ray_sort)
+        if args.walk_order >= 0:
+            c.set_walk_order(args.walk_order)
+        if args.no_xcd_swizzle:
+            c.set_xcd_swizzle(False)
+        c.set_tree(args.tree)
+        if args.mode:
+            c.set_mode(args.mode)
+        c.set_shard(rank, world)
+        c.upload_scene(flat)
+        c.upload_camera(cam)
+        c.set_config(cfg)
+        return c
+
+    ctx = make_context(local_rank)
     frame = ShardedFrame(ctx, rank, world, W, H, dist if world > 1 else None, torch.device("cuda", local_rank), overlap=not args.no_overlap)
 
     def step():
@@ -185,19 +191,24 @@ def main():
     # repeat ("median of 5").  Nothing but step() runs between the fences.
     alpha_before = float(ctx.read_accum()[..., 3].sum()) if rank == 0 and world == 1 else None
     passes_before = ctx.pass_count()
-    samples = []
+    def timed_repeats(one_step):
+        """EXACTLY `steps` steps between two fences, repeated until `repeats` repeats and `min_seconds` of timed wall have been collected.
+        Every rank sees the same (max-reduced) samples, so all of them stop after the same repeat."""
+        out = []
+        while len(out) < max(args.repeats, 1) or (sum(out) < args.min_seconds and len(out) < 4096):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            fence()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out.append(float(t.item()))
+        return out
+
     t_all0 = time.perf_counter()
-    # every rank sees the same (max-reduced) samples, so all of them stop after the same repeat
-    while len(samples) < max(args.repeats, 1) or (sum(samples) < args.min_seconds and len(samples) < 4096):
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        samples.append(float(t.item()))
+    samples = timed_repeats(step)
     timed_wall = time.perf_counter() - t_all0
     elapsed = sorted(samples)[len(samples) // 2]
     kernel_ms, launches = ctx.kernel_time_ms()   # hip events around every render batch of the timed repeats
@@ -229,42 +240,49 @@ def main():
         end_to_end = {"value": args.steps * RPP * W * H / e2e / 1e6, "unit": "Mrays/s", "ms_per_step": e2e / args.steps * 1e3,
                       "includes": "render + tone map + hiprz_read_rgba8 into host memory (8.3 MB per step over PCIe, synchronous)"}
         ctx.kernel_time_ms()
-    # ---- the hosts' default on one GPU (rayzath_amd.engine.default_streams, Hip::Engine::defaultStreams): the frame split over K
-    # contexts-with-a-stream on the SAME GPU (hiprz_create_multi with the device named K times) — one share's sorts, pass bookkeeping and
-    # kernel tails run beside another share's walks.  Measured with the same protocol, reported beside `value`: the roofline above
-    # belongs to whole-frame launches on one stream, which is what `value` times and what a rank of a multi-GPU job runs.
+    # ---- the hosts' default packaging (rayzath_amd.engine.default_streams, Hip::Engine::defaultStreams): the rank's share of the frame over K
+    # streams on its GPU (hiprz_create_multi with the device named K times: tiles interleaved, ONE scene copy shared) — one stream's sorts,
+    # pass bookkeeping and kernel tails run beside another's walks.  The same protocol as above, sharding and gather included; when K > 1 this
+    # is the line's `value` (what a host gets by default) and the single-stream figure — the one the per-launch roofline belongs to — is
+    # reported beside it as `single_stream`.
     several_streams = None
     from rayzath_amd.engine import default_streams
     k_streams = args.streams if args.streams > 0 else default_streams(len(flat.spot_lights) + len(flat.direct_lights))
-    if world == 1 and k_streams > 1:
-        fast = Context([local_rank] * k_streams)
-        fast.set_traversal_mode(args.traversal)
-        if args.pipeline >= 0:
-            fast.set_pipeline(args.pipeline)
-        fast.set_ray_sort(args.ray_sort)
-        if args.walk_order >= 0:
-            fast.set_walk_order(args.walk_order)
-        if args.no_xcd_swizzle:
-            fast.set_xcd_swizzle(False)
-        fast.set_tree(args.tree)
-        if args.mode:
-            fast.set_mode(args.mode)
-        fast.upload_scene(flat), fast.upload_camera(cam), fast.set_config(cfg)
+    if k_streams > 1:
+        fence()
+        fast = make_context([local_rank] * k_streams)
+        fast_frame = ShardedFrame(fast, rank, world, W, H, dist if world > 1 else None, torch.device("cuda", local_rank), overlap=not args.no_overlap)
+
+        def fast_step():
+            fast.render(RPP)
+            if world > 1:
+                fast_frame.gather()
+            else:
+                fast.tonemap()
+
         fast.render(1)
+        if args.verify_gather and world > 1:  # the frame assembled from every rank's streams == one unsharded context's
+            fast.render(RPP)
+            img = fast_frame.gather_accum()
+            fast_frame.sync()
+            if rank == 0:
+                import numpy as np
+                ref = Context(local_rank)
+                ref.set_traversal_mode(args.traversal)
+                ref.upload_scene(flat), ref.upload_camera(cam), ref.set_config(cfg)
+                ref.render(1 + RPP)
+                assert np.array_equal(img.cpu().numpy(), ref.read_accum()), "frame gathered from the ranks' streams differs from the unsharded frame"
+                ref.close()
+            assert fast_frame.ray_count() == (1 + RPP) * W * H
         for _ in range(args.warmup):
-            fast.render(RPP), fast.tonemap()
-        fast_samples = []
-        for _ in range(max(args.repeats, 1)):
-            fast.sync()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                fast.render(RPP), fast.tonemap()
-            fast.sync()
-            fast_samples.append(time.perf_counter() - t0)
+            fast_step()
+        fast_samples = timed_repeats(fast_step)
         fast_elapsed = sorted(fast_samples)[len(fast_samples) // 2]
         several_streams = {"streams": k_streams, "value": args.steps * RPP * W * H / fast_elapsed / 1e6, "unit": "Mrays/s",
-                           "ms_per_step": fast_elapsed / args.steps * 1e3, "repeat_seconds": fast_samples,
-                           "note": "same steps, same protocol; the frame's tiles interleaved over %d contexts on the same GPU, each with its own stream (the Engine hosts' default for scenes without lights)" % k_streams}
+                           "ms_per_step": fast_elapsed / args.steps * 1e3, "repeats": len(fast_samples), "timed_seconds": sum(fast_samples),
+                           "repeat_seconds_min_median_max": [min(fast_samples), fast_elapsed, max(fast_samples)],
+                           "note": "same steps, same protocol; every rank's tiles interleaved over %d contexts on its GPU, each with its own stream, one scene copy (the Engine hosts' default for scenes without lights)" % k_streams}
+        fence()
         fast.close()
     rays = args.steps * RPP * W * H
     result = None
@@ -345,8 +363,8 @@ def main():
             compute = json.load(open(spath)).get(kernel_name.split(" ")[0], {})
         result = {
             "metric": "Mrays/s (path segments, primary+secondary) at 1920x1080 depth 8" if args.config == "B" else f"Mrays/s config {args.config}",
-            "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "value": several_streams["value"] if several_streams else rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": several_streams["ms_per_step"] if several_streams else elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": preset["note"], "resolution": [W, H], "max_depth": preset["max_depth"], "passes_per_step": RPP,
                        "triangles": int(len(flat.tris)), "instances": int(len(flat.instances)),
@@ -360,6 +378,9 @@ def main():
                        "passes_timed": passes_timed, "timed_wall_seconds": timed_wall},
             "spp_per_s": spp_per_s,
             "end_to_end": end_to_end,
+            "streams_per_gpu": k_streams, "value_from": "several_streams" if several_streams else "single_stream",
+            "single_stream": {"value": rays / elapsed / 1e6, "unit": "Mrays/s", "ms_per_step": elapsed / args.steps * 1e3,
+                              "note": "one context, one stream per GPU: whole-frame launches, what `roofline` and `timing` describe"},
             "several_streams": several_streams,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS,
                          "traffic": traffic, "kernel": kernel_name, "avg_launch_us": kernel_s * 1e6,

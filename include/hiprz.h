@@ -426,8 +426,10 @@ int hiprz_ray_count(hiprz_ctx* ctx, uint64_t* out); /* Camera::rayCount, camera.
 int hiprz_pass_count(hiprz_ctx* ctx, uint32_t* out);
 
 /* --- multi-GPU hand-off: tile-major device buffers for an RCCL gather.
- * Layout: owned tile lt (global tile lt*world+rank), 256 pixels each (4 waves of 8x8). --- */
-int hiprz_local_pixel_capacity(hiprz_ctx* ctx, size_t* out);          /* owned tiles * 256 */
+ * Layout: owned tile lt (global tile lt*world+rank), 256 pixels each (4 waves of 8x8).  A context over n devices / streams
+ * (hiprz_create_multi) hands out n slices of hiprz_local_pixel_capacity / n pixels each: slice r = the tiles of sub-shard rank * n + r of
+ * world * n.  The slices of all ranks laid end to end are the sub-shards 0 .. world * n - 1: hiprz_untile_gathered(world * n parts). --- */
+int hiprz_local_pixel_capacity(hiprz_ctx* ctx, size_t* out);          /* owned tiles * 256 (n slices of the job's largest sub-shard on a multi context) */
 int hiprz_export_accum_tiles(hiprz_ctx* ctx, void* dst_device, size_t bytes);  /* float4 per local pixel, D2D on ctx stream */
 /* The same for the tone-mapped output: u32 RGBA8 per local pixel (after hiprz_tonemap). */
 int hiprz_export_rgba8_tiles(hiprz_ctx* ctx, void* dst_device, size_t bytes);

@@ -195,7 +195,31 @@ void invalidate_graphs(hiprz_ctx* c) {
         if (rz_rc != HIPRZ_OK) return fail(c, rz_rc, "device " + std::to_string(p->device) + ": " + p->error);              \
     }
 
+// Scene calls: a peer on ANOTHER device mirrors the scene itself; a peer on the head's own device (a second stream on the same GPU)
+// walks the head's copy — one scene blob per device, however many streams share it.
+#define RZ_FANOUT_OTHER_DEVICES(c, call)                                                                                       \
+    for (hiprz_ctx* p : (c)->peers) {                                                                                         \
+        if (p->device == (c)->device) continue;                                                                               \
+        const int rz_rc = (call);                                                                                             \
+        if (rz_rc != HIPRZ_OK) return fail(c, rz_rc, "device " + std::to_string(p->device) + ": " + p->error);              \
+    }
+
 namespace {
+
+// a same-device peer takes over the head's view of the scene (pointers into the head's buffers, every derived figure)
+void adopt_scene(hiprz_ctx* p, const hiprz_ctx* head) {
+    p->dscene = head->dscene, p->have_scene = head->have_scene, p->stack_entries = head->stack_entries, p->lds_scene = head->lds_scene;
+    p->n_nodes = head->n_nodes, p->flat_world = head->flat_world, p->n_textures = head->n_textures, p->scene_tree = head->scene_tree;
+    p->tree_mode = head->tree_mode, p->n_tris = head->n_tris, p->n_tlas_order = head->n_tlas_order;
+    p->scene_shared = true;
+    invalidate_graphs(p);
+    p->reset_pending = true;
+    for (auto& f : p->parked) f.reset_pending = true;
+}
+void share_scene_with_streams(hiprz_ctx* c) {
+    for (hiprz_ctx* p : c->peers)
+        if (p->device == c->device) adopt_scene(p, c);
+}
 
 struct TreeCheck {
     const hiprz_scene* sc;
@@ -996,6 +1020,37 @@ void assign_setting(hiprz_ctx* c, T& field, const T& value) {
 }
 }  // namespace
 
+// Tile-major hand-off of a context's share.  One device / one stream: the owned tiles of shard (rank, world), in order.  A context over
+// several devices or streams (n parts) hands out n slices of equal capacity — slice r holds sub-shard rank * n + r of world * n, what
+// that device rendered — so the slices of all the ranks of a job, laid end to end, are the sub-shards 0 .. world * n - 1 in order:
+// hiprz_untile_gathered with world * n parts of that capacity assembles the frame.
+namespace {
+size_t part_capacity(const hiprz_ctx* c) {  // pixels per slice: the largest sub-shard of the job (the lowest ranks own one tile more)
+    const uint32_t n_tiles = c->tiles_x * c->tiles_y, total = c->world;  // c->world is already user_world * parts on a multi-device head
+    return size_t((n_tiles + total - 1u) / total) * 256u;
+}
+template <typename T, typename Tiles>
+int export_tiles(hiprz_ctx* c, void* dst_device, size_t bytes, const char* what, Tiles tiles_of) {
+    const uint32_t n_parts = uint32_t(c->peers.size()) + 1u;
+    const size_t cap = c->peers.empty() ? size_t(c->n_local_tiles) * 256u : part_capacity(c);
+    if (!dst_device || bytes < cap * n_parts * sizeof(T)) return fail(c, HIPRZ_ERR_INVALID, std::string(what) + ": destination too small");
+    (void)hipSetDevice(c->device);
+    T* dst = static_cast<T*>(dst_device);
+    if (c->n_local_tiles) RZ_HIP(c, hipMemcpyAsync(dst, tiles_of(c), size_t(c->n_local_tiles) * 256u * sizeof(T), hipMemcpyDeviceToDevice, c->stream));
+    for (uint32_t r = 1; r < n_parts; ++r) {  // every peer pushes its slice on its own stream; the head's stream waits for all of them
+        hiprz_ctx* p = c->peers[r - 1u];
+        const size_t peer_bytes = size_t(p->n_local_tiles) * 256u * sizeof(T);
+        if (!peer_bytes) continue;
+        (void)hipSetDevice(p->device);
+        RZ_HIP(c, hipMemcpyPeerAsync(dst + cap * r, c->device, tiles_of(p), p->device, peer_bytes, p->stream));
+        RZ_HIP(c, hipEventRecord(p->peer_done, p->stream));
+        (void)hipSetDevice(c->device);
+        RZ_HIP(c, hipStreamWaitEvent(c->stream, p->peer_done, 0));
+    }
+    return HIPRZ_OK;
+}
+}  // namespace
+
 extern "C" {
 
 int hiprz_validate_scene(const hiprz_scene* scene, char* message, size_t len) {
@@ -1170,7 +1225,17 @@ const char* hiprz_last_error(const hiprz_ctx* c) { return c ? c->error.c_str() :
 
 int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     if (!c) return HIPRZ_ERR_INVALID;
-    RZ_FANOUT(c, hiprz_upload_scene(p, sc));
+    RZ_FANOUT_OTHER_DEVICES(c, hiprz_upload_scene(p, sc));
+    for (hiprz_ctx* p : c->peers)  // streams on this device may still be reading the buffers this call replaces
+        if (p->device == c->device) (void)hipStreamSynchronize(p->stream);
+    struct Share {  // whatever way this call ends, the streams on this device see what the head holds then
+        hiprz_ctx* c;
+        ~Share() {
+            share_scene_with_streams(c);
+            for (hiprz_ctx* p : c->peers)
+                if (p->device == c->device) resolve_pipeline(p);
+        }
+    } share{c};
     invalidate_graphs(c);
     StageTimer timer;
     SceneCheck chk;
@@ -1422,7 +1487,13 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
 int hiprz_update_shading(hiprz_ctx* c, const hiprz_material* materials, uint32_t n_materials, const hiprz_spot_light* spot_lights,
                          uint32_t n_spot_lights, const hiprz_direct_light* direct_lights, uint32_t n_direct_lights) {
     if (!c) return HIPRZ_ERR_INVALID;
-    RZ_FANOUT(c, hiprz_update_shading(p, materials, n_materials, spot_lights, n_spot_lights, direct_lights, n_direct_lights));
+    RZ_FANOUT_OTHER_DEVICES(c, hiprz_update_shading(p, materials, n_materials, spot_lights, n_spot_lights, direct_lights, n_direct_lights));
+    struct Share {
+        hiprz_ctx* c;
+        ~Share() { share_scene_with_streams(c); }
+    } share{c};
+    for (hiprz_ctx* p : c->peers)  // streams on this device read the records that are about to be replaced
+        if (p->device == c->device) (void)hipStreamSynchronize(p->stream);
     if (!c->have_scene) return fail(c, HIPRZ_ERR_STATE, "update_shading before upload_scene");
     const uint32_t uploaded = (c->dscene.off_inst_materials - c->dscene.off_materials) / uint32_t(sizeof(hiprz_material));
     if (!materials || n_materials < 2u || ((n_materials * sizeof(hiprz_material) + 15u) & ~size_t(15)) != size_t(c->dscene.off_inst_materials - c->dscene.off_materials))
@@ -1465,7 +1536,13 @@ int restart_after_geometry_change(hiprz_ctx* c) {
 
 int hiprz_update_triangles(hiprz_ctx* c, uint32_t first, uint32_t n, const hiprz_tri* tris, const hiprz_tri_attr* attrs) {
     if (!c) return HIPRZ_ERR_INVALID;
-    RZ_FANOUT(c, hiprz_update_triangles(p, first, n, tris, attrs));
+    RZ_FANOUT_OTHER_DEVICES(c, hiprz_update_triangles(p, first, n, tris, attrs));
+    struct Share {
+        hiprz_ctx* c;
+        ~Share() { share_scene_with_streams(c); }
+    } share{c};
+    for (hiprz_ctx* p : c->peers)
+        if (p->device == c->device) (void)hipStreamSynchronize(p->stream);
     if (!c->have_scene || c->scene_tree != HIPRZ_TREE_DEVICE) return fail(c, HIPRZ_ERR_STATE, "update_triangles: the scene was not uploaded under HIPRZ_TREE_DEVICE");
     if (n == 0u) return HIPRZ_OK;
     if (!tris || !attrs || uint64_t(first) + n > c->n_tris) return fail(c, HIPRZ_ERR_INVALID, "update_triangles: range outside the uploaded triangles");
@@ -1480,7 +1557,13 @@ int hiprz_update_triangles(hiprz_ctx* c, uint32_t first, uint32_t n, const hiprz
 
 int hiprz_update_instances(hiprz_ctx* c, const hiprz_instance* instances, uint32_t n) {
     if (!c) return HIPRZ_ERR_INVALID;
-    RZ_FANOUT(c, hiprz_update_instances(p, instances, n));
+    RZ_FANOUT_OTHER_DEVICES(c, hiprz_update_instances(p, instances, n));
+    struct Share {
+        hiprz_ctx* c;
+        ~Share() { share_scene_with_streams(c); }
+    } share{c};
+    for (hiprz_ctx* p : c->peers)
+        if (p->device == c->device) (void)hipStreamSynchronize(p->stream);
     if (!c->have_scene || c->scene_tree != HIPRZ_TREE_DEVICE) return fail(c, HIPRZ_ERR_STATE, "update_instances: the scene was not uploaded under HIPRZ_TREE_DEVICE");
     if (!instances || n != c->dscene.n_instances || n != c->device_instances.size()) return fail(c, HIPRZ_ERR_INVALID, "update_instances: the scene was uploaded with " + std::to_string(c->dscene.n_instances) + " instances");
     bool fast_div = c->dscene.fast_div != 0u;
@@ -1867,26 +1950,16 @@ int hiprz_pass_count(hiprz_ctx* c, uint32_t* out) {
 
 int hiprz_local_pixel_capacity(hiprz_ctx* c, size_t* out) {
     if (!c || !out) return HIPRZ_ERR_INVALID;
-    *out = size_t(c->n_local_tiles) * 256u;
+    *out = c->peers.empty() ? size_t(c->n_local_tiles) * 256u : part_capacity(c) * (c->peers.size() + 1u);
     return HIPRZ_OK;
 }
 int hiprz_export_accum_tiles(hiprz_ctx* c, void* dst_device, size_t bytes) {
     if (!c) return HIPRZ_ERR_INVALID;
-    if (!c->peers.empty()) return fail(c, HIPRZ_ERR_STATE, "tile export is for single-device contexts (a multi-device context gathers inside hiprz_read_*)");
-    const size_t need = size_t(c->n_local_tiles) * 256u * sizeof(float4);
-    if (!dst_device || bytes < need) return fail(c, HIPRZ_ERR_INVALID, "export_accum_tiles: destination too small");
-    (void)hipSetDevice(c->device);
-    if (need) RZ_HIP(c, hipMemcpyAsync(dst_device, c->accum.ptr, need, hipMemcpyDeviceToDevice, c->stream));
-    return HIPRZ_OK;
+    return export_tiles<float4>(c, dst_device, bytes, "export_accum_tiles", [](hiprz_ctx* x) { return (const float4*)x->accum.ptr; });
 }
 int hiprz_export_rgba8_tiles(hiprz_ctx* c, void* dst_device, size_t bytes) {
     if (!c) return HIPRZ_ERR_INVALID;
-    if (!c->peers.empty()) return fail(c, HIPRZ_ERR_STATE, "tile export is for single-device contexts (a multi-device context gathers inside hiprz_read_*)");
-    const size_t need = size_t(c->n_local_tiles) * 256u * sizeof(uint32_t);
-    if (!dst_device || bytes < need) return fail(c, HIPRZ_ERR_INVALID, "export_rgba8_tiles: destination too small");
-    (void)hipSetDevice(c->device);
-    if (need) RZ_HIP(c, hipMemcpyAsync(dst_device, c->rgba8.ptr, need, hipMemcpyDeviceToDevice, c->stream));
-    return HIPRZ_OK;
+    return export_tiles<uint32_t>(c, dst_device, bytes, "export_rgba8_tiles", [](hiprz_ctx* x) { return (const uint32_t*)x->rgba8.ptr; });
 }
 int hiprz_untile_rgba8(hiprz_ctx* c, const void* src_tiles, uint32_t rank, uint32_t world, void* dst_image) {
     if (!c) return HIPRZ_ERR_INVALID;

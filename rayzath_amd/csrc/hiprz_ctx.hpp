@@ -179,6 +179,7 @@ struct hiprz_ctx : hiprz_frame_state {
     hiprz::DeviceArray<hiprz_direct_light> direct_lights;
     hiprz::DScene dscene{};
     bool have_scene = false;
+    bool scene_shared = false;  // a second stream on the head's device: `dscene` points into the head context's buffers
     uint32_t stack_entries = 2;  // LDS stack entries per lane the trees need (MODE 1)
     bool lds_scene = false;      // hot blob is staged into LDS by every workgroup
     int lds_scene_override = -1; // -1 auto, 0 never, 1 always (if it fits at all)

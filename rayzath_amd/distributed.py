@@ -84,7 +84,11 @@ class ShardedFrame:
         self.ctx, self.rank, self.world, self.dist = ctx, rank, world, dist
         self.width, self.height = width, height
         tiles_x, tiles_y = tile_grid(width, height)
-        self.capacity_max = owned_tile_count(0, world, tiles_x * tiles_y) * TILE_PIXELS
+        # a context over n devices / streams hands out n slices (sub-shard rank * n + r of world * n in slice r), each with the capacity of the
+        # job's largest sub-shard: the ranks' buffers laid end to end are the sub-shards 0 .. world * n - 1 (include/hiprz.h)
+        self.n_parts = ctx.device_count() if hasattr(ctx, "device_count") else 1
+        self.part_capacity = owned_tile_count(0, world * self.n_parts, tiles_x * tiles_y) * TILE_PIXELS
+        self.capacity_max = self.part_capacity * self.n_parts
         self.device = device
         on_gpu = device is not None and device.type == "cuda"
         self.stream = torch.cuda.ExternalStream(ctx.stream(), device=device) if on_gpu else None
@@ -123,10 +127,11 @@ class ShardedFrame:
         if gathered is None or parts[0].data_ptr() != gathered.data_ptr():  # world 1, or the host-staged rehearsal path
             fn = ctx.untile_rgba8 if element_bytes == 4 else ctx.untile_accum
             for r, part in enumerate(parts):
-                fn(part.data_ptr(), r, self.world, image.data_ptr())
+                for k in range(self.n_parts):  # slice k of rank r = sub-shard r * n_parts + k of world * n_parts
+                    fn(part.data_ptr() + k * self.part_capacity * element_bytes, r * self.n_parts + k, self.world * self.n_parts, image.data_ptr())
             return
         stream = self.comm.cuda_stream if self.comm is not None and self.comm is not self.stream else None
-        ctx.untile_gathered(gathered.data_ptr(), self.world, self.capacity_max * element_bytes, element_bytes, image.data_ptr(), stream)
+        ctx.untile_gathered(gathered.data_ptr(), self.world * self.n_parts, self.part_capacity * element_bytes, element_bytes, image.data_ptr(), stream)
 
     def ray_count(self):
         """Rays traced by ALL shards since the last reset (each context counts its own pixels)."""

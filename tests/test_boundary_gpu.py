@@ -77,6 +77,48 @@ def test_multi_device_context_over_two_physical_gpus(built):
         assert one.pick(*xy) == two.pick(*xy)
 
 
+def test_tile_export_of_a_context_with_several_streams(built):
+    """hiprz_export_*_tiles of a context over several streams: n slices (sub-shard rank * n + r of world * n in slice r) that
+    hiprz_untile_accum / hiprz_untile_gathered assemble into the frame one single-stream context renders — alone and as the two ranks of a
+    job.  (Device buffers straight from the HIP runtime: the test process keeps torch off the GPU.)"""
+    import ctypes as C
+    hip = C.CDLL("/opt/rocm/lib/libamdhip64.so")                     # the runtime libhiprz.so itself is linked against (one HIP runtime per process)
+    hip.hipMalloc.argtypes, hip.hipMemset.argtypes = [C.POINTER(C.c_void_p), C.c_size_t], [C.c_void_p, C.c_int, C.c_size_t]
+    hip.hipMemcpy.argtypes, hip.hipFree.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int], [C.c_void_p]
+    world = scenes.cornell_sphere(200, 120, 24)
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(tracing=Tracing(5, 4)).struct()
+    one = Context(0)
+    one.upload_scene(flat), one.upload_camera(cam), one.set_config(cfg)
+    one.render(1), one.render(4)
+    want = one.read_accum()
+    total = np.zeros_like(want)
+    for rank, n_ranks, streams in ((0, 1, 3), (0, 2, 2), (1, 2, 2)):
+        many = Context([0] * streams)
+        many.set_shard(rank, n_ranks)
+        many.upload_scene(flat), many.upload_camera(cam), many.set_config(cfg)
+        many.render(1), many.render(4)
+        capacity = many.local_pixel_capacity()
+        part_capacity = capacity // streams                           # every slice has the capacity of the job's largest sub-shard
+        buf, img = C.c_void_p(), C.c_void_p()
+        assert hip.hipMalloc(C.byref(buf), capacity * 16) == 0 and hip.hipMalloc(C.byref(img), want.nbytes) == 0
+        hip.hipMemset(img, 0, want.nbytes)
+        many.export_accum_tiles(buf.value, capacity * 16)
+        for k in range(streams):
+            many.untile_accum(buf.value + k * part_capacity * 16, rank * streams + k, n_ranks * streams, img.value)
+        many.sync()
+        got = np.zeros_like(want)
+        assert hip.hipMemcpy(got.ctypes.data, img, want.nbytes, 2) == 0   # hipMemcpyDeviceToHost
+        hip.hipFree(buf), hip.hipFree(img)
+        if n_ranks == 1:
+            assert np.array_equal(got, want)
+        else:
+            assert not ((np.abs(total).sum(-1) > 0) & (np.abs(got).sum(-1) > 0)).any()
+            total += got
+        many.close()
+    assert np.array_equal(total, want)
+
+
 def test_every_camera_has_its_own_frame(built):
     world = scenes.cornell_sphere(160, 96, resolution=24)
     flat = flatten(world)

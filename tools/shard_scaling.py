@@ -18,6 +18,7 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--shards", default="1,2,4,8")
 ap.add_argument("--traversal", type=int, default=-1)
 ap.add_argument("--pipeline", type=int, default=-1)
+ap.add_argument("--streams", type=int, default=1, help="streams per shard: Context([0] * streams), tiles interleaved, one scene copy")
 ap.add_argument("--tree", type=int, default=0, help="0 the snapshot's mesh trees, 1 host SAH rebuild, 2 built on the device")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -30,7 +31,7 @@ for config in args.config.split(","):
     for n in [int(v) for v in args.shards.split(",")]:
         per_shard, kernel_ms = [], []
         for r in range(n):
-            ctx = Context(0)
+            ctx = Context([0] * args.streams) if args.streams > 1 else Context(0)
             ctx.set_traversal_mode(args.traversal)
             if args.pipeline >= 0:
                 ctx.set_pipeline(args.pipeline)
