@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--walk-order", type=int, default=-1, help="mesh child order of the skip-link walk: 0 reference order, 1 front to back (-1: library default)")
     ap.add_argument("--streams", type=int, default=-1, help="streams per GPU of the packaging `value` is measured on: every rank's tiles interleaved over this many contexts-with-a-stream on its GPU sharing one scene copy (-1 = the Engine hosts' default, rayzath_amd.engine.default_streams: 2 for scenes without lights, else 1); the single-stream figure is always measured too (`single_stream`, `roofline`)")
     ap.add_argument("--mode", type=int, default=0, help="hiprz_set_mode flags: 0 = the CPU kernel (the parity-checked default), 63 = every behaviour of the reference's CUDA engine")
-    ap.add_argument("--tree", type=int, default=0, help="0 the scene's (reference) mesh trees, 1 rebuilt with a binned SAH (hiprz_set_tree; same frames, fewer tests; not the default)")
+    ap.add_argument("--tree", type=int, default=0, help="0 the scene's (reference) mesh trees, 1 rebuilt with a binned SAH, 2 / 3 built on the device in Morton order / with a binned SAH (hiprz_set_tree; same frames; not the default)")
     ap.add_argument("--no-xcd-swizzle", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-gather", action="store_true", help="check the gathered frame against an unsharded render (N > 1)")

@@ -352,6 +352,11 @@ int hiprz_set_temporal_blend(hiprz_ctx* ctx, float blend);
  * instances is part of its arithmetic, so that tree must be the reference's: it is, node for node).  Frames are those of the reference
  * trees bit for bit.  Afterwards hiprz_update_triangles and hiprz_update_instances change geometry without a host-side tree build. */
 #define HIPRZ_TREE_DEVICE 2u
+/* HIPRZ_TREE_DEVICE_SAH: as HIPRZ_TREE_DEVICE, the mesh trees built by the device with HIPRZ_TREE_SAH's binned surface-area heuristic
+ * (16 bins per axis, leaves of at most 8 triangles; level by level for large nodes, a thread per subtree below 32 triangles) instead
+ * of Morton order: a few more milliseconds of build for walks as short as the host-built surface-area trees'.  Same frames, same
+ * hiprz_update_triangles / hiprz_update_instances afterwards. */
+#define HIPRZ_TREE_DEVICE_SAH 3u
 int hiprz_set_tree(hiprz_ctx* ctx, uint32_t tree);
 /* Scenes uploaded under HIPRZ_TREE_DEVICE only.  New records for the triangles [first, first + n) of the uploaded snapshot's order
  * (vertices moved, normals / texture coordinates / face normals as the caller computed them; materials and source indices are taken

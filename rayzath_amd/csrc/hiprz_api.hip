@@ -96,7 +96,7 @@ __global__ void rz_pick_kernel(const DScene s, const DCamera cam, uint32_t x, ui
     hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
     Counters cnt;
     out4[0] = out4[1] = out4[2] = -1, out4[3] = 0;
-    if (s.n_instances != 0u && closest_hit_skip<false, false>(s, TopCache{nullptr, nullptr, 0u}, ray, hit, cnt) == 2) {
+    if (s.n_instances != 0u && closest_hit_skip<false, false, true>(s, TopCache{nullptr, nullptr, 0u}, ray, hit, cnt) == 2) {
         const uint32_t inst = uint32_t(hit.instance);
         const uint32_t material_base = __float_as_uint(s.instances[7 * inst + 1].w);
         const uint32_t material_count = __float_as_uint(s.instances[7 * inst + 2].w);
@@ -210,7 +210,7 @@ namespace {
 void adopt_scene(hiprz_ctx* p, const hiprz_ctx* head) {
     p->dscene = head->dscene, p->have_scene = head->have_scene, p->stack_entries = head->stack_entries, p->lds_scene = head->lds_scene;
     p->n_nodes = head->n_nodes, p->flat_world = head->flat_world, p->n_textures = head->n_textures, p->scene_tree = head->scene_tree;
-    p->tree_mode = head->tree_mode, p->n_tris = head->n_tris, p->n_tlas_order = head->n_tlas_order;
+    p->tree_mode = head->tree_mode, p->device_sah = head->device_sah, p->n_tris = head->n_tris, p->n_tlas_order = head->n_tlas_order;
     p->scene_shared = true;
     invalidate_graphs(p);
     p->reset_pending = true;
@@ -1742,8 +1742,9 @@ int hiprz_set_temporal_blend(hiprz_ctx* c, float blend) {
 int hiprz_set_tree(hiprz_ctx* c, uint32_t tree) {
     if (!c) return HIPRZ_ERR_INVALID;
     RZ_FANOUT(c, hiprz_set_tree(p, tree));
-    if (tree > HIPRZ_TREE_DEVICE) return fail(c, HIPRZ_ERR_INVALID, "set_tree: HIPRZ_TREE_REFERENCE, HIPRZ_TREE_SAH or HIPRZ_TREE_DEVICE");
-    c->tree_mode = tree;
+    if (tree > HIPRZ_TREE_DEVICE_SAH) return fail(c, HIPRZ_ERR_INVALID, "set_tree: HIPRZ_TREE_REFERENCE, HIPRZ_TREE_SAH, HIPRZ_TREE_DEVICE or HIPRZ_TREE_DEVICE_SAH");
+    c->tree_mode = tree == HIPRZ_TREE_DEVICE_SAH ? HIPRZ_TREE_DEVICE : tree;  // one kind of scene (device-built, refittable), two builders
+    c->device_sah = tree == HIPRZ_TREE_DEVICE_SAH;
     return HIPRZ_OK;
 }
 

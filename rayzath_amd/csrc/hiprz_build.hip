@@ -502,6 +502,357 @@ __global__ void rz_build_world_tree_kernel(WorldViews w) {
     *w.n_order_out = n_order;
 }
 
+
+// =======================================================================================
+// Binned surface-area build on the device (HIPRZ_TREE_DEVICE_SAH): the host's SahBuilder (hiprz_host.cpp: 16 bins per axis, leaves of at most
+// 8 triangles, a node step priced at 4 triangle tests) as kernels.  Top phase, level by level, for nodes of more than kSahSmall triangles: every
+// triangle adds itself to its node's bins (a node's triangles are one contiguous run of positions, so a workgroup of 256 positions meets at
+// most 9 such nodes and keeps their bins in LDS before it touches the global ones), one thread per node evaluates the 3 x 15 planes and
+// allocates the children, every triangle moves to its side (one atomic per wave, node and side).  Bottom phase: one thread per subtree of at
+// most kSahSmall triangles runs the host's recursion on its own run of positions.  Boxes are then fitted exactly, bottom-up, by the refit kernel.
+// =======================================================================================
+constexpr uint32_t kSahBins = 16u, kSahLeaf = 8u, kSahSmall = 32u;
+constexpr float kSahTraversal = 4.0f;
+constexpr uint32_t kSahLarge = 1u, kSahSmallRoot = 2u, kSahLeafNode = 3u, kSahInner = 4u;  // node states (n_info & 7); axis in bits 4..5, plane in bits 8..12
+
+struct SahViews {
+    const float4* tris;
+    const float4* attrs;
+    uint32_t n;
+    float* cen;             // [n][3] centre of the triangle's box
+    float* tbox;            // [n][6] min.xyz max.xyz
+    uint32_t* idx[2];       // triangle of the mesh at every position, ping-pong per level
+    uint32_t* tri_node[2];  // node that holds the position
+    uint32_t* n_first;      // nodes (local ids: 0 = root; a pair of children is allocated together)
+    uint32_t* n_count;
+    float* n_box;           // [6] the box the node bins over (exact boxes are fitted at the end)
+    uint32_t* n_parent;
+    uint32_t* n_info;
+    uint32_t* n_child;
+    uint32_t* n_hist;       // slot of the node in this level's bins
+    uint32_t* hist;         // [slot][3][16][7]: count, ordered(min.xyz), ordered(max.xyz)
+    uint32_t* cursors;      // [node][2]
+    uint32_t* counters;     // [0] nodes allocated, [1] large nodes of the next level, [2] small roots
+    uint32_t* active[2];
+    uint32_t* small_roots;
+};
+RZ_DEV uint32_t ordered(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+RZ_DEV float unordered(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+RZ_DEV float box_area(const float* b) {
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+RZ_DEV void box_grow(float* b, const float* o) {
+    for (int k = 0; k < 3; ++k) b[k] = fminf(b[k], o[k]), b[3 + k] = fmaxf(b[3 + k], o[3 + k]);
+}
+RZ_DEV int sah_bin(float c, float lo, float scale) {
+    int b = int((c - lo) * scale);
+    return b < 0 ? 0 : (b >= int(kSahBins) ? int(kSahBins) - 1 : b);
+}
+
+__global__ void __launch_bounds__(256) rz_sah_prepare_kernel(SahViews v, float3 mesh_lo, float3 mesh_hi) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t == 0u) {
+        v.n_first[0] = 0u, v.n_count[0] = v.n, v.n_parent[0] = RZ_END, v.n_hist[0] = 0u, v.n_child[0] = 0u;
+        v.n_info[0] = v.n > kSahSmall ? kSahLarge : kSahSmallRoot;
+        const float b[6] = {mesh_lo.x, mesh_lo.y, mesh_lo.z, mesh_hi.x, mesh_hi.y, mesh_hi.z};
+        for (int k = 0; k < 6; ++k) v.n_box[k] = b[k];
+        v.counters[0] = 1u, v.counters[1] = 0u, v.counters[2] = 0u;
+        v.active[0][0] = 0u;
+        if (v.n <= kSahSmall) v.small_roots[0] = 0u, v.counters[2] = 1u;
+    }
+    if (t >= v.n) return;
+    float mn[3], mx[3];
+    triangle_box(v.tris, v.attrs, t, mn, mx);
+    for (int k = 0; k < 3; ++k) v.tbox[6 * size_t(t) + k] = mn[k], v.tbox[6 * size_t(t) + 3 + k] = mx[k], v.cen[3 * size_t(t) + k] = (mn[k] + mx[k]) * 0.5f;
+    v.idx[0][t] = t, v.tri_node[0][t] = 0u;
+}
+__global__ void __launch_bounds__(256) rz_sah_clear_kernel(uint32_t* hist, uint32_t n_slots) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n_slots * 3u * kSahBins * 7u) return;
+    const uint32_t w = i % 7u;
+    hist[i] = w == 0u ? 0u : (w < 4u ? 0xFFFFFFFFu : 0u);
+}
+__global__ void __launch_bounds__(256) rz_sah_bin_kernel(SahViews v, uint32_t cur) {
+    __shared__ uint32_t lds_hist[9][3 * kSahBins][7];  // 256 positions meet at most 9 runs of more than 32 (two cut ones around seven whole ones)
+    __shared__ uint32_t lds_node[9];
+    __shared__ uint32_t wave_starts[4];
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t node = 0u;
+    bool large = false;
+    if (p < v.n) {
+        node = v.tri_node[cur][p];
+        large = (v.n_info[node] & 7u) == kSahLarge;
+    }
+    // a node's positions are one run, and only nodes of more than kSahSmall triangles take part: at most 8 runs per 256 positions
+    const bool starts = large && (p == v.n_first[node] || tid == 0u);
+    const unsigned long long smask = __ballot(starts);
+    if (lane == 0u) wave_starts[wave] = uint32_t(__popcll(smask));
+    for (uint32_t k = tid; k < 9u * 3u * kSahBins * 7u; k += 256u) {
+        const uint32_t w = k % 7u;
+        (&lds_hist[0][0][0])[k] = w == 0u ? 0u : (w < 4u ? 0xFFFFFFFFu : 0u);
+    }
+    __syncthreads();
+    uint32_t local = uint32_t(__popcll(smask & ((2ull << lane) - 1ull)));
+    for (uint32_t w = 0; w < wave; ++w) local += wave_starts[w];
+    local -= 1u;  // runs before and including mine, minus one (a large position always has a start at or before it)
+    if (starts) lds_node[local] = node;
+    if (large) {
+        const uint32_t t = v.idx[cur][p];
+        const float* nb = v.n_box + 6 * size_t(node);
+        const float* tb = v.tbox + 6 * size_t(t);
+        for (uint32_t a = 0; a < 3u; ++a) {
+            const float lo = nb[a], ext = nb[3 + a] - nb[a];
+            const int b = sah_bin(v.cen[3 * size_t(t) + a], lo, ext > 0.0f ? float(kSahBins) / ext : 0.0f);
+            uint32_t* h = lds_hist[local][a * kSahBins + uint32_t(b)];
+            atomicAdd(&h[0], 1u);
+            for (int k = 0; k < 3; ++k) atomicMin(&h[1 + k], ordered(tb[k])), atomicMax(&h[4 + k], ordered(tb[3 + k]));
+        }
+    }
+    __syncthreads();
+    const uint32_t n_local = wave_starts[0] + wave_starts[1] + wave_starts[2] + wave_starts[3];
+    for (uint32_t k = tid; k < n_local * 3u * kSahBins; k += 256u) {
+        const uint32_t l = k / (3u * kSahBins), ab = k % (3u * kSahBins);
+        const uint32_t* h = lds_hist[l][ab];
+        if (h[0] == 0u) continue;
+        uint32_t* g = v.hist + (size_t(v.n_hist[lds_node[l]]) * 3u * kSahBins + ab) * 7u;
+        atomicAdd(&g[0], h[0]);
+        for (int q = 1; q < 4; ++q) atomicMin(&g[q], h[q]);
+        for (int q = 4; q < 7; ++q) atomicMax(&g[q], h[q]);
+    }
+}
+// one thread per large node of the level: the plane of least cost over the three axes (SahBuilder::build), or — no plane separates
+// anything — the run cut in half; allocates the two children
+__global__ void __launch_bounds__(64) rz_sah_split_kernel(SahViews v, uint32_t cur_list, uint32_t n_active) {
+    const uint32_t a_i = blockIdx.x * 64u + threadIdx.x;
+    if (a_i >= n_active) return;
+    const uint32_t node = v.active[cur_list][a_i];
+    const uint32_t* hist = v.hist + size_t(v.n_hist[node]) * 3u * kSahBins * 7u;
+    const uint32_t count = v.n_count[node], first = v.n_first[node];
+    float best_cost = 3.4e38f;
+    int best_axis = -1, best_plane = 0;
+    uint32_t best_left = 0u;
+    float best_lbox[6] = {0, 0, 0, 0, 0, 0}, best_rbox[6] = {0, 0, 0, 0, 0, 0};
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t* h = hist + size_t(a) * kSahBins * 7u;
+        float right_area[kSahBins], acc[6];
+        uint32_t right_count[kSahBins];
+        uint32_t n = 0u;
+        for (int b = int(kSahBins) - 1; b > 0; --b) {
+            const uint32_t* hb = h + size_t(b) * 7u;
+            if (hb[0]) {
+                const float bb[6] = {unordered(hb[1]), unordered(hb[2]), unordered(hb[3]), unordered(hb[4]), unordered(hb[5]), unordered(hb[6])};
+                if (n == 0u) for (int k = 0; k < 6; ++k) acc[k] = bb[k];
+                else box_grow(acc, bb);
+                n += hb[0];
+            }
+            right_area[b] = n ? box_area(acc) : 0.0f, right_count[b] = n;
+        }
+        n = 0u;
+        for (int b = 0; b + 1 < int(kSahBins); ++b) {
+            const uint32_t* hb = h + size_t(b) * 7u;
+            if (hb[0]) {
+                const float bb[6] = {unordered(hb[1]), unordered(hb[2]), unordered(hb[3]), unordered(hb[4]), unordered(hb[5]), unordered(hb[6])};
+                if (n == 0u) for (int k = 0; k < 6; ++k) acc[k] = bb[k];
+                else box_grow(acc, bb);
+                n += hb[0];
+            }
+            if (n == 0u || right_count[b + 1] == 0u) continue;
+            const float cost = box_area(acc) * float(n) + right_area[b + 1] * float(right_count[b + 1]);
+            if (cost < best_cost) {
+                best_cost = cost, best_axis = a, best_plane = b + 1, best_left = n;
+                for (int k = 0; k < 6; ++k) best_lbox[k] = acc[k];
+            }
+        }
+    }
+    const float* nb = v.n_box + 6 * size_t(node);
+    uint32_t axis = 3u, plane = 0u, left = count / 2u;  // no plane separates anything: halve the run (partition type "by size": never flipped)
+    for (int k = 0; k < 6; ++k) best_rbox[k] = nb[k];
+    if (best_axis >= 0) {
+        axis = uint32_t(best_axis), plane = uint32_t(best_plane), left = best_left;
+        const uint32_t* h = hist + size_t(best_axis) * kSahBins * 7u;
+        bool any = false;
+        for (uint32_t b = plane; b < kSahBins; ++b) {
+            const uint32_t* hb = h + size_t(b) * 7u;
+            if (!hb[0]) continue;
+            const float bb[6] = {unordered(hb[1]), unordered(hb[2]), unordered(hb[3]), unordered(hb[4]), unordered(hb[5]), unordered(hb[6])};
+            if (!any) for (int k = 0; k < 6; ++k) best_rbox[k] = bb[k];
+            else box_grow(best_rbox, bb);
+            any = true;
+        }
+    } else {
+        for (int k = 0; k < 6; ++k) best_lbox[k] = nb[k];
+    }
+    const uint32_t pair = atomicAdd(&v.counters[0], 2u);
+    v.n_child[node] = pair;
+    v.n_info[node] = kSahInner | (axis << 4) | (plane << 8);
+    v.cursors[2 * size_t(node)] = 0u, v.cursors[2 * size_t(node) + 1] = 0u;
+    for (uint32_t k = 0; k < 2u; ++k) {
+        const uint32_t c = pair + k, c_count = k == 0u ? left : count - left;
+        v.n_first[c] = k == 0u ? first : first + left, v.n_count[c] = c_count, v.n_parent[c] = node, v.n_child[c] = 0u;
+        for (int q = 0; q < 6; ++q) v.n_box[6 * size_t(c) + q] = k == 0u ? best_lbox[q] : best_rbox[q];
+        if (c_count > kSahSmall) {
+            const uint32_t slot = atomicAdd(&v.counters[1], 1u);
+            v.active[cur_list ^ 1u][slot] = c, v.n_hist[c] = slot, v.n_info[c] = kSahLarge;
+        } else {
+            v.small_roots[atomicAdd(&v.counters[2], 1u)] = c, v.n_info[c] = kSahSmallRoot;
+        }
+    }
+}
+// every position moves to its side of its node's plane (positions of nodes that were not split this level stay)
+__global__ void __launch_bounds__(256) rz_sah_partition_kernel(SahViews v, uint32_t cur) {
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool in = p < v.n;
+    uint32_t node = in ? v.tri_node[cur][p] : RZ_END, t = in ? v.idx[cur][p] : 0u;
+    const uint32_t info = in ? v.n_info[node] : 0u;
+    const bool moved = in && (info & 7u) == kSahInner;  // a triangle points at an inner node only in the level that split it
+    uint32_t side = 0u, dest = p, child = node;
+    if (moved) {
+        const uint32_t axis = (info >> 4) & 3u, plane = (info >> 8) & 31u, first = v.n_first[node], count = v.n_count[node];
+        if (axis == 3u) side = (p - first) >= count / 2u ? 1u : 0u;
+        else {
+            const float* nb = v.n_box + 6 * size_t(node);
+            const float ext = nb[3 + axis] - nb[axis];
+            side = uint32_t(sah_bin(v.cen[3 * size_t(t) + axis], nb[axis], ext > 0.0f ? float(kSahBins) / ext : 0.0f)) >= plane ? 1u : 0u;
+        }
+        child = v.n_child[node] + side;
+    }
+    // one atomic per (wave, node, side): the lanes of a group count themselves by ballot
+    unsigned long long todo = __ballot(moved);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t key = __shfl(child, leader);
+        const unsigned long long group = __ballot(moved && child == key);
+        if (moved && child == key) {
+            uint32_t base = 0u;
+            if (int(lane) == leader) base = atomicAdd(&v.cursors[2 * size_t(node) + side], uint32_t(__popcll(group)));
+            base = __shfl(base, leader);
+            dest = v.n_first[child] + base + uint32_t(__popcll(group & ((1ull << lane) - 1ull)));
+        }
+        todo &= ~group;
+    }
+    if (in) v.idx[cur ^ 1u][dest] = t, v.tri_node[cur ^ 1u][dest] = child;
+}
+// one thread per subtree of at most kSahSmall triangles: SahBuilder::build on its own run of positions
+__global__ void __launch_bounds__(64) rz_sah_small_kernel(SahViews v, uint32_t cur, uint32_t n_roots) {
+    const uint32_t r = blockIdx.x * 64u + threadIdx.x;
+    if (r >= n_roots) return;
+    uint32_t* idx = v.idx[cur];
+    uint32_t stack[2 * kSahSmall];
+    uint32_t sp = 0u;
+    stack[sp++] = v.small_roots[r];
+    while (sp) {
+        const uint32_t node = stack[--sp], first = v.n_first[node], count = v.n_count[node];
+        float cbox[6];
+        for (uint32_t k = 0; k < count; ++k) {
+            const float* c = v.cen + 3 * size_t(idx[first + k]);
+            for (int q = 0; q < 3; ++q) cbox[q] = k ? fminf(cbox[q], c[q]) : c[q], cbox[3 + q] = k ? fmaxf(cbox[3 + q], c[q]) : c[q];
+        }
+        float box[6];
+        for (uint32_t k = 0; k < count; ++k) {
+            const float* tb = v.tbox + 6 * size_t(idx[first + k]);
+            if (k == 0u) for (int q = 0; q < 6; ++q) box[q] = tb[q];
+            else box_grow(box, tb);
+        }
+        for (int q = 0; q < 6; ++q) v.n_box[6 * size_t(node) + q] = box[q];
+        bool leaf = count <= 2u;
+        int best_axis = -1, best_plane = 0;
+        float best_cost = 3.4e38f;
+        if (!leaf) {
+            for (int a = 0; a < 3; ++a) {
+                const float lo = cbox[a], ext = cbox[3 + a] - cbox[a];
+                if (!(ext > 0.0f)) continue;
+                const float scale = float(kSahBins) / ext;
+                float bin_box[kSahBins][6];
+                uint32_t bin_count[kSahBins];
+                for (uint32_t b = 0; b < kSahBins; ++b) bin_count[b] = 0u;
+                for (uint32_t k = 0; k < count; ++k) {
+                    const uint32_t t = idx[first + k];
+                    const int b = sah_bin(v.cen[3 * size_t(t) + a], lo, scale);
+                    const float* tb = v.tbox + 6 * size_t(t);
+                    if (bin_count[b]++ == 0u) for (int q = 0; q < 6; ++q) bin_box[b][q] = tb[q];
+                    else box_grow(bin_box[b], tb);
+                }
+                float right_area[kSahBins], acc[6];
+                uint32_t right_count[kSahBins], n = 0u;
+                for (int b = int(kSahBins) - 1; b > 0; --b) {
+                    if (bin_count[b]) {
+                        if (n == 0u) for (int q = 0; q < 6; ++q) acc[q] = bin_box[b][q];
+                        else box_grow(acc, bin_box[b]);
+                        n += bin_count[b];
+                    }
+                    right_area[b] = n ? box_area(acc) : 0.0f, right_count[b] = n;
+                }
+                n = 0u;
+                for (int b = 0; b + 1 < int(kSahBins); ++b) {
+                    if (bin_count[b]) {
+                        if (n == 0u) for (int q = 0; q < 6; ++q) acc[q] = bin_box[b][q];
+                        else box_grow(acc, bin_box[b]);
+                        n += bin_count[b];
+                    }
+                    if (n == 0u || right_count[b + 1] == 0u) continue;
+                    const float cost = box_area(acc) * float(n) + right_area[b + 1] * float(right_count[b + 1]);
+                    if (cost < best_cost) best_cost = cost, best_axis = a, best_plane = b + 1;
+                }
+            }
+            const float node_area = box_area(box);
+            const float split_cost = best_axis >= 0 && node_area > 0.0f ? kSahTraversal + best_cost / node_area : 3.4e38f;
+            if (count <= kSahLeaf && float(count) <= split_cost) leaf = true;
+            if (!leaf && !(best_axis >= 0 && (count > kSahLeaf || split_cost < float(count)))) best_axis = -1;
+        }
+        if (leaf) {
+            v.n_info[node] = kSahLeafNode;
+            continue;
+        }
+        uint32_t mid, axis = 3u;
+        if (best_axis >= 0) {  // two-pointer partition of the run by bin < plane
+            axis = uint32_t(best_axis);
+            const float lo = cbox[best_axis], scale = float(kSahBins) / (cbox[3 + best_axis] - cbox[best_axis]);
+            uint32_t i = first, j = first + count;
+            while (i < j) {
+                if (sah_bin(v.cen[3 * size_t(idx[i]) + best_axis], lo, scale) < best_plane) ++i;
+                else {
+                    --j;
+                    const uint32_t tmp = idx[i];
+                    idx[i] = idx[j], idx[j] = tmp;
+                }
+            }
+            mid = i - first;
+        } else {  // every centroid in one spot: halve the run as it stands
+            mid = count / 2u;
+        }
+        if (mid == 0u || mid == count) {
+            v.n_info[node] = kSahLeafNode;  // (cannot happen: a chosen plane has triangles on both sides)
+            continue;
+        }
+        const uint32_t pair = atomicAdd(&v.counters[0], 2u);
+        v.n_child[node] = pair, v.n_info[node] = kSahInner | (axis << 4);
+        for (uint32_t k = 0; k < 2u; ++k) {
+            const uint32_t c = pair + k;
+            v.n_first[c] = k == 0u ? first : first + mid, v.n_count[c] = k == 0u ? mid : count - mid, v.n_parent[c] = node, v.n_child[c] = 0u;
+            v.n_info[c] = kSahSmallRoot;
+        }
+        stack[sp++] = pair + 1u, stack[sp++] = pair;
+    }
+}
+// the node records of the region in the walks' layout (boxes provisional: the refit kernel fits them exactly afterwards)
+__global__ void __launch_bounds__(256) rz_sah_emit_kernel(SahViews v, EmitViews e) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x, n_nodes = v.counters[0];
+    if (k == 0u) v.counters[3] = (n_nodes - 1u) / 2u;  // pairs of children, as the links kernel counts
+    if (k >= n_nodes) return;
+    const uint32_t info = v.n_info[k], state = info & 7u;
+    if (state == kSahInner) {
+        const uint32_t axis = (info >> 4) & 3u;
+        write_node(e, e.region + k, v.n_box + 6 * size_t(k), e.region + v.n_child[k], (axis == 3u ? 3u : 2u - axis) << HIPRZ_NODE_PTYPE_SHIFT);
+    } else {
+        write_node(e, e.region + k, v.n_box + 6 * size_t(k), e.tri_first + v.n_first[k], v.n_count[k] | HIPRZ_NODE_LEAF);
+    }
+    e.slot_parent[k] = v.n_parent[k] == RZ_END ? RZ_END : e.region + v.n_parent[k];
+}
+
 // Host proof over the downloaded tables of one region (what derive_tables proves for host-built trees): under every octant the walk
 // that enters every box visits each of the region's nodes exactly once and ends; every index stays inside the region; the leaves
 // tile the mesh's triangle range exactly.
@@ -547,6 +898,72 @@ T* carve(unsigned char*& cursor, size_t count) {
     return p;
 }
 
+constexpr size_t sah_workspace_bytes(size_t n) {
+    return 256u * 40u + n * 4u * (3u + 6u + 2u + 2u + 1u) + 2u * n * 4u * (6u + 6u + 2u) + (n / kSahSmall + 2u) * (3u * kSahBins * 7u * 4u + 8u) + n * 16u * 9u;
+}
+// one mesh by the binned surface-area build; the stream is synchronised once per level of the top phase (the host sizes the next level)
+int build_mesh_sah(hiprz_ctx* c, DeviceMesh& m, float4* blob_tris, float4* blob_attrs, size_t n_cap) {
+    hipStream_t st = c->stream;
+    unsigned char* cursor = c->build_temp.ptr;
+    const size_t n = n_cap, nodes = 2u * n_cap, slots = n_cap / kSahSmall + 2u;
+    SahViews v{};
+    v.tris = blob_tris + 3 * size_t(m.tri_first), v.attrs = blob_attrs + 6 * size_t(m.tri_first), v.n = m.n_tris;
+    v.cen = carve<float>(cursor, 3 * n), v.tbox = carve<float>(cursor, 6 * n);
+    v.idx[0] = carve<uint32_t>(cursor, n), v.idx[1] = carve<uint32_t>(cursor, n);
+    v.tri_node[0] = carve<uint32_t>(cursor, n), v.tri_node[1] = carve<uint32_t>(cursor, n);
+    v.n_first = carve<uint32_t>(cursor, nodes), v.n_count = carve<uint32_t>(cursor, nodes), v.n_parent = carve<uint32_t>(cursor, nodes);
+    v.n_info = carve<uint32_t>(cursor, nodes), v.n_child = carve<uint32_t>(cursor, nodes), v.n_hist = carve<uint32_t>(cursor, nodes);
+    v.n_box = carve<float>(cursor, 6 * nodes), v.cursors = carve<uint32_t>(cursor, 2 * nodes);
+    v.hist = carve<uint32_t>(cursor, slots * 3u * kSahBins * 7u);
+    v.active[0] = carve<uint32_t>(cursor, slots), v.active[1] = carve<uint32_t>(cursor, slots);
+    v.small_roots = carve<uint32_t>(cursor, n);
+    v.counters = carve<uint32_t>(cursor, 8);
+    float4* tris_tmp = carve<float4>(cursor, 3 * n);
+    float4* attrs_tmp = carve<float4>(cursor, 6 * n);
+    const uint32_t blocks = (m.n_tris + 255u) / 256u;
+    hipLaunchKernelGGL(rz_sah_prepare_kernel, dim3(blocks), dim3(256), 0, st, v, make_float3(m.bb_min[0], m.bb_min[1], m.bb_min[2]),
+                       make_float3(m.bb_max[0], m.bb_max[1], m.bb_max[2]));
+    uint32_t cur = 0u, list = 0u, n_active = m.n_tris > kSahSmall ? 1u : 0u;
+    for (uint32_t level = 0; n_active != 0u; ++level) {
+        if (level > 256u) return fail(c, HIPRZ_ERR_DEVICE, "device surface-area build does not end");
+        hipLaunchKernelGGL(rz_sah_clear_kernel, dim3((n_active * 3u * kSahBins * 7u + 255u) / 256u), dim3(256), 0, st, v.hist, n_active);
+        hipLaunchKernelGGL(rz_sah_bin_kernel, dim3(blocks), dim3(256), 0, st, v, cur);
+        hipLaunchKernelGGL(rz_sah_split_kernel, dim3((n_active + 63u) / 64u), dim3(64), 0, st, v, list, n_active);
+        hipLaunchKernelGGL(rz_sah_partition_kernel, dim3(blocks), dim3(256), 0, st, v, cur);
+        RZ_HIP(c, hipMemcpyAsync(&n_active, v.counters + 1, 4, hipMemcpyDeviceToHost, st));
+        RZ_HIP(c, hipMemsetAsync(v.counters + 1, 0, 4, st));
+        RZ_HIP(c, hipStreamSynchronize(st));
+        if (n_active > slots) return fail(c, HIPRZ_ERR_DEVICE, "device surface-area build: more large nodes than triangles allow");
+        cur ^= 1u, list ^= 1u;
+    }
+    uint32_t n_roots = 0u;
+    RZ_HIP(c, hipMemcpyAsync(&n_roots, v.counters + 2, 4, hipMemcpyDeviceToHost, st));
+    RZ_HIP(c, hipStreamSynchronize(st));
+    if (n_roots > m.n_tris) return fail(c, HIPRZ_ERR_DEVICE, "device surface-area build: more subtrees than triangles");
+    if (n_roots) hipLaunchKernelGGL(rz_sah_small_kernel, dim3((n_roots + 63u) / 64u), dim3(64), 0, st, v, cur, n_roots);
+    EmitViews e{reinterpret_cast<float4*>(c->dev_nodes.ptr), c->slot_parent.ptr + m.region, m.region, m.tri_first};
+    const uint32_t max_slots = 2u * m.n_tris - 1u;
+    hipLaunchKernelGGL(rz_sah_emit_kernel, dim3((max_slots + 255u) / 256u), dim3(256), 0, st, v, e);
+    BuildViews b{};
+    b.tris = v.tris, b.attrs = v.attrs, b.n = m.n_tris, b.perm = v.idx[cur];
+    hipLaunchKernelGGL(rz_build_permute_kernel, dim3(blocks), dim3(256), 0, st, b, tris_tmp, attrs_tmp);
+    RZ_HIP(c, hipMemcpyAsync(const_cast<float4*>(v.tris), tris_tmp, size_t(m.n_tris) * 48u, hipMemcpyDeviceToDevice, st));
+    RZ_HIP(c, hipMemcpyAsync(const_cast<float4*>(v.attrs), attrs_tmp, size_t(m.n_tris) * 96u, hipMemcpyDeviceToDevice, st));
+    uint32_t n_nodes = 0u;
+    RZ_HIP(c, hipMemcpyAsync(&n_nodes, v.counters, 4, hipMemcpyDeviceToHost, st));
+    RZ_HIP(c, hipStreamSynchronize(st));
+    if (n_nodes == 0u || n_nodes > max_slots || !(n_nodes & 1u)) return fail(c, HIPRZ_ERR_DEVICE, "device surface-area build: node count out of range");
+    m.n_slots = n_nodes;
+    // exact boxes bottom-up over the emitted topology, then the skip links and the 64-byte walk records
+    RZ_HIP(c, c->refit_visit.resize(m.n_slots));
+    RZ_HIP(c, hipMemsetAsync(c->refit_visit.ptr, 0, size_t(m.n_slots) * 4u, st));
+    hipLaunchKernelGGL(rz_refit_kernel, dim3((m.n_slots + 255u) / 256u), dim3(256), 0, st, e, m.n_slots, blob_tris, blob_attrs, c->refit_visit.ptr, c->nodes64.ptr);
+    hipLaunchKernelGGL(rz_build_links_kernel, dim3((m.n_slots * 8u + 255u) / 256u), dim3(256), 0, st, e, v.counters + 3, c->nodes64.ptr, c->node_skip.ptr);
+    RZ_HIP(c, hipStreamSynchronize(st));
+    RZ_HIP(c, hipGetLastError());
+    return HIPRZ_OK;
+}
+
 }  // namespace
 
 // Capacity of the node arrays of a scene whose mesh trees are built on the device: the uploaded prefix + per mesh a region of 2n - 1
@@ -577,13 +994,25 @@ int device_build_mesh_trees(hiprz_ctx* c, std::vector<DeviceMesh>& meshes, const
     if (n_max <= kLeafMax) return HIPRZ_OK;
     // one workspace, carved; every array padded to 256 bytes
     const size_t n = n_max;
-    const size_t bytes = 256u * 24u + n * 4u * 12u + n * 4u * 6u * 2u + n * 16u * 9u + (2u * n) * 4u;
+    const size_t bytes = c->device_sah ? sah_workspace_bytes(n) : 256u * 24u + n * 4u * 12u + n * 4u * 6u * 2u + n * 16u * 9u + (2u * n) * 4u;
     RZ_HIP(c, c->build_temp.resize(bytes));
     RZ_HIP(c, c->slot_parent.resize(c->node_capacity));
     const int src = sort_temp_resize(c, c->build_sort, n);
     if (src != HIPRZ_OK) return src;
     for (auto& m : meshes) {
         if (m.region == RZ_END) continue;
+        if (c->device_sah) {
+            const int rc = build_mesh_sah(c, m, blob_tris, blob_attrs, n);
+            if (rc != HIPRZ_OK) return rc;
+            if (validate) {
+                std::vector<uint32_t> rec(16 * size_t(m.n_slots));
+                RZ_HIP(c, hipMemcpy(rec.data(), c->nodes64.ptr + 16 * size_t(m.region), rec.size() * 4u, hipMemcpyDeviceToHost));
+                std::string why;
+                if (!validate_region(rec, m.region, m.n_slots, m.tri_first, m.n_tris, kSahLeaf, why))
+                    return fail(c, HIPRZ_ERR_DEVICE, "device-built mesh tree refused (" + why + ")");
+            }
+            continue;
+        }
         unsigned char* cursor = c->build_temp.ptr;
         BuildViews b{};
         b.tris = blob_tris + 3 * size_t(m.tri_first), b.attrs = blob_attrs + 6 * size_t(m.tri_first), b.n = m.n_tris;

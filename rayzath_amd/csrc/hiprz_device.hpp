@@ -982,7 +982,9 @@ RZ_DEV void fetch_node(const DScene& s, const TopCache& top, uint32_t n, float4&
         n0 = s.nodes[2 * n], n1 = s.nodes[2 * n + 1], link = s.node_skip[n];
     }
 }
-template <bool COUNT, bool RCP>
+// TIES: the trees may be in another order than the reference's (rebuilt or device-built): among equally distant triangles of a mesh the
+// one the reference meets first wins (tri_hit_ordered on the triangles' reference positions), as in the cooperative walks.
+template <bool COUNT, bool RCP, bool TIES = false>
 RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit& hit, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
     WalkRay g;
@@ -1015,6 +1017,7 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                 WalkRay lr;
                 float len = to_local<RCP>(x, g, lr, scene_fast);
                 bool found = false;
+                uint32_t held_refpos = 0u;
                 uint32_t m = x.blas_root;
                 // closestIntersection(const Mesh&, ...): cpu_engine_kernel.cpp:331-352, as a "while-while" walk in bounded
                 // rounds: lanes without a leaf step through nodes until they HOLD one (at most walk_k steps per round), then the
@@ -1052,12 +1055,14 @@ RZ_DEV int closest_hit_skip(const DScene& s, const TopCache& top, Ray& ray, Hit&
                         float t, b1, b2, det;
                         RZ_PHASE(4);
                         RZ_COUNT(tri_tests);
-                        if (tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
+                        const uint32_t refpos = __float_as_uint(c.w);
+                        if (TIES ? tri_hit_ordered(xyz(a), xyz(b), xyz(c), lr, found && refpos < held_refpos, t, b1, b2, det)
+                                 : tri_hit(xyz(a), xyz(b), xyz(c), lr, t, b1, b2, det)) {
                             lr.far_ = t;
                             hit.triangle = tj;
                             hit.external = det > 0.0f;
                             hit.bx = b1, hit.by = b2;
-                            found = true;
+                            found = true, held_refpos = refpos;
                         }
                     }
                 }

@@ -141,7 +141,8 @@ class Context:
 
     def set_tree(self, tree):
         """0 = the uploaded (reference) mesh trees, 1 = rebuilt with a binned SAH at the next upload_scene (same frames, fewer tests),
-        2 = all trees built on the device at upload (same frames; update_triangles / update_instances afterwards)."""
+        2 = all trees built on the device at upload (same frames; update_triangles / update_instances afterwards), 3 = as 2 with the
+        device's binned surface-area builder for the mesh trees."""
         self._check(self.lib.hiprz_set_tree(self._ctx, tree))
 
     def update_triangles(self, first, tris, attrs):

@@ -1,4 +1,4 @@
-"""Trees built, refitted and rebuilt ON THE DEVICE (hiprz_set_tree(HIPRZ_TREE_DEVICE), rayzath_amd/csrc/hiprz_build.hip; SURVEY.md §8 f4 —
+"""Trees built, refitted and rebuilt ON THE DEVICE (hiprz_set_tree(HIPRZ_TREE_DEVICE / HIPRZ_TREE_DEVICE_SAH), rayzath_amd/csrc/hiprz_build.hip; SURVEY.md §8 f4 —
 the reference rebuilds on the host at every change: bvh_tree_node.hpp:117-215, component_container.hpp:259-363):
 
   * frames with device-built trees == frames with the reference trees == frames with the host SAH trees, bit for bit, on a deep textured
@@ -18,7 +18,7 @@ from rayzath_amd.scene import FlatScene, Instance, Material, camera_struct, flat
 from test_trees_gpu import _ties_world
 
 pytestmark = pytest.mark.gpu
-DEVICE = 2
+DEVICE, DEVICE_SAH = 2, 3   # HIPRZ_TREE_DEVICE (Morton order), HIPRZ_TREE_DEVICE_SAH (binned surface-area build)
 
 
 def _render(flat, cam, cfg, tree, passes=(1, 5, 4)):
@@ -46,13 +46,14 @@ def _worlds(name):
     }[name]
 
 
+@pytest.mark.parametrize("device", [DEVICE, DEVICE_SAH])
 @pytest.mark.parametrize("name", ["textured", "living room", "shading inputs", "exact ties"])
-def test_device_built_trees_give_the_same_frames_and_pass_validation(built, name):
+def test_device_built_trees_give_the_same_frames_and_pass_validation(built, name, device):
     build, samples = _worlds(name)
     world = build()
     flat, cam = flatten(world), camera_struct(world.camera)
     cfg = RenderConfig(LightSampling(*samples), Tracing(6, 4)).struct()
-    ref, sah, dev = (_render(flat, cam, cfg, t) for t in (0, 1, DEVICE))
+    ref, sah, dev = (_render(flat, cam, cfg, t) for t in (0, 1, device))
     _same_frames(ref, dev)
     _same_frames(sah, dev)
     for xy in [(10, 10), (100, 60), (60, 70)]:
@@ -113,7 +114,8 @@ def test_device_built_world_tree_is_the_host_builders(built, n_instances):
     assert np.array_equal(order, flat.tlas_order)
 
 
-def test_refit_and_world_rebuild_equal_a_fresh_upload(built):
+@pytest.mark.parametrize("device", [DEVICE, DEVICE_SAH])
+def test_refit_and_world_rebuild_equal_a_fresh_upload(built, device):
     """A mesh is deformed and an instance moved: hiprz_update_triangles + hiprz_update_instances on the device against a fresh upload of the
     changed world (host trees)."""
     def build(deformed):
@@ -128,7 +130,7 @@ def test_refit_and_world_rebuild_equal_a_fresh_upload(built):
     before, after = build(False), build(True)
     flat0, flat1, cam = flatten(before), flatten(after), camera_struct(before.camera)
     cfg = RenderConfig(tracing=Tracing(6, 4)).struct()
-    dev = _render(flat0, cam, cfg, DEVICE)
+    dev = _render(flat0, cam, cfg, device)
     # the changed triangles in the order they were uploaded in: a mesh's triangles are identified by their index before leaf reordering
     sphere = next(k for k, i in enumerate(before.instances) if i.name == "bugatti stand-in")
     def mesh_range(flat):
@@ -160,13 +162,14 @@ def test_refit_and_world_rebuild_equal_a_fresh_upload(built):
     assert not np.array_equal(fresh.read_depth(), _render(flat0, cam, cfg, 0).read_depth())   # the change is visible
 
 
-def test_config_d_built_on_the_device(built):
+@pytest.mark.parametrize("device", [DEVICE, DEVICE_SAH])
+def test_config_d_built_on_the_device(built, device):
     """BASELINE config D (301 400 triangles): tree built on the device, the frame of the reference trees; build and refit times printed."""
     preset = scenes.CONFIGS["D"]
     world = preset["build"]()
     flat, cam = flatten(world), camera_struct(world.camera)
     cfg = RenderConfig(tracing=Tracing(preset["max_depth"], 4)).struct()
-    ref, dev = _render(flat, cam, cfg, 0, passes=(1, 2)), _render(flat, cam, cfg, DEVICE, passes=(1, 2))
+    ref, dev = _render(flat, cam, cfg, 0, passes=(1, 2)), _render(flat, cam, cfg, device, passes=(1, 2))
     _same_frames(ref, dev)
     dev.update_triangles(0, flat.tris, flat.tri_attrs)            # a refit of every triangle (to the same place): the frame does not change
     dev.render(1), dev.render(2)
