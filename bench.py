@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--walk-order", type=int, default=-1, help="mesh child order of the skip-link walk: 0 reference order, 1 front to back (-1: library default)")
     ap.add_argument("--streams", type=int, default=-1, help="streams per GPU of the packaging `value` is measured on: every rank's tiles interleaved over this many contexts-with-a-stream on its GPU sharing one scene copy (-1 = the Engine hosts' default, rayzath_amd.engine.default_streams: 2 for scenes without lights, else 1); the single-stream figure is always measured too (`single_stream`, `roofline`)")
     ap.add_argument("--mode", type=int, default=0, help="hiprz_set_mode flags: 0 = the CPU kernel (the parity-checked default), 63 = every behaviour of the reference's CUDA engine")
-    ap.add_argument("--tree", type=int, default=0, help="0 the scene's (reference) mesh trees, 1 rebuilt with a binned SAH, 2 / 3 built on the device in Morton order / with a binned SAH (hiprz_set_tree; same frames; not the default)")
+    ap.add_argument("--tree", type=int, default=4, help="hiprz_set_tree: 4 the Engine hosts' default (the scene's own trees when it is staged in LDS, else built on the device with a binned SAH), 0 the scene's (reference) mesh trees, 1 rebuilt on the host with a binned SAH, 2 / 3 built on the device in Morton order / with a binned SAH; frames are the same under all of them")
     ap.add_argument("--no-xcd-swizzle", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify-gather", action="store_true", help="check the gathered frame against an unsharded render (N > 1)")
@@ -370,7 +370,8 @@ def main():
                        "triangles": int(len(flat.tris)), "instances": int(len(flat.instances)),
                        "sharding": f"interleaved 32x8 tiles over {world} GPU(s), gather to rank 0 per step" if world > 1 else "single GPU",
                        "traversal": {1: "lds-stack", 2: "workgroup-binned", 3: "skip-links"}[ctx.traversal_mode()],
-                       "mesh_trees": "binned SAH, rebuilt at upload" if args.tree else "reference builder (scene snapshot)",
+                       "mesh_trees": ["reference builder (scene snapshot)", "binned SAH, rebuilt on the host at upload", "built on the device at upload (Morton order)",
+                                      "built on the device at upload (binned SAH)"][ctx.tree()] + (" — hiprz_set_tree(HIPRZ_TREE_AUTO), the Engine hosts' default" if args.tree == 4 else ""),
                        "integrator": "CPU kernel (parity-checked)" if not (args.mode & 31) else f"CUDA-compat flags {args.mode} (hiprz_set_mode)",
                        "pipeline": {0: "fused (one kernel per pass)", 1: "trace+shade (two kernels per pass)", 2: "resident (one kernel per step)"}[pipeline]},
             "timing": {"protocol": f"{len(samples)} repeats of exactly {args.steps} steps ({args.steps * RPP} passes) between barrier + synchronize fences (repeated until >= {args.min_seconds:g} s of timed wall); value = median repeat",

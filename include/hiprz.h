@@ -357,7 +357,13 @@ int hiprz_set_temporal_blend(hiprz_ctx* ctx, float blend);
  * of Morton order: a few more milliseconds of build for walks as short as the host-built surface-area trees'.  Same frames, same
  * hiprz_update_triangles / hiprz_update_instances afterwards. */
 #define HIPRZ_TREE_DEVICE_SAH 3u
+/* HIPRZ_TREE_AUTO: per uploaded scene — HIPRZ_TREE_REFERENCE when the scene's records are small enough to be staged in LDS (the resident
+ * kernels walk the snapshot's trees there: BASELINE config B), HIPRZ_TREE_DEVICE_SAH otherwise (configs C, D, E: 3 - 9 % more rays per
+ * second, a device build of 1 - 4 ms).  What the Engine hosts and bench.py set; a bare context keeps HIPRZ_TREE_REFERENCE, the anchor of
+ * the work counters. */
+#define HIPRZ_TREE_AUTO 4u
 int hiprz_set_tree(hiprz_ctx* ctx, uint32_t tree);
+int hiprz_tree(hiprz_ctx* ctx, uint32_t* tree_out); /* the trees of the uploaded scene: HIPRZ_TREE_REFERENCE .. HIPRZ_TREE_DEVICE_SAH */
 /* Scenes uploaded under HIPRZ_TREE_DEVICE only.  New records for the triangles [first, first + n) of the uploaded snapshot's order
  * (vertices moved, normals / texture coordinates / face normals as the caller computed them; materials and source indices are taken
  * from the new records): the device copies are rewritten and the boxes of the mesh trees that hold them are fitted again, bottom-up,

@@ -293,10 +293,12 @@ Engine::Engine(int device, int streams) : m_device(device) {
         m_streams_pending = streams == 0;
     }
     if (rc != HIPRZ_OK) throw Exception(rc, std::string("HIPGPU backend unavailable: ") + hiprz_last_error(nullptr));
+    check(hiprz_set_tree(m_ctx, m_tree));
 }
 Engine::Engine(const std::vector<int>& devices) {
     const int rc = hiprz_create_multi(&m_ctx, devices.data(), int(devices.size()));
     if (rc != HIPRZ_OK) throw Exception(rc, std::string("HIPGPU backend unavailable: ") + hiprz_last_error(nullptr));
+    check(hiprz_set_tree(m_ctx, m_tree));
 }
 Engine::~Engine() { hiprz_destroy(m_ctx); }
 

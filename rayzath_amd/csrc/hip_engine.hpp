@@ -236,7 +236,7 @@ private:
     hiprz_ctx* m_ctx = nullptr;
     int m_device = 0;
     bool m_streams_pending = false;  // the context is still the single one of the constructor: the first world decides
-    uint32_t m_mode = 0, m_tree = 0;  // what mode() / tree() set, for the context that replaces it
+    uint32_t m_mode = 0, m_tree = HIPRZ_TREE_AUTO;  // what mode() / tree() set (the hosts' default trees: per scene), for the context that replaces it
     std::mutex m_mutex;  // renderWorld is serialised (cpu_engine_core.cpp:15)
     bool m_pending_readback = false;
     std::unique_ptr<Exception> m_deferred;

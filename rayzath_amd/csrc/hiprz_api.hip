@@ -210,7 +210,7 @@ namespace {
 void adopt_scene(hiprz_ctx* p, const hiprz_ctx* head) {
     p->dscene = head->dscene, p->have_scene = head->have_scene, p->stack_entries = head->stack_entries, p->lds_scene = head->lds_scene;
     p->n_nodes = head->n_nodes, p->flat_world = head->flat_world, p->n_textures = head->n_textures, p->scene_tree = head->scene_tree;
-    p->tree_mode = head->tree_mode, p->device_sah = head->device_sah, p->n_tris = head->n_tris, p->n_tlas_order = head->n_tlas_order;
+    p->tree_mode = head->tree_mode, p->device_sah = head->device_sah, p->build_sah = head->build_sah, p->n_tris = head->n_tris, p->n_tlas_order = head->n_tlas_order;
     p->scene_shared = true;
     invalidate_graphs(p);
     p->reset_pending = true;
@@ -1247,12 +1247,21 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     std::vector<hiprz_tri> rebuilt_tris;
     std::vector<hiprz_tri_attr> rebuilt_attrs;
     std::vector<hiprz_instance> rebuilt_instances;
-    if (c->tree_mode != HIPRZ_TREE_REFERENCE && sc->n_tris != 0u) {
+    uint32_t tree = c->tree_mode;
+    c->build_sah = c->device_sah;
+    if (tree == HIPRZ_TREE_AUTO) {
+        // a scene whose records can be staged in LDS keeps the snapshot's trees (the resident kernels walk those); any other gets the
+        // device's surface-area trees.  (A lower bound of the hot blob: node records, triangles + shading records, instances.)
+        const size_t records = size_t(sc->n_nodes) * 32u + size_t(sc->n_tris) * 144u + size_t(sc->n_instances) * 112u;
+        tree = records > kLdsSceneLimit ? HIPRZ_TREE_DEVICE : HIPRZ_TREE_REFERENCE;
+        c->build_sah = true;
+    }
+    if (tree != HIPRZ_TREE_REFERENCE && sc->n_tris != 0u) {
         const uint32_t max_nodes = sc->n_nodes + 2u * sc->n_tris + sc->n_instances + 1u;
         rebuilt_nodes.resize(max_nodes);
         std::vector<uint32_t> order(sc->n_tris), roots(sc->n_instances ? sc->n_instances : 1u);
         uint32_t n_nodes = 0u, tlas_root = 0u;
-        if (hiprz_rebuild_mesh_trees(sc, c->tree_mode, rebuilt_nodes.data(), max_nodes, &n_nodes, order.data(), roots.data(), &tlas_root) != HIPRZ_OK)
+        if (hiprz_rebuild_mesh_trees(sc, tree, rebuilt_nodes.data(), max_nodes, &n_nodes, order.data(), roots.data(), &tlas_root) != HIPRZ_OK)
             return fail(c, HIPRZ_ERR_INVALID, "upload_scene: the mesh trees could not be rebuilt (leaves of a mesh must tile one range of triangles)");
         rebuilt_nodes.resize(n_nodes);
         rebuilt_tris.resize(sc->n_tris), rebuilt_attrs.resize(sc->n_tris);
@@ -1350,7 +1359,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
 
     // HIPRZ_TREE_DEVICE: the node arrays get room behind the uploaded prefix for the world tree (2 * instances + 1 slots) and for every
     // mesh tree (2 * triangles - 1 slots) the device is going to build; regions start at odd slots, their child pairs at even ones
-    const bool device_trees = own_trees && c->tree_mode == HIPRZ_TREE_DEVICE;
+    const bool device_trees = own_trees && tree == HIPRZ_TREE_DEVICE;
     std::vector<DeviceMesh> device_meshes;
     std::vector<uint32_t> instance_mesh(sc->n_instances, RZ_END);
     uint32_t node_capacity = uint32_t(dnodes.size()), world_region = 0u;
@@ -1444,7 +1453,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     // Stage the blob in LDS when three workgroups per CU (the kernel's register-limited residency)
     // still fit into the CU's 160 KiB together with their traversal stacks.
     c->lds_scene = size_t(d.hot_bytes) + size_t(c->stack_entries) * 1024u + BinnedLds::kFixedBytes <= kLdsSceneLimit;
-    c->scene_tree = own_trees ? c->tree_mode : HIPRZ_TREE_REFERENCE;
+    c->scene_tree = own_trees ? tree : HIPRZ_TREE_REFERENCE;
     if (own_trees) c->lds_scene = false;  // rebuilt trees are walked front to back on skip links only (ties by reference position)
     c->n_tris = sc->n_tris, c->n_tlas_order = sc->n_tlas_order;
     c->device_meshes.clear(), c->instance_mesh.clear();
@@ -1742,9 +1751,16 @@ int hiprz_set_temporal_blend(hiprz_ctx* c, float blend) {
 int hiprz_set_tree(hiprz_ctx* c, uint32_t tree) {
     if (!c) return HIPRZ_ERR_INVALID;
     RZ_FANOUT(c, hiprz_set_tree(p, tree));
-    if (tree > HIPRZ_TREE_DEVICE_SAH) return fail(c, HIPRZ_ERR_INVALID, "set_tree: HIPRZ_TREE_REFERENCE, HIPRZ_TREE_SAH, HIPRZ_TREE_DEVICE or HIPRZ_TREE_DEVICE_SAH");
+    if (tree > HIPRZ_TREE_AUTO) return fail(c, HIPRZ_ERR_INVALID, "set_tree: HIPRZ_TREE_REFERENCE, _SAH, _DEVICE, _DEVICE_SAH or _AUTO");
     c->tree_mode = tree == HIPRZ_TREE_DEVICE_SAH ? HIPRZ_TREE_DEVICE : tree;  // one kind of scene (device-built, refittable), two builders
     c->device_sah = tree == HIPRZ_TREE_DEVICE_SAH;
+    return HIPRZ_OK;
+}
+
+int hiprz_tree(hiprz_ctx* c, uint32_t* tree_out) {
+    if (!c || !tree_out) return HIPRZ_ERR_INVALID;
+    if (!c->have_scene) return fail(c, HIPRZ_ERR_STATE, "tree: no scene uploaded");
+    *tree_out = c->scene_tree == HIPRZ_TREE_DEVICE && c->build_sah ? HIPRZ_TREE_DEVICE_SAH : c->scene_tree;
     return HIPRZ_OK;
 }
 

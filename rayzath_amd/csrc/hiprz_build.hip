@@ -535,6 +535,8 @@ struct SahViews {
     uint32_t* counters;     // [0] nodes allocated, [1] large nodes of the next level, [2] small roots
     uint32_t* active[2];
     uint32_t* small_roots;
+    uint32_t leaf_max;      // kSahLeaf (experiments: HIPRZ_SAH_LEAF, 1..8)
+    float traversal;        // kSahTraversal (experiments: HIPRZ_SAH_COST)
 };
 RZ_DEV uint32_t ordered(float f) {
     const uint32_t b = __float_as_uint(f);
@@ -799,9 +801,9 @@ __global__ void __launch_bounds__(64) rz_sah_small_kernel(SahViews v, uint32_t c
                 }
             }
             const float node_area = box_area(box);
-            const float split_cost = best_axis >= 0 && node_area > 0.0f ? kSahTraversal + best_cost / node_area : 3.4e38f;
-            if (count <= kSahLeaf && float(count) <= split_cost) leaf = true;
-            if (!leaf && !(best_axis >= 0 && (count > kSahLeaf || split_cost < float(count)))) best_axis = -1;
+            const float split_cost = best_axis >= 0 && node_area > 0.0f ? v.traversal + best_cost / node_area : 3.4e38f;
+            if (count <= v.leaf_max && float(count) <= split_cost) leaf = true;
+            if (!leaf && !(best_axis >= 0 && (count > v.leaf_max || split_cost < float(count)))) best_axis = -1;
         }
         if (leaf) {
             v.n_info[node] = kSahLeafNode;
@@ -920,6 +922,9 @@ int build_mesh_sah(hiprz_ctx* c, DeviceMesh& m, float4* blob_tris, float4* blob_
     v.counters = carve<uint32_t>(cursor, 8);
     float4* tris_tmp = carve<float4>(cursor, 3 * n);
     float4* attrs_tmp = carve<float4>(cursor, 6 * n);
+    v.leaf_max = kSahLeaf, v.traversal = kSahTraversal;
+    if (const char* e = std::getenv("HIPRZ_SAH_LEAF")) v.leaf_max = std::min(kSahLeaf, std::max(1u, uint32_t(std::atoi(e))));
+    if (const char* e = std::getenv("HIPRZ_SAH_COST")) v.traversal = float(std::atof(e));
     const uint32_t blocks = (m.n_tris + 255u) / 256u;
     hipLaunchKernelGGL(rz_sah_prepare_kernel, dim3(blocks), dim3(256), 0, st, v, make_float3(m.bb_min[0], m.bb_min[1], m.bb_min[2]),
                        make_float3(m.bb_max[0], m.bb_max[1], m.bb_max[2]));
@@ -994,14 +999,14 @@ int device_build_mesh_trees(hiprz_ctx* c, std::vector<DeviceMesh>& meshes, const
     if (n_max <= kLeafMax) return HIPRZ_OK;
     // one workspace, carved; every array padded to 256 bytes
     const size_t n = n_max;
-    const size_t bytes = c->device_sah ? sah_workspace_bytes(n) : 256u * 24u + n * 4u * 12u + n * 4u * 6u * 2u + n * 16u * 9u + (2u * n) * 4u;
+    const size_t bytes = c->build_sah ? sah_workspace_bytes(n) : 256u * 24u + n * 4u * 12u + n * 4u * 6u * 2u + n * 16u * 9u + (2u * n) * 4u;
     RZ_HIP(c, c->build_temp.resize(bytes));
     RZ_HIP(c, c->slot_parent.resize(c->node_capacity));
     const int src = sort_temp_resize(c, c->build_sort, n);
     if (src != HIPRZ_OK) return src;
     for (auto& m : meshes) {
         if (m.region == RZ_END) continue;
-        if (c->device_sah) {
+        if (c->build_sah) {
             const int rc = build_mesh_sah(c, m, blob_tris, blob_attrs, n);
             if (rc != HIPRZ_OK) return rc;
             if (validate) {

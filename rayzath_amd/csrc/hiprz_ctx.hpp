@@ -213,6 +213,7 @@ struct hiprz_ctx : hiprz_frame_state {
     uint32_t tree_mode = 0;   // HIPRZ_TREE_* (hiprz_set_tree), applied by hiprz_upload_scene
     uint32_t scene_tree = 0;  // ... of the scene that is uploaded now
     bool device_sah = false;  // HIPRZ_TREE_DEVICE_SAH: the device's mesh trees by the binned surface-area build instead of Morton order
+    bool build_sah = false;   // ... of the scene that is uploaded now (HIPRZ_TREE_AUTO decides per scene)
     uint32_t mode_flags = 0;  // HIPRZ_COMPAT_* (hiprz_set_mode): an integrator flag routes every pass through rz_compat_pass_kernel
     uint32_t graph_captures = 0;  // how often a batch was captured + instantiated (hiprz_graph_captures)
     uint32_t n_textures = 0;  // of the uploaded scene

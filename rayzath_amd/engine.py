@@ -39,6 +39,9 @@ class RenderConfig:
 COMPAT_BEER_LAMBERT, COMPAT_SCATTERING, COMPAT_SHADOW_COLOR, COMPAT_TEXTURE_MULT, COMPAT_FILTERING, COMPAT_REPROJECTION = 1, 2, 4, 8, 16, 32  # hiprz_set_mode
 
 
+TREE_REFERENCE, TREE_SAH, TREE_DEVICE, TREE_DEVICE_SAH, TREE_AUTO = range(5)   # hiprz_set_tree (include/hiprz.h)
+
+
 def default_streams(n_lights):
     """How many contexts-with-a-stream the hosts put on ONE GPU (hiprz_create_multi with the device named that often, tiles interleaved):
     two when the scene has no lights — one half's sorts, pass bookkeeping and kernel tails run beside the other half's walks (measured on
@@ -139,10 +142,16 @@ class Context:
         """Camera::temporalBlend of the selected camera: the weight of the previous frame's history at a restart (COMPAT_REPROJECTION)."""
         self._check(self.lib.hiprz_set_temporal_blend(self._ctx, blend))
 
+    def tree(self):
+        """The trees of the uploaded scene (hiprz_tree): TREE_REFERENCE .. TREE_DEVICE_SAH."""
+        out = C.c_uint32(0)
+        self._check(self.lib.hiprz_tree(self._ctx, C.byref(out)))
+        return out.value
+
     def set_tree(self, tree):
         """0 = the uploaded (reference) mesh trees, 1 = rebuilt with a binned SAH at the next upload_scene (same frames, fewer tests),
         2 = all trees built on the device at upload (same frames; update_triangles / update_instances afterwards), 3 = as 2 with the
-        device's binned surface-area builder for the mesh trees."""
+        device's binned surface-area builder for the mesh trees, 4 (TREE_AUTO) = 0 for scenes staged in LDS, 3 for all others."""
         self._check(self.lib.hiprz_set_tree(self._ctx, tree))
 
     def update_triangles(self, first, tris, attrs):
@@ -321,6 +330,7 @@ class Engine:
         """`device`: a GPU id, or a list of ids (one context over several GPUs).  `streams` (single GPU only): how many contexts share
         the GPU, None = default_streams() of the first world rendered; asking for `engine.context` before that settles for one."""
         self._device, self._streams, self._context = device, streams, None
+        self._tree = TREE_AUTO   # the hosts' default: the snapshot's trees for scenes staged in LDS, the device's surface-area trees otherwise
         self.backend = HostBackend(_lib.load())
         self._world_key = None
         self._camera_key, self._camera_ids = {}, None
@@ -329,7 +339,14 @@ class Engine:
     def context(self):
         if self._context is None:
             self._context = Context(self._device)
+            self._context.set_tree(self._tree)
         return self._context
+
+    def set_tree(self, tree):
+        """Context.set_tree for the engine's context (default TREE_AUTO); takes effect at the next scene upload, which this forces."""
+        self._tree, self._world_key = tree, None
+        if self._context is not None:
+            self._context.set_tree(tree)
 
     def set_mode(self, compat_flags):
         """Context.set_mode for the engine's context (COMPAT_REPROJECTION works over several streams / devices too: the context assembles
@@ -342,6 +359,7 @@ class Engine:
         if self._context is None and not isinstance(self._device, (list, tuple)):
             k = self._streams or default_streams(len(world.spot_lights) + len(world.direct_lights))
             self._context = Context([self._device] * k) if k > 1 else Context(self._device)
+            self._context.set_tree(self._tree)
             if getattr(self, "_mode", 0):
                 self._context.set_mode(self._mode)
         ctx = self.context

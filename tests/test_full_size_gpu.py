@@ -168,6 +168,23 @@ def test_resident_equals_split_at_full_size(built, name):
     assert digest(a.read_rgba8()) == digest(b.read_rgba8())
 
 
+@pytest.mark.parametrize("name,chosen", [("B", 0), ("C", 3), ("D", 3), ("E", 3)])
+def test_the_hosts_default_trees_give_the_reference_trees_frames_at_full_size(built, name, chosen):
+    """hiprz_set_tree(HIPRZ_TREE_AUTO) — what rayzath_amd.engine.Engine, Hip::Engine and bench.py run — keeps the snapshot's trees for
+    the scene that is staged in LDS (B) and has the device build surface-area trees for the others; the frame is the one of the
+    reference trees, bit for bit (accumulator, depth, 8-bit image)."""
+    from rayzath_amd.engine import TREE_AUTO
+    a, b = context(name, tree=0), context(name, tree=TREE_AUTO)
+    assert a.tree() == 0 and b.tree() == chosen
+    for c in (a, b):
+        c.render(1), c.render(8)
+        c.tonemap()
+    assert digest(a.read_accum()) == digest(b.read_accum())
+    assert digest(a.read_depth()) == digest(b.read_depth())
+    assert digest(a.read_rgba8()) == digest(b.read_rgba8())
+    a.close(), b.close()
+
+
 @pytest.mark.parametrize("name", ["C", "E"])
 def test_ray_order_and_shadow_deferral_are_invisible_at_full_size(built, name, monkeypatch):
     out = []
