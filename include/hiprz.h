@@ -253,7 +253,7 @@ typedef struct hiprz_ctx hiprz_ctx;
 /* --- lifecycle (replaces Cuda::Engine ctor/dtor, RayZath/cuda_engine.cu:8-21) --- */
 int hiprz_create(hiprz_ctx** out, int device_id);
 /* One context over several GPUs of a node (replaces the device selection of Cuda::EngineCore, cuda_engine_core.cu:17, which is pinned
- * to device 0): device r of n renders the interleaved tiles t with t % n == r (hiprz_set_shard then splits the context's share once
+ * to device 0): device r of n renders shard r of n of the interleaved tiles (hiprz_set_shard, which then splits the context's share once
  * more), the scene is mirrored to every device, and hiprz_read_* / hiprz_pick / hiprz_ray_count return the whole frame — the peers'
  * tiles cross xGMI in peer-to-peer copies on the head's stream.  Global pixel ids and seeds are unchanged: the frame equals the
  * single-device frame bit for bit.  The same id may be listed more than once: several contexts-with-a-stream on one GPU, each rendering
@@ -290,8 +290,13 @@ int hiprz_set_config(hiprz_ctx* ctx, const hiprz_config* config);
 int hiprz_set_camera_count(hiprz_ctx* ctx, uint32_t n);
 int hiprz_camera_count(hiprz_ctx* ctx, uint32_t* out);
 int hiprz_select_camera(hiprz_ctx* ctx, uint32_t index);
-/* Own only the 32x8-pixel tiles t with t % world == rank (global pixel ids and seeds are
- * unchanged, so results are identical for any world size).  Default rank 0 of 1. */
+/* Own only shard `rank` of `world` of the frame's 32x8-pixel tiles: the tiles are numbered row by row, shard `rank` owns the numbers t with
+ * t % world == rank and keeps them in order (local tile lt = t / world; the shards' counts differ by at most one).  Within tile row r the
+ * numbers are rotated by a few columns so that column c goes to shard (c + offset(r)) % world, offset() running through a permutation of
+ * 0 .. world - 1 every `world` rows: a column of tiles, a row or a slanted line of the image is dealt to all shards in turn — a thin
+ * expensive feature (a lamp post, the edge of a wall) does not land on one or two of them, as it does with unrotated numbers whenever
+ * `world` divides the tiles per row (rayzath_amd/csrc/hiprz_shard.hpp; rayzath_amd/distributed.py mirrors it).  Global pixel ids and
+ * seeds are unchanged, so results are identical for any world size.  Default rank 0 of 1. */
 int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
 
 /* Tree-walk variant of the pass kernels.  -1 (default) = chosen per scene; 1 = nested loops with a per-lane stack in LDS;
@@ -437,7 +442,7 @@ int hiprz_ray_count(hiprz_ctx* ctx, uint64_t* out); /* Camera::rayCount, camera.
 int hiprz_pass_count(hiprz_ctx* ctx, uint32_t* out);
 
 /* --- multi-GPU hand-off: tile-major device buffers for an RCCL gather.
- * Layout: owned tile lt (global tile lt*world+rank), 256 pixels each (4 waves of 8x8).  A context over n devices / streams
+ * Layout: local tile lt of the shard (hiprz_set_shard), 256 pixels each (4 waves of 8x8).  A context over n devices / streams
  * (hiprz_create_multi) hands out n slices of hiprz_local_pixel_capacity / n pixels each: slice r = the tiles of sub-shard rank * n + r of
  * world * n.  The slices of all ranks laid end to end are the sub-shards 0 .. world * n - 1: hiprz_untile_gathered(world * n parts). --- */
 int hiprz_local_pixel_capacity(hiprz_ctx* ctx, size_t* out);          /* owned tiles * 256 (n slices of the job's largest sub-shard on a multi context) */

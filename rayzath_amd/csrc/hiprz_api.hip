@@ -50,8 +50,8 @@ __global__ void __launch_bounds__(256) rz_tonemap_image_kernel(const float4* ima
 template <typename T>
 __global__ void __launch_bounds__(256) rz_untile_kernel(const T* tiles, T* image, uint32_t width, uint32_t height,
                                                         uint32_t tiles_x, uint32_t rank, uint32_t world) {
-    const uint32_t tile = blockIdx.x * world + rank;
-    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    uint32_t tx, ty;
+    shard_tile(blockIdx.x, tiles_x, rank, world, tx, ty);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
     if (x < width && y < height) image[size_t(y) * width + x] = tiles[size_t(blockIdx.x) * 256u + threadIdx.x];
@@ -61,9 +61,10 @@ __global__ void __launch_bounds__(256) rz_untile_kernel(const T* tiles, T* image
 template <typename T>
 __global__ void __launch_bounds__(256) rz_untile_gathered_kernel(const T* tiles, size_t part_stride, T* image, uint32_t width, uint32_t height,
                                                                  uint32_t tiles_x, uint32_t n_tiles, uint32_t world, uint32_t rank0) {
-    const uint32_t part = blockIdx.y, tile = blockIdx.x * world + rank0 + part;
-    if (tile >= n_tiles) return;
-    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    const uint32_t part = blockIdx.y;
+    if (blockIdx.x * world + rank0 + part >= n_tiles) return;  // the higher shards own one tile less
+    uint32_t tx, ty;
+    shard_tile(blockIdx.x, tiles_x, rank0 + part, world, tx, ty);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
     if (x < width && y < height) image[size_t(y) * width + x] = tiles[part * part_stride + size_t(blockIdx.x) * 256u + threadIdx.x];
@@ -71,8 +72,8 @@ __global__ void __launch_bounds__(256) rz_untile_gathered_kernel(const T* tiles,
 __global__ void __launch_bounds__(256) rz_untile_state_kernel(const float4* st0, const float4* st1, const float2* st2, float* ray9,
                                                               uint32_t* md2, uint32_t width, uint32_t height, uint32_t tiles_x,
                                                               uint32_t rank, uint32_t world) {
-    const uint32_t tile = blockIdx.x * world + rank;
-    const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+    uint32_t tx, ty;
+    shard_tile(blockIdx.x, tiles_x, rank, world, tx, ty);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
     if (x >= width || y >= height) return;
@@ -338,7 +339,7 @@ int assemble_history(hiprz_ctx* c) {
         RZ_HIP(c, hipMemsetAsync(c->prev_accum.ptr, 0, n * sizeof(float4), c->stream));
         RZ_HIP(c, hipMemsetAsync(c->prev_depth.ptr, 0, n * sizeof(float), c->stream));
     }
-    const uint32_t n_parts = uint32_t(c->peers.size()) + 1u, n_tiles = c->tiles_x * c->tiles_y;
+    const uint32_t n_parts = uint32_t(c->peers.size()) + 1u;
     const size_t stride = size_t(c->n_local_tiles) * 256u;
     RZ_HIP(c, c->gather.resize(stride * n_parts * (sizeof(float4) + sizeof(float))));
     float4* parts_a = reinterpret_cast<float4*>(c->gather.ptr);
@@ -360,9 +361,9 @@ int assemble_history(hiprz_ctx* c) {
     }
     if (c->n_local_tiles) {
         hipLaunchKernelGGL((rz_untile_gathered_kernel<float4>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts_a, stride, c->prev_accum.ptr,
-                           c->camera.width, c->camera.height, c->tiles_x, n_tiles, c->world, c->rank);
+                           c->camera.width, c->camera.height, c->tiles_x, c->tiles_x * c->tiles_y, c->world, c->rank);
         hipLaunchKernelGGL((rz_untile_gathered_kernel<float>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts_d, stride, c->prev_depth.ptr,
-                           c->camera.width, c->camera.height, c->tiles_x, n_tiles, c->world, c->rank);
+                           c->camera.width, c->camera.height, c->tiles_x, c->tiles_x * c->tiles_y, c->world, c->rank);
     }
     c->history_ready = true;
     // every peer gets the same images; its stream waits for the copy before its first pass runs
@@ -398,12 +399,12 @@ int allocate_frame(hiprz_ctx* c) {
     const uint32_t W = c->camera.width, H = c->camera.height;
     c->tiles_x = (W + 31u) / 32u;
     c->tiles_y = (H + 7u) / 8u;
-    const uint32_t n_tiles = c->tiles_x * c->tiles_y;
-    c->n_local_tiles = c->rank < n_tiles ? (n_tiles - c->rank + c->world - 1u) / c->world : 0u;
+    c->n_local_tiles = shard_local_tiles(c->tiles_x, c->tiles_y, c->rank, c->world);
     // owned active pixels (ray counter of this shard)
     uint64_t owned = 0;
     for (uint32_t lt = 0; lt < c->n_local_tiles; ++lt) {
-        const uint32_t t = lt * c->world + c->rank, tx = t % c->tiles_x, ty = t / c->tiles_x;
+        uint32_t tx, ty;
+        shard_tile(lt, c->tiles_x, c->rank, c->world, tx, ty);  // (hiprz_shard.hpp)
         const uint32_t w = std::min(32u, W - tx * 32u), h = std::min(8u, H - ty * 8u);
         owned += uint64_t(w) * h;
     }
@@ -794,10 +795,9 @@ int read_untiled(hiprz_ctx* c, const T* tiles, T* dst, size_t bytes, const char*
             (void)hipSetDevice(c->device);
             RZ_HIP(c, hipStreamWaitEvent(c->stream, p->peer_done, 0));
         }
-        const uint32_t n_tiles = c->tiles_x * c->tiles_y;
         if (c->n_local_tiles)
             hipLaunchKernelGGL((rz_untile_gathered_kernel<T>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts, stride, image, c->camera.width,
-                               c->camera.height, c->tiles_x, n_tiles, c->world, c->rank);
+                               c->camera.height, c->tiles_x, c->tiles_x * c->tiles_y, c->world, c->rank);
     }
     RZ_HIP(c, hipMemcpyAsync(dst, image, bytes, hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));
@@ -1026,8 +1026,7 @@ void assign_setting(hiprz_ctx* c, T& field, const T& value) {
 // hiprz_untile_gathered with world * n parts of that capacity assembles the frame.
 namespace {
 size_t part_capacity(const hiprz_ctx* c) {  // pixels per slice: the largest sub-shard of the job (the lowest ranks own one tile more)
-    const uint32_t n_tiles = c->tiles_x * c->tiles_y, total = c->world;  // c->world is already user_world * parts on a multi-device head
-    return size_t((n_tiles + total - 1u) / total) * 256u;
+    return size_t(shard_local_tiles(c->tiles_x, c->tiles_y, 0u, c->world)) * 256u;  // c->world is already user_world * parts on a multi-device head
 }
 template <typename T, typename Tiles>
 int export_tiles(hiprz_ctx* c, void* dst_device, size_t bytes, const char* what, Tiles tiles_of) {
@@ -1983,8 +1982,7 @@ int hiprz_untile_rgba8(hiprz_ctx* c, const void* src_tiles, uint32_t rank, uint3
     if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "untile before camera upload");
     if (!src_tiles || !dst_image || world == 0 || rank >= world) return fail(c, HIPRZ_ERR_INVALID, "untile_rgba8: bad arguments");
     (void)hipSetDevice(c->device);
-    const uint32_t n_tiles = c->tiles_x * c->tiles_y;
-    const uint32_t n_local = rank < n_tiles ? (n_tiles - rank + world - 1u) / world : 0u;
+    const uint32_t n_local = shard_local_tiles(c->tiles_x, c->tiles_y, rank, world);
     if (n_local)
         hipLaunchKernelGGL((rz_untile_kernel<uint32_t>), dim3(n_local), dim3(256), 0, c->stream,
                            reinterpret_cast<const uint32_t*>(src_tiles), reinterpret_cast<uint32_t*>(dst_image), c->camera.width,
@@ -2000,7 +1998,7 @@ int hiprz_untile_gathered(hiprz_ctx* c, const void* src_parts, uint32_t world, s
         return fail(c, HIPRZ_ERR_INVALID, "untile_gathered: bad arguments");
     (void)hipSetDevice(c->device);
     const uint32_t n_tiles = c->tiles_x * c->tiles_y;
-    const uint32_t per_rank = (n_tiles + world - 1u) / world;
+    const uint32_t per_rank = shard_local_tiles(c->tiles_x, c->tiles_y, 0u, world);
     if (part_stride_bytes < size_t(per_rank) * 256u * element_bytes) return fail(c, HIPRZ_ERR_INVALID, "untile_gathered: part stride smaller than a shard");
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
     if (n_tiles) {
@@ -2020,8 +2018,7 @@ int hiprz_untile_accum(hiprz_ctx* c, const void* src_tiles, uint32_t rank, uint3
     if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "untile before camera upload");
     if (!src_tiles || !dst_image || world == 0 || rank >= world) return fail(c, HIPRZ_ERR_INVALID, "untile_accum: bad arguments");
     (void)hipSetDevice(c->device);
-    const uint32_t n_tiles = c->tiles_x * c->tiles_y;
-    const uint32_t n_local = rank < n_tiles ? (n_tiles - rank + world - 1u) / world : 0u;
+    const uint32_t n_local = shard_local_tiles(c->tiles_x, c->tiles_y, rank, world);
     if (n_local)
         hipLaunchKernelGGL((rz_untile_kernel<float4>), dim3(n_local), dim3(256), 0, c->stream,
                            reinterpret_cast<const float4*>(src_tiles), reinterpret_cast<float4*>(dst_image), c->camera.width,
@@ -2052,17 +2049,18 @@ int hiprz_ray_cast(hiprz_ctx* c, uint32_t x, uint32_t y, hiprz_raycast* out) {
     if (y >= c->camera.height) y = c->camera.height - 1;
     (void)hipSetDevice(c->device);
     // depth of the pixel: only the shard that owns it can answer
-    const uint32_t tile = (y / 8u) * c->tiles_x + (x / 32u);
+    uint32_t owner, lt;
+    shard_of_tile(x / 32u, y / 8u, c->tiles_x, c->world, owner, lt);
     *out = hiprz_raycast{-1, -1, -1, 0u};
-    if (tile % c->world != c->rank) {
+    if (owner != c->rank) {
         for (hiprz_ctx* p : c->peers)
-            if (tile % p->world == p->rank) {
+            if (p->world == c->world && owner == p->rank) {
                 const int rc = hiprz_ray_cast(p, x, y, out);
                 return rc == HIPRZ_OK ? rc : fail(c, rc, "device " + std::to_string(p->device) + ": " + p->error);
             }
         return HIPRZ_OK;
     }
-    const uint32_t lt = tile / c->world, in_tile = ((x % 32u) / 8u) * 64u + (y % 8u) * 8u + (x % 8u);
+    const uint32_t in_tile = ((x % 32u) / 8u) * 64u + (y % 8u) * 8u + (x % 8u);
     float depth = 0.0f;
     RZ_HIP(c, hipMemcpyAsync(&depth, c->depth.ptr + size_t(lt) * 256u + in_tile, sizeof(float), hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "hiprz.h"
+#include "hiprz_shard.hpp"
 
 namespace hiprz {
 
@@ -1993,11 +1994,12 @@ RZ_DEV uint32_t tonemap(col4 color, float aperture, float exposure_time) {
     return r | (g << 8) | (b << 16) | 0xFF000000u;
 }
 
-// thread -> pixel.  A block is one 32x8 tile (4 waves of 8x8 pixels); owned tile `lt` of
-// shard (rank, world) is global tile lt*world + rank.
+// thread -> pixel.  A block is one 32x8 tile (4 waves of 8x8 pixels); where owned tile `lt` of
+// shard (rank, world) lies in the frame: hiprz_shard.hpp.
 struct PixelId {
     uint32_t x, y, local;
     bool active;
+    bool tile_inside;  // the thread's workgroup has a tile (the swizzled grid is padded to a multiple of 8 workgroups)
 };
 RZ_DEV PixelId pixel_of_thread(const DFrame& f, const DCamera& c, uint32_t block, uint32_t tid) {
     // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one, MI355X_MICROARCH.md), each with its
@@ -2009,13 +2011,14 @@ RZ_DEV PixelId pixel_of_thread(const DFrame& f, const DCamera& c, uint32_t block
         const uint32_t per_xcd = (f.n_local_tiles + 7u) >> 3;
         lt = (block & 7u) * per_xcd + (block >> 3);
     }
-    const uint32_t tile = lt * f.world + f.rank;
-    const uint32_t tx = tile % f.tiles_x, ty = tile / f.tiles_x;
+    uint32_t tx, ty;
+    shard_tile(lt, f.tiles_x, f.rank, f.world, tx, ty);
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     PixelId p;
     p.x = tx * 32u + wave * 8u + (lane & 7u);
     p.y = ty * 8u + (lane >> 3);
     p.local = lt * 256u + tid;
+    p.tile_inside = lt < f.n_local_tiles;
     p.active = lt < f.n_local_tiles && p.x < c.width && p.y < c.height;
     return p;
 }
@@ -2023,13 +2026,14 @@ RZ_DEV PixelId pixel_of_thread(const DFrame& f, const DCamera& c, uint32_t block
 // PixelId of a local (tile-major) pixel index — the trace kernel's mapping when rays are walked in sorted order
 RZ_DEV PixelId pixel_of_local(const DFrame& f, const DCamera& c, uint32_t local) {
     const uint32_t lt = local >> 8, tid = local & 255u;
-    const uint32_t tile = lt * f.world + f.rank;
-    const uint32_t tx = tile % f.tiles_x, ty = tile / f.tiles_x;
+    uint32_t tx, ty;
+    shard_tile(lt, f.tiles_x, f.rank, f.world, tx, ty);
     const uint32_t wave = tid >> 6, lane = tid & 63u;
     PixelId p;
     p.x = tx * 32u + wave * 8u + (lane & 7u);
     p.y = ty * 8u + (lane >> 3);
     p.local = local;
+    p.tile_inside = lt < f.n_local_tiles;
     p.active = lt < f.n_local_tiles && p.x < c.width && p.y < c.height;
     return p;
 }

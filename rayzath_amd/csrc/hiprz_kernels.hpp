@@ -296,10 +296,11 @@ template <bool COUNT, int MODE, bool LDS_SCENE, int SHADING, int WAVES = RZ_MIN_
 __global__ void __launch_bounds__(256, WAVES) rz_batch_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f,
                                                                       uint32_t n_passes, uint32_t park_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
+    const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
+    if (!p.tile_inside) return;  // (the whole workgroup: the padding of the swizzled grid)
     DScene s = scene_in;
     unsigned char* workspace = rz_lds + stage_scene<LDS_SCENE>(s, rz_lds);
     uint32_t* lds_column = stack_column<MODE>(workspace);
-    const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
     Counters cnt;
     PathState ps;
     load_path<false>(f, cam, p, ps);
@@ -364,6 +365,7 @@ __global__ void __launch_bounds__(64, MINW) rz_wave_batch_kernel(const DScene s,
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
     const PixelId p = pixel_of_local(f, cam, slot);
+    if (!p.tile_inside) return;  // (the whole wave)
     Counters cnt;
     PathState ps;
     load_path<false>(f, cam, p, ps);

@@ -1,5 +1,6 @@
 """Multi-GPU frame assembly: one process per GPU, the framebuffer sharded by interleaved
-32x8-pixel tiles (tile t belongs to rank t % world; include/hiprz.h: hiprz_set_shard), the
+32x8-pixel tiles (numbered row by row, tile t to rank t % world, the rows rotated so that column c of row r goes to rank
+(c + shard_row_offset(r)) % world; include/hiprz.h: hiprz_set_shard), the
 scene replicated, and ONE collective per readback: a gather of the tile-major tone-mapped RGBA8
 tiles (or the RGBA32F accumulators) to rank 0 over RCCL (torch.distributed backend "nccl") —
 SURVEY.md §8e.  There is no collective on the per-pass data path: pixels are independent.
@@ -15,8 +16,29 @@ def tile_grid(width, height):
     return (width + TILE_W - 1) // TILE_W, (height + TILE_H - 1) // TILE_H
 
 
+_ROW_OFFSETS = {8: (0, 1, 3, 7, 5, 4, 2, 6), 4: (0, 1, 3, 2)}
+
+
+def shard_row_offset(row, world):
+    """rayzath_amd/csrc/hiprz_shard.hpp: shard_row_offset — what is added to a tile's column before `% world` in tile row `row`
+    (an integer or an array of them)."""
+    table = _ROW_OFFSETS.get(world)
+    return np.asarray(table)[np.asarray(row) % world] if table else np.asarray(row) % world
+
+
+def shard_row_shift(row, tiles_x, world):
+    """hiprz_shard.hpp: shard_row_shift — the columns by which tile row `row` is rotated."""
+    return ((np.asarray(row) % world) * (tiles_x % world) + world - shard_row_offset(row, world)) % world % tiles_x
+
+
 def owned_tile_count(rank, world, n_tiles):
     return (n_tiles - rank + world - 1) // world if rank < n_tiles else 0
+
+
+def tile_owner(tx, ty, tiles_x, world):
+    """The shard that owns tile (tx, ty) (integers or arrays): hiprz_shard.hpp, shard_of_tile."""
+    shift = shard_row_shift(ty, tiles_x, world)
+    return (np.asarray(ty) * tiles_x + (np.asarray(tx) - shift) % tiles_x) % world
 
 
 def tile_pixel_coords(width, height, rank, world):
@@ -28,7 +50,8 @@ def tile_pixel_coords(width, height, rank, world):
     lt = np.arange(n, dtype=np.int64)[:, None]
     tid = np.arange(TILE_PIXELS, dtype=np.int64)[None, :]
     tile = lt * world + rank
-    tx, ty = tile % tiles_x, tile // tiles_x
+    ty = tile // tiles_x
+    tx = (tile % tiles_x + shard_row_shift(ty, tiles_x, world)) % tiles_x
     wave, lane = tid >> 6, tid & 63
     x = tx * TILE_W + wave * 8 + (lane & 7)
     y = ty * TILE_H + (lane >> 3)

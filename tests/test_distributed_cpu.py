@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from rayzath_amd.distributed import TILE_PIXELS, owned_tile_count, tile_grid, tile_pixel_coords
+from rayzath_amd.distributed import TILE_PIXELS, owned_tile_count, tile_grid, tile_owner, tile_pixel_coords
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -28,10 +28,34 @@ def test_tiles_partition_the_frame(size, world):
         assert len(x) == n * TILE_PIXELS
         inside = x >= 0
         np.add.at(seen, (y[inside], x[inside]), 1)
+        assert (tile_owner(x[inside] // 32, y[inside] // 8, tiles_x, world) == rank).all()
         if rank:  # capacity never exceeds rank 0's (the gather pads to it)
             assert n <= owned_tile_count(0, world, tiles_x * tiles_y)
     assert total_tiles == tiles_x * tiles_y
     assert (seen == 1).all()  # every pixel owned by exactly one shard
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 8])
+@pytest.mark.parametrize("width", [1280, 1920, 2560, 3840])
+def test_a_column_a_row_or_a_diagonal_of_tiles_is_dealt_to_all_shards(world, width):
+    """What the row offsets are for (hiprz_shard.hpp): a thin feature of the image must not land on one or two shards.  With tile t going
+    to shard t % world a column of tiles fell on ONE shard whenever world divides the tiles per row (1280, 2560, 3840 pixels)."""
+    tiles_x, tiles_y = tile_grid(width, width * 9 // 16)
+    rows, columns = np.mgrid[0:tiles_y, 0:tiles_x]
+    owner = tile_owner(columns, rows, tiles_x, world)
+    most = lambda line: np.bincount(line, minlength=world).max()
+    for c in range(world, tiles_x):     # (the first columns of a row wrap around its end and follow the unrotated numbers)
+        assert most(owner[:, c]) <= -(-tiles_y // world)
+    for r in range(tiles_y):
+        assert most(owner[r, :]) <= -(-tiles_x // world)
+    if world in (2, 4, 8):
+        for dr, dc in [(1, 1), (1, -1), (1, 2), (1, -2), (2, 1), (2, -1), (1, 3), (1, -3), (3, 1), (3, -1), (1, 4), (1, -4)]:
+            for c0 in range(-tiles_x, 2 * tiles_x, 5):
+                k = np.arange(256)
+                rr, cc = k * dr, c0 + k * dc
+                inside = (rr < tiles_y) & (cc >= world) & (cc < tiles_x)
+                if inside.sum() >= 4 * world:   # at most two tiles of every `world` consecutive ones on the line
+                    assert np.bincount(owner[rr[inside], cc[inside]], minlength=world).max() <= 2 * -(-inside.sum() // world), (dr, dc, c0)
 
 
 def test_a_wave_is_an_8x8_pixel_square():
@@ -85,5 +109,4 @@ def test_gather_assembles_the_frame_over_gloo(tmp_path, world, size):
     yy, xx = np.mgrid[0:H, 0:W]
     assert np.array_equal(image[..., 0], xx) and np.array_equal(image[..., 1], yy)
     assert np.array_equal(image[..., 3], yy * W + xx)
-    tiles_x, _ = tile_grid(W, H)
-    assert np.array_equal(image[..., 2], ((yy // 8) * tiles_x + xx // 32) % world)  # owner = tile id mod world
+    assert np.array_equal(image[..., 2], tile_owner(xx // 32, yy // 8, tile_grid(W, H)[0], world))

@@ -19,7 +19,7 @@ ap.add_argument("--shards", default="1,2,4,8")
 ap.add_argument("--traversal", type=int, default=-1)
 ap.add_argument("--pipeline", type=int, default=-1)
 ap.add_argument("--streams", type=int, default=1, help="streams per shard: Context([0] * streams), tiles interleaved, one scene copy")
-ap.add_argument("--tree", type=int, default=0, help="0 the snapshot's mesh trees, 1 host SAH rebuild, 2 built on the device")
+ap.add_argument("--tree", type=int, default=0, help="hiprz_set_tree: 0 the snapshot's mesh trees, 1 host SAH rebuild, 2 / 3 built on the device (Morton order / SAH), 4 the hosts' default")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 for config in args.config.split(","):
