@@ -1255,13 +1255,19 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
         tree = records > kLdsSceneLimit ? HIPRZ_TREE_DEVICE : HIPRZ_TREE_REFERENCE;
         c->build_sah = true;
     }
+    std::vector<uint32_t> order, roots;
+    uint32_t n_nodes = 0u, tlas_root = 0u;
     if (tree != HIPRZ_TREE_REFERENCE && sc->n_tris != 0u) {
         const uint32_t max_nodes = sc->n_nodes + 2u * sc->n_tris + sc->n_instances + 1u;
         rebuilt_nodes.resize(max_nodes);
-        std::vector<uint32_t> order(sc->n_tris), roots(sc->n_instances ? sc->n_instances : 1u);
-        uint32_t n_nodes = 0u, tlas_root = 0u;
-        if (hiprz_rebuild_mesh_trees(sc, tree, rebuilt_nodes.data(), max_nodes, &n_nodes, order.data(), roots.data(), &tlas_root) != HIPRZ_OK)
-            return fail(c, HIPRZ_ERR_INVALID, "upload_scene: the mesh trees could not be rebuilt (leaves of a mesh must tile one range of triangles)");
+        order.resize(sc->n_tris), roots.resize(sc->n_instances ? sc->n_instances : 1u);
+        if (hiprz_rebuild_mesh_trees(sc, tree, rebuilt_nodes.data(), max_nodes, &n_nodes, order.data(), roots.data(), &tlas_root) != HIPRZ_OK) {
+            if (c->tree_mode != HIPRZ_TREE_AUTO)
+                return fail(c, HIPRZ_ERR_INVALID, "upload_scene: the mesh trees could not be rebuilt (leaves of a mesh must tile one range of triangles)");
+            tree = HIPRZ_TREE_REFERENCE;  // HIPRZ_TREE_AUTO promises an upload wherever the snapshot's own trees are valid
+        }
+    }
+    if (tree != HIPRZ_TREE_REFERENCE && sc->n_tris != 0u) {
         rebuilt_nodes.resize(n_nodes);
         rebuilt_tris.resize(sc->n_tris), rebuilt_attrs.resize(sc->n_tris);
         for (uint32_t i = 0; i < sc->n_tris; ++i) {

@@ -175,3 +175,50 @@ def test_config_d_built_on_the_device(built, device):
     dev.render(1), dev.render(2)
     _same_frames(ref, dev)
     print(dev.timings())
+
+
+def test_the_hosts_default_trees_fall_back_where_a_rebuild_is_impossible(built):
+    """A snapshot whose mesh trees cannot be rebuilt (here: two distinct trees over the SAME triangles — their leaves do not tile ranges
+    of their own) is a valid snapshot for the reference's walks.  hiprz_set_tree(1 / 2 / 3) refuse it; HIPRZ_TREE_AUTO, the hosts'
+    default, must upload it on its own trees and render the reference trees' frame."""
+    from rayzath_amd.engine import TREE_AUTO
+    from rayzath_amd._lib import HiprzError
+    world = scenes.textured_sphere_scene(200, 120, resolution=96, map_size=64)
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(tracing=Tracing(6, 4)).struct()
+    # a second copy of the biggest mesh tree's nodes, entered by a twin of its instance (moved aside)
+    roots = flat.instances["blas_root"]
+    def subtree(root):
+        out, stack = [], [int(root)]
+        while stack:
+            i = stack.pop()
+            out.append(i)
+            n = flat.nodes[i]
+            if not (n["meta"] & _abi.NODE_LEAF):
+                stack += [int(n["begin"]), int(n["begin"]) + 1]
+        return out
+    big = max(range(len(roots)), key=lambda k: len(subtree(roots[k])) if roots[k] < len(flat.nodes) else 0)
+    old = sorted(subtree(roots[big]))
+    where = {o: len(flat.nodes) + k for k, o in enumerate(old)}
+    # children stay adjacent: a pair (b, b + 1) is copied to (where[b], where[b] + 1) because `old` is sorted and pairs are adjacent
+    copy = flat.nodes[old].copy()
+    for k, o in enumerate(old):
+        if not (copy[k]["meta"] & _abi.NODE_LEAF):
+            assert where[int(copy[k]["begin"]) + 1] == where[int(copy[k]["begin"])] + 1
+            copy[k]["begin"] = where[int(copy[k]["begin"])]
+    twin = flat.instances[big:big + 1].copy()
+    twin["blas_root"] = where[int(roots[big])]
+    twin["position"][0] += np.float32(0.0)        # the same place: every hit is an exact tie between the two instances
+    mats = np.concatenate([flat.inst_materials, flat.inst_materials[int(twin["material_base"][0]):int(twin["material_base"][0]) + int(twin["material_count"][0])]])
+    twin["material_base"] = len(flat.inst_materials)
+    snap = FlatScene(nodes=np.concatenate([flat.nodes, copy]), tlas_root=flat.tlas_root, tlas_order=flat.tlas_order, tris=flat.tris, tri_attrs=flat.tri_attrs,
+                     instances=np.concatenate([flat.instances, twin]), inst_materials=mats, materials=flat.materials, textures=flat.textures,
+                     texels=flat.texels, spot_lights=flat.spot_lights, direct_lights=flat.direct_lights)
+    # (the twin is in no world-tree leaf: it is never entered, but its tree makes the triangles shared)
+    for tree in (1, DEVICE, DEVICE_SAH):
+        with pytest.raises(HiprzError):
+            _render(snap, cam, cfg, tree)
+    ref, auto = _render(snap, cam, cfg, 0), _render(snap, cam, cfg, TREE_AUTO)
+    assert auto.tree() == 0
+    _same_frames(ref, auto)
+    assert _render(flat, cam, cfg, TREE_AUTO).tree() == DEVICE_SAH   # ... while the plain world gets the device's trees

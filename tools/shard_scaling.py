@@ -19,6 +19,7 @@ ap.add_argument("--shards", default="1,2,4,8")
 ap.add_argument("--traversal", type=int, default=-1)
 ap.add_argument("--pipeline", type=int, default=-1)
 ap.add_argument("--streams", type=int, default=1, help="streams per shard: Context([0] * streams), tiles interleaved, one scene copy")
+ap.add_argument("--lds-scene", type=int, default=-1, help="hiprz_set_lds_scene: 0 never stage the scene in LDS (the cooperative walks from global memory), -1 per scene")
 ap.add_argument("--tree", type=int, default=0, help="hiprz_set_tree: 0 the snapshot's mesh trees, 1 host SAH rebuild, 2 / 3 built on the device (Morton order / SAH), 4 the hosts' default")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -35,6 +36,8 @@ for config in args.config.split(","):
             ctx.set_traversal_mode(args.traversal)
             if args.pipeline >= 0:
                 ctx.set_pipeline(args.pipeline)
+            if args.lds_scene >= 0:
+                ctx.set_lds_scene(args.lds_scene)
             ctx.set_shard(r, n)
             ctx.set_tree(args.tree)
             ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(cfg)
