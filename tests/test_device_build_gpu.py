@@ -222,3 +222,57 @@ def test_the_hosts_default_trees_fall_back_where_a_rebuild_is_impossible(built):
     assert auto.tree() == 0
     _same_frames(ref, auto)
     assert _render(flat, cam, cfg, TREE_AUTO).tree() == DEVICE_SAH   # ... while the plain world gets the device's trees
+
+
+def _awkward_world():
+    """Meshes chosen against the device builders: 5 ... 40 triangles (one small subtree, no top phase), 200 copies of ONE triangle (no
+    plane separates anything: the top phase halves runs), zero-area triangles among real ones, triangles along one line of centroids, a
+    mesh spanning six orders of magnitude, and a fan of slivers around one vertex."""
+    from rayzath_amd.scene import Mesh
+    rng = np.random.default_rng(5)
+    world = scenes.cornell_box(160, 100)
+    paint = [world.add(Material((200, 60, 40, 255), 0.0, 1.0)), world.add(Material((40, 160, 220, 255), 0.2, 0.4))]
+    def soup(n, spread=0.5):
+        v = rng.uniform(-spread, spread, (n, 3, 3)).astype(np.float32) * np.float32(0.35) + rng.uniform(-spread, spread, (n, 1, 3)).astype(np.float32)
+        return v.reshape(-1, 3), np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+    meshes = []
+    for n in (5, 8, 9, 33, 40):
+        meshes.append(Mesh(*soup(n), name=f"soup {n}"))
+    one = np.array([[-0.3, -0.2, 0.0], [0.3, -0.2, 0.1], [0.0, 0.3, -0.1]], np.float32)
+    meshes.append(Mesh(np.tile(one, (200, 1)), np.arange(600, dtype=np.uint32).reshape(-1, 3), tri_materials=(np.arange(200) % 2).astype(np.uint32), name="200 copies"))
+    v, t = soup(60)
+    v[t[::3, 2]] = v[t[::3, 1]]                                   # every third triangle has no area
+    meshes.append(Mesh(v, t, name="zero areas"))
+    line = np.linspace(-0.5, 0.5, 70, dtype=np.float32)
+    v = np.stack([np.stack([line, 0 * line, 0 * line], 1) + d for d in (np.float32([0, 0.1, 0]), np.float32([0.01, -0.1, 0.05]), np.float32([-0.01, -0.1, -0.05]))], 1).reshape(-1, 3)
+    meshes.append(Mesh(v, np.arange(210, dtype=np.uint32).reshape(-1, 3), name="centroids on a line"))
+    v, t = soup(50)
+    v[: 3 * 10] *= np.float32(1e-4)
+    v[3 * 40:] *= np.float32(30.0)
+    meshes.append(Mesh(v, t, name="six orders of magnitude"))
+    k = 96
+    ang = np.linspace(0, 2 * np.pi, k, endpoint=False, dtype=np.float32)
+    rim = np.stack([np.cos(ang), np.sin(ang), 0.05 * np.sin(5 * ang)], 1).astype(np.float32) * np.float32(0.5)
+    v = np.concatenate([np.zeros((1, 3), np.float32), rim])
+    meshes.append(Mesh(v, np.stack([np.zeros(k), 1 + np.arange(k), 1 + (np.arange(k) + 1) % k], 1).astype(np.uint32), name="fan"))
+    for i, m in enumerate(meshes):
+        m = world.add(m)
+        world.add(Instance(m, paint, position=(-0.9 + 0.45 * (i % 5), 0.45 + 0.6 * (i // 5), -0.3 + 0.15 * (i % 3)), rotation=(0.2 * i, 0.3, 0.1 * i),
+                           scale=(0.02, 0.02, 0.02) if m.name == "six orders of magnitude" else (0.6, 0.6, 0.6)))
+    return world
+
+
+@pytest.mark.parametrize("device", [DEVICE, DEVICE_SAH])
+def test_awkward_meshes_through_the_device_builders(built, device):
+    world = _awkward_world()
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(tracing=Tracing(6, 4)).struct()
+    ref, dev = _render(flat, cam, cfg, 0), _render(flat, cam, cfg, device)
+    assert dev.tree() == device
+    _same_frames(ref, dev)
+    nodes, root, order, roots, refpos = dev.download_trees(len(flat.instances), len(flat.tris), len(flat.tlas_order))
+    assert sorted(refpos.tolist()) == list(range(len(flat.tris)))
+    dev.update_triangles(0, flat.tris, flat.tri_attrs)            # a refit to the same place over these trees
+    for n in (1, 5, 4):
+        dev.render(n)
+    _same_frames(ref, dev)
