@@ -235,6 +235,48 @@ FlatScene flatten(const World& world) {
     return f;
 }
 
+namespace {
+hiprz_mesh_desc mesh_desc(const Mesh& m) {
+    hiprz_mesh_desc d{};
+    d.n_vertices = uint32_t(m.vertices.size() / 3), d.vertices = m.vertices.data();
+    d.n_texcrds = uint32_t(m.texcrds.size() / 2), d.texcrds = m.texcrds.data();
+    d.n_normals = uint32_t(m.normals.size() / 3), d.normals = m.normals.data();
+    d.n_triangles = uint32_t(m.tri_materials.size());
+    d.tri_vertices = m.tri_vertices.data(), d.tri_texcrds = m.tri_texcrds.data();
+    d.tri_normals = m.tri_normals.data(), d.tri_materials = m.tri_materials.data();
+    return d;
+}
+}  // namespace
+
+FlatScene flattenMotion(const World& world, const std::vector<uint32_t>& uploaded_sources) {
+    FlatScene f;
+    // the meshes in flatten()'s order; every mesh's triangles in the order they were uploaded in
+    std::map<const Mesh*, size_t> seen;
+    size_t cursor = 0;
+    for (const auto& inst : world.instances) {
+        if (!inst->mesh || seen.count(inst->mesh.get())) continue;
+        seen[inst->mesh.get()] = seen.size();
+        const hiprz_mesh_desc d = mesh_desc(*inst->mesh);
+        if (cursor + d.n_triangles > uploaded_sources.size()) return FlatScene{};
+        const size_t base = f.tris.size();
+        f.tris.resize(base + d.n_triangles), f.tri_attrs.resize(base + d.n_triangles);
+        if (d.n_triangles &&
+            hiprz_fill_triangles(&d, uploaded_sources.data() + cursor, d.n_triangles, f.tris.data() + base, f.tri_attrs.data() + base) != HIPRZ_OK)
+            return FlatScene{};
+        cursor += d.n_triangles;
+    }
+    if (cursor != uploaded_sources.size()) return FlatScene{};
+    for (const auto& inst : world.instances) {
+        hiprz_instance r{};
+        const Xform own = own_transform(inst->position, inst->rotation, inst->scale), grouped = in_group(*inst);
+        store(r, grouped);
+        if (inst->mesh) hiprz_instance_bounds(inst->mesh->vertices.data(), uint32_t(inst->mesh->vertices.size() / 3), &r);
+        if (world.group_transforms == World::GroupTransforms::Cpu) store(r, own);
+        f.instances.push_back(r);
+    }
+    return f;
+}
+
 FlatScene flattenShading(const World& world) {
     // the map indices must be those of the uploaded scene: textures are numbered in first-use order over world material, default
     // material and the world's materials — exactly what flatten() does, so the numbering is replayed without copying any texels
@@ -376,6 +418,21 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
                 }
     }
     // re-mirror what changed; any change restarts accumulation (cpu_engine_renderer.cpp:108-112)
+    bool moved_in_place = false;
+    if (world.isMoved() && !world.isModified() && m_last_world == &world && world.instances.size() == m_uploaded_instances) {
+        // an animation frame: where the device built the trees it refits them and rebuilds the world tree; no tree is built on the host
+        uint32_t tree = HIPRZ_TREE_REFERENCE;
+        if (hiprz_tree(m_ctx, &tree) == HIPRZ_OK && (tree == HIPRZ_TREE_DEVICE || tree == HIPRZ_TREE_DEVICE_SAH)) {
+            const FlatScene motion = flattenMotion(world, m_uploaded_sources);
+            if (motion.instances.size() == m_uploaded_instances && motion.tris.size() == m_uploaded_sources.size()) {
+                if (!motion.tris.empty()) check(hiprz_update_triangles(m_ctx, 0u, uint32_t(motion.tris.size()), motion.tris.data(), motion.tri_attrs.data()));
+                if (!motion.instances.empty()) check(hiprz_update_instances(m_ctx, motion.instances.data(), uint32_t(motion.instances.size())));
+                moved_in_place = true;
+            }
+        }
+    }
+    if (world.isMoved() && !moved_in_place) world.makeModified();  // no device trees (or another topology): an ordinary modification
+    world.makeUnmoved();
     if (world.isModified() || m_last_world != &world) {
         const FlatScene flat = flatten(world);
         const hiprz_scene view = flat.view();
@@ -383,6 +440,9 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
         world.makeUnmodified(), world.makeShadingUnmodified();
         m_last_world = &world;
         m_uploaded_maps = flat.maps;
+        m_uploaded_sources.resize(flat.tris.size());
+        for (size_t k = 0; k < flat.tris.size(); ++k) m_uploaded_sources[k] = flat.tris[k].source_index;
+        m_uploaded_instances = flat.instances.size();
     } else if (world.isShadingModified()) {  // materials / lights only: replaced in place, no tree is touched
         const FlatScene shading = flattenShading(world);
         // flattenShading numbers the maps in first-use order; those indices mean something only if they name the SAME map objects in
@@ -396,6 +456,9 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
             const hiprz_scene view = flat.view();
             check(hiprz_upload_scene(m_ctx, &view));
             m_uploaded_maps = flat.maps;
+            m_uploaded_sources.resize(flat.tris.size());
+            for (size_t k = 0; k < flat.tris.size(); ++k) m_uploaded_sources[k] = flat.tris[k].source_index;
+            m_uploaded_instances = flat.instances.size();
         }
         world.makeShadingUnmodified();
     }

@@ -164,9 +164,16 @@ struct World : public Updatable {  // world.hpp:64-76
     void makeShadingModified() { m_shading_modified = true; }
     bool isShadingModified() const { return m_shading_modified; }
     void makeShadingUnmodified() { m_shading_modified = false; }
+    // vertices of meshes and / or transformations of instances moved; the same meshes with the same triangles in the same instances
+    // (an animation frame).  Where the context holds device-built trees the engine then refits them on the device and rebuilds the
+    // world tree there (hiprz_update_triangles / hiprz_update_instances) instead of building every tree again on the host, as the
+    // reference does at any change (component_container.hpp:259-363); otherwise it is an ordinary modification.
+    void makeMoved() { m_moved = true; }
+    bool isMoved() const { return m_moved; }
+    void makeUnmoved() { m_moved = false; }
 
 private:
-    bool m_shading_modified = false;
+    bool m_shading_modified = false, m_moved = false;
 };
 
 struct LightSampling {  // engine_parts.hpp:76-94
@@ -200,6 +207,9 @@ struct FlatScene {
 };
 FlatScene flatten(const World& world);           // pure host
 FlatScene flattenShading(const World& world);    // materials + lights only (for hiprz_update_shading): pure host
+// triangles + instances only (for hiprz_update_triangles / hiprz_update_instances): the meshes' triangles in the order of an earlier
+// flatten() (`uploaded_sources` = its tris[k].source_index), no tree is built.  Empty when the world no longer matches that order.
+FlatScene flattenMotion(const World& world, const std::vector<uint32_t>& uploaded_sources);
 hiprz_camera cameraRecord(const Camera& camera); // pure host
 
 class Engine {
@@ -244,6 +254,8 @@ private:
     std::vector<const Camera*> m_camera_slots;  // camera k of the context mirrors this camera
     std::vector<hiprz_camera> m_camera_records; // ... as this record (a modified camera whose record is unchanged is not uploaded again)
     std::vector<const void*> m_uploaded_maps;   // the maps of the uploaded scene: hiprz_update_shading may only refer to these, by these indices
+    std::vector<uint32_t> m_uploaded_sources;   // source_index of every uploaded triangle, in upload order (World::makeMoved: the order new vertices go up in)
+    size_t m_uploaded_instances = 0;
 };
 
 }  // namespace RayZath::Hip

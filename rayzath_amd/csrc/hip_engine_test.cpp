@@ -2,6 +2,7 @@
 // backend; tests/test_cpp_host.py compares what it writes with the Python host side on the same scene.
 //   hip_engine_test flatten <out.bin>          pure host: dump the flattened snapshot
 //   hip_engine_test render  <out.bin> <calls>  GPU: renderWorld <calls> times, dump the camera outputs
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -101,6 +102,69 @@ int main(int argc, char** argv) {
             const bool eq2 = world.camera.image_buffer == fresh.camera.image_buffer;
             std::printf("swapped maps %s, colour change %s\n", eq ? "equal" : "DIFFERENT", eq2 ? "equal" : "DIFFERENT");
             return eq && eq2 ? 0 : 1;
+        } catch (const Exception& e) {
+            std::fprintf(stderr, "Hip::Exception %d: %s\n", e.code, e.what());
+            return 1;
+        }
+    }
+    if (mode == "moved") {  // World::makeMoved(): an animation frame goes through the device refit, not through a host-side tree build
+        try {
+            auto grid = [](int n) {  // a wavy sheet of 2 n^2 triangles
+                auto m = std::make_shared<Mesh>();
+                for (int j = 0; j <= n; ++j)
+                    for (int i = 0; i <= n; ++i) m->createVertex(float(i) / n - 0.5f, 0.05f * std::sin(9.0f * i / n) * std::cos(7.0f * j / n), float(j) / n - 0.5f);
+                for (int j = 0; j < n; ++j)
+                    for (int i = 0; i < n; ++i) {
+                        const uint32_t a = uint32_t(j * (n + 1) + i), b = a + 1, c = a + uint32_t(n + 1), d = c + 1;
+                        m->createTriangle({a, c, b}), m->createTriangle({b, c, d});
+                    }
+                return m;
+            };
+            auto scene = [&](World& w, bool moved) {
+                build(w, 96, 64);
+                auto sheet = grid(40);
+                w.meshes.push_back(sheet);
+                instance(w, sheet, w.materials[4], {0.1f, 0.9f, 0.3f}, {0.5f, 0.2f, 0.1f}, {1.6f, 1.6f, 1.6f});
+                if (moved) {
+                    for (size_t k = 0; k < sheet->vertices.size(); k += 3) sheet->vertices[k + 1] = 0.08f * std::cos(11.0f * sheet->vertices[k]) + 0.3f * sheet->vertices[k + 2];
+                    w.instances.back()->position = {-0.2f, 1.1f, 0.1f};
+                    w.instances[6]->rotation = {0.1f, 0.9f, 0.0f};
+                }
+            };
+            World world, fresh;
+            scene(world, false), scene(fresh, true);
+            RenderConfig cfg;
+            cfg.tracing.max_depth = 4, cfg.tracing.rpp = 3;
+            Engine engine(0, 1), reference(0, 1);
+            engine.tree(HIPRZ_TREE_DEVICE_SAH);  // (the hosts' default would keep the snapshot's trees for a scene this small)
+            engine.renderWorld(world, cfg);
+            const std::vector<uint8_t> before = world.camera.image_buffer;
+            auto& sheet = *world.meshes.back();
+            for (size_t k = 0; k < sheet.vertices.size(); k += 3) sheet.vertices[k + 1] = 0.08f * std::cos(11.0f * sheet.vertices[k]) + 0.3f * sheet.vertices[k + 2];
+            world.instances.back()->position = {-0.2f, 1.1f, 0.1f};
+            world.instances[6]->rotation = {0.1f, 0.9f, 0.0f};
+            world.makeMoved();
+            engine.renderWorld(world, cfg);
+            const bool refitted = engine.timingsString().find("refit mesh trees (device)") != std::string::npos;
+            reference.renderWorld(fresh, cfg);
+            const bool eq = world.camera.image_buffer == fresh.camera.image_buffer && world.camera.depth_buffer == fresh.camera.depth_buffer &&
+                            world.camera.ray_count == fresh.camera.ray_count;
+            // without device trees the same call is an ordinary modification
+            World plain;
+            scene(plain, false);
+            Engine host_trees(0, 1);
+            host_trees.tree(HIPRZ_TREE_REFERENCE);
+            host_trees.renderWorld(plain, cfg);
+            auto& sheet2 = *plain.meshes.back();
+            for (size_t k = 0; k < sheet2.vertices.size(); k += 3) sheet2.vertices[k + 1] = 0.08f * std::cos(11.0f * sheet2.vertices[k]) + 0.3f * sheet2.vertices[k + 2];
+            plain.instances.back()->position = {-0.2f, 1.1f, 0.1f};
+            plain.instances[6]->rotation = {0.1f, 0.9f, 0.0f};
+            plain.makeMoved();
+            host_trees.renderWorld(plain, cfg);
+            const bool eq2 = plain.camera.image_buffer == fresh.camera.image_buffer;
+            std::printf("moved frame %s, %s, changed %s, on host trees %s\n", eq ? "equal" : "DIFFERENT", refitted ? "refitted on the device" : "NOT REFITTED",
+                        before != world.camera.image_buffer ? "yes" : "NO", eq2 ? "equal" : "DIFFERENT");
+            return eq && refitted && eq2 && before != world.camera.image_buffer ? 0 : 1;
         } catch (const Exception& e) {
             std::fprintf(stderr, "Hip::Exception %d: %s\n", e.code, e.what());
             return 1;

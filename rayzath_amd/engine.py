@@ -12,7 +12,7 @@ import numpy as np
 
 from . import _abi, _lib
 from ._lib import HiprzError
-from .scene import HostBackend, camera_struct, flatten
+from .scene import HostBackend, camera_struct, flatten, flatten_motion
 
 
 class LightSampling:
@@ -365,6 +365,20 @@ class Engine:
         ctx = self.context
         # the backend re-mirrors what changed and restarts accumulation then (cpu_engine_renderer.cpp:108-112)
         world_key = getattr(world, "_version", None), id(world)
+        if getattr(world, "_moved", False):  # World.mark_moved(): an animation frame
+            world._moved = False
+            moved = None
+            if self._world_key == world_key and not getattr(world, "_dirty", True) and ctx.tree() in (TREE_DEVICE, TREE_DEVICE_SAH) \
+                    and len(world.instances) == len(self._flat.instances):
+                moved = flatten_motion(world, self._flat.tris["source_index"], self.backend)
+            if moved is None:
+                world._dirty = True       # no device trees (or another topology): an ordinary modification
+            else:                         # the device refits its trees and rebuilds the world tree; nothing is built on the host
+                tris, attrs, instances = moved
+                if len(tris):
+                    ctx.update_triangles(0, tris, attrs)
+                if len(instances):
+                    ctx.update_instances(instances)
         if self._world_key != world_key or getattr(world, "_dirty", True):
             self._flat = flatten(world, self.backend)
             ctx.upload_scene(self._flat)

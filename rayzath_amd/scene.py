@@ -206,6 +206,13 @@ class World:
         self.material = Material((0xFF, 0xFF, 0xFF, 0x00), 0.0, 0.0, 0.0, 1.0, 0.0, name="world_material")
         self.default_material = Material((0xC0, 0xC0, 0xC0, 0xFF), name="world_default_material")
 
+    def mark_moved(self):
+        """Vertices of meshes and / or transformations of instances moved — the same meshes with the same triangles in the same instances
+        (an animation frame).  An Engine whose context holds device-built trees refits them on the device and rebuilds the world tree there
+        (Context.update_triangles / update_instances) instead of building every tree again on the host, as the reference does at any change
+        (component_container.hpp:259-363); otherwise this is `_dirty = True`."""
+        self._moved = True
+
     def add(self, obj):
         {Material: self.materials, Mesh: self.meshes, Instance: self.instances, SpotLight: self.spot_lights,
          DirectLight: self.direct_lights, Group: self.groups}[type(obj)].append(obj)
@@ -368,6 +375,16 @@ class HostBackend:
             raise ValueError(f"{self.prefix}build_world_tree failed ({rc})")
         return nodes[:n.value].copy(), order[:n_order.value].copy()
 
+    def fill_triangles(self, mesh, order):
+        """The mesh's triangles `order` (indices into the mesh) as device records, in that order (hiprz_fill_triangles)."""
+        order = np.ascontiguousarray(order, dtype=np.uint32)
+        tris, attrs = np.zeros(len(order), dtype=_abi.tri_dtype), np.zeros(len(order), dtype=_abi.tri_attr_dtype)
+        d = mesh.desc()
+        rc = self._fn("fill_triangles")(C.byref(d), order.ctypes.data, len(order), tris.ctypes.data, attrs.ctypes.data)
+        if rc != 0:
+            raise ValueError(f"{self.prefix}fill_triangles failed ({rc}) for mesh {mesh.name!r}")
+        return tris, attrs
+
     def instance_bounds(self, vertices, inst_record):
         self._fn("instance_bounds")(vertices.ctypes.data, len(vertices), inst_record.ctypes.data)
 
@@ -433,6 +450,37 @@ def _in_group(inst, backend):
         s = (s * g.scale.astype(F32)).astype(F32)
         g = g.group
     return p, s, x, y, z
+
+
+def flatten_motion(world, uploaded_sources, backend=None):
+    """Triangles and instance records only, for Context.update_triangles / update_instances: every mesh's triangles in the order of an
+    earlier flatten() (`uploaded_sources` = its tris["source_index"]), no tree is built.  None when the world no longer matches that order."""
+    backend = backend or HostBackend()
+    seen, cursor, tri_parts, attr_parts = set(), 0, [], []
+    for inst in world.instances:
+        if inst.mesh is None or id(inst.mesh) in seen:
+            continue
+        seen.add(id(inst.mesh))
+        T = len(inst.mesh.tri_vertices)
+        if cursor + T > len(uploaded_sources) or (T and int(uploaded_sources[cursor:cursor + T].max()) >= T):
+            return None
+        tris, attrs = backend.fill_triangles(inst.mesh, uploaded_sources[cursor:cursor + T])
+        tri_parts.append(tris), attr_parts.append(attrs)
+        cursor += T
+    if cursor != len(uploaded_sources):
+        return None
+    instances = np.zeros(len(world.instances), dtype=_abi.instance_dtype)
+    for i, inst in enumerate(world.instances):
+        r = instances[i:i + 1]
+        own = (inst.position, inst.scale) + backend.axes(inst.rotation)
+        r["position"], r["scale"], r["x_axis"], r["y_axis"], r["z_axis"] = _in_group(inst, backend)
+        if inst.mesh is not None:
+            backend.instance_bounds(inst.mesh.vertices, r)
+        if world.group_transforms == "cpu":
+            r["position"], r["scale"], r["x_axis"], r["y_axis"], r["z_axis"] = own
+    tris = np.concatenate(tri_parts) if tri_parts else np.zeros(0, _abi.tri_dtype)
+    attrs = np.concatenate(attr_parts) if attr_parts else np.zeros(0, _abi.tri_attr_dtype)
+    return tris, attrs, instances
 
 
 def flatten(world, backend=None):

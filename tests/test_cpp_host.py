@@ -82,6 +82,15 @@ def test_cpp_engine_renders_like_the_python_host(built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_engine_refits_a_moved_world_on_the_device(built):
+    """World::makeMoved() — vertices and transformations changed, nothing else: with device-built trees Hip::Engine calls
+    hiprz_update_triangles / hiprz_update_instances (no host-side tree build, as the reference does at every change) and renders the
+    frame a fresh engine renders from the moved world; on host trees the same call is an ordinary modification."""
+    proc = subprocess.run([EXE, "moved", "-"], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0 and "moved frame equal, refitted on the device, changed yes, on host trees equal" in proc.stdout, proc.stdout + proc.stderr
+
+
+@pytest.mark.gpu
 def test_cpp_engine_reuploads_when_a_material_is_repointed_at_another_uploaded_map(built):
     """World::makeShadingModified() after two materials swapped their (already uploaded) textures: the map indices of the in-place path
     are positions in the uploaded texture list, so the engine has to notice that the first-use order changed and upload the scene again."""

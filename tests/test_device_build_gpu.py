@@ -276,3 +276,43 @@ def test_awkward_meshes_through_the_device_builders(built, device):
     for n in (1, 5, 4):
         dev.render(n)
     _same_frames(ref, dev)
+
+
+def test_python_engine_refits_a_moved_world_on_the_device(built):
+    """World.mark_moved() through rayzath_amd.engine.Engine: with the hosts' default trees (device SAH for this scene) the engine calls
+    update_triangles / update_instances and renders what a fresh engine renders from the moved world."""
+    from rayzath_amd.engine import Engine
+    def build(deformed):
+        world = scenes.textured_sphere_scene(200, 120, resolution=96, map_size=64)
+        if deformed:
+            deform(world)
+        return world
+    def deform(world):
+        inst = next(i for i in world.instances if i.name == "bugatti stand-in")
+        v = inst.mesh.vertices
+        inst.mesh.vertices = np.ascontiguousarray(v * np.array([1.0, 1.25, 0.9], dtype=np.float32) + np.sin(v[:, [1, 2, 0]] * 7.0).astype(np.float32) * np.float32(0.03), dtype=np.float32)
+        inst.position = (inst.position + np.array([0.25, -0.1, 0.2], dtype=np.float32)).astype(np.float32)
+        inst.rotation = (inst.rotation + np.array([0.1, 0.4, 0.0], dtype=np.float32)).astype(np.float32)
+    cfg = RenderConfig(tracing=Tracing(6, 4))
+    world, fresh = build(False), build(True)
+    engine, reference = Engine(0, streams=1), Engine(0, streams=1)
+    engine.renderWorld(world, cfg)
+    assert engine.context.tree() == DEVICE_SAH
+    before = world.camera.image_buffer.copy()
+    deform(world)
+    world.mark_moved()
+    engine.renderWorld(world, cfg)
+    assert "refit mesh trees (device)" in engine.context.timings() and "build world tree (device)" in engine.context.timings()
+    reference.renderWorld(fresh, cfg)
+    assert np.array_equal(world.camera.image_buffer, fresh.camera.image_buffer) and np.array_equal(world.camera.depth_buffer, fresh.camera.depth_buffer)
+    assert world.camera.ray_count == fresh.camera.ray_count
+    assert not np.array_equal(before, world.camera.image_buffer)
+    # on host trees the same call is an ordinary modification
+    plain = build(False)
+    host = Engine(0, streams=1)
+    host.set_tree(0)
+    host.renderWorld(plain, cfg)
+    deform(plain)
+    plain.mark_moved()
+    host.renderWorld(plain, cfg)
+    assert host.context.tree() == 0 and np.array_equal(plain.camera.image_buffer, fresh.camera.image_buffer)
