@@ -1378,6 +1378,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
                 DeviceMesh m;
                 m.tri_first = leaf.begin, m.n_tris = leaf.meta & HIPRZ_NODE_COUNT_MASK;
                 m.ref_first = m.n_tris ? sc->tris[leaf.begin].pad0 : 0u;
+                m.leaf_slot = new_index[root];
                 std::memcpy(m.bb_min, leaf.bb_min, 12), std::memcpy(m.bb_max, leaf.bb_max, 12);
                 mesh_of_root[root] = uint32_t(device_meshes.size());
                 device_meshes.push_back(m);
@@ -1472,6 +1473,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
         RZ_HIP(c, c->has_mesh.assign(has_mesh.data(), has_mesh.size(), c->stream));
         RZ_HIP(c, hipStreamSynchronize(c->stream));
         RZ_HIP(c, c->slot_parent.resize(node_capacity));
+        RZ_HIP(c, hipMemsetAsync(c->slot_parent.ptr, 0xFF, size_t(node_capacity) * sizeof(uint32_t), c->stream));  // RZ_END: the single leaves of small meshes have no parent
         int rc = HIPRZ_OK;
         if (sc->n_tlas_order) {
             rc = device_build_world_tree(c, validate);

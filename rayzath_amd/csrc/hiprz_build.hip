@@ -996,9 +996,8 @@ int device_build_mesh_trees(hiprz_ctx* c, std::vector<DeviceMesh>& meshes, const
     float4* blob_attrs = reinterpret_cast<float4*>(c->hot.ptr + c->dscene.off_tri_attrs);
     uint32_t n_max = 0;
     for (const auto& m : meshes) n_max = std::max(n_max, m.n_tris);
-    if (n_max <= kLeafMax) return HIPRZ_OK;
-    // one workspace, carved; every array padded to 256 bytes
-    const size_t n = n_max;
+    // one workspace, carved; every array padded to 256 bytes (meshes of at most kLeafMax triangles stay the single leaves they were uploaded as)
+    const size_t n = std::max<uint32_t>(n_max, kLeafMax + 1u);
     const size_t bytes = c->build_sah ? sah_workspace_bytes(n) : 256u * 24u + n * 4u * 12u + n * 4u * 6u * 2u + n * 16u * 9u + (2u * n) * 4u;
     RZ_HIP(c, c->build_temp.resize(bytes));
     RZ_HIP(c, c->slot_parent.resize(c->node_capacity));
@@ -1119,11 +1118,14 @@ int device_update_triangles(hiprz_ctx* c, uint32_t first, uint32_t n, const hipr
     RZ_HIP(c, c->update_attrs.assign(attrs, n, st));
     hipLaunchKernelGGL(rz_refit_scatter_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, c->update_tris.ptr, c->update_attrs.ptr, first, n, c->ref_to_dev.ptr, blob_tris, blob_attrs);
     for (const auto& m : c->device_meshes) {
-        if (m.region == RZ_END || m.ref_first + m.n_tris <= first || first + n <= m.ref_first) continue;
-        RZ_HIP(c, c->refit_visit.resize(m.n_slots));
-        RZ_HIP(c, hipMemsetAsync(c->refit_visit.ptr, 0, size_t(m.n_slots) * 4u, st));
-        EmitViews e{reinterpret_cast<float4*>(c->dev_nodes.ptr), c->slot_parent.ptr + m.region, m.region, m.tri_first};
-        hipLaunchKernelGGL(rz_refit_kernel, dim3((m.n_slots + 255u) / 256u), dim3(256), 0, st, e, m.n_slots, blob_tris, blob_attrs, c->refit_visit.ptr, c->nodes64.ptr);
+        if (m.n_tris == 0u || m.ref_first + m.n_tris <= first || first + n <= m.ref_first) continue;
+        // a mesh too small to have been built is one leaf (the uploaded placeholder): a region of one slot without a parent
+        const uint32_t region = m.region != RZ_END ? m.region : m.leaf_slot, n_slots = m.region != RZ_END ? m.n_slots : 1u;
+        if (region == RZ_END) continue;
+        RZ_HIP(c, c->refit_visit.resize(n_slots));
+        RZ_HIP(c, hipMemsetAsync(c->refit_visit.ptr, 0, size_t(n_slots) * 4u, st));
+        EmitViews e{reinterpret_cast<float4*>(c->dev_nodes.ptr), c->slot_parent.ptr + region, region, m.tri_first};
+        hipLaunchKernelGGL(rz_refit_kernel, dim3((n_slots + 255u) / 256u), dim3(256), 0, st, e, n_slots, blob_tris, blob_attrs, c->refit_visit.ptr, c->nodes64.ptr);
     }
     RZ_HIP(c, hipStreamSynchronize(st));
     RZ_HIP(c, hipGetLastError());

@@ -88,6 +88,7 @@ struct DeviceMesh {
     uint32_t tri_first = 0, n_tris = 0;  // its triangles in the device order
     uint32_t ref_first = 0;              // ... and in the uploaded snapshot's order (a mesh's triangles are contiguous in both)
     uint32_t region = 0xFFFFFFFFu;       // slot of its root in the node arrays (RZ_END: too small to build, stays one leaf)
+    uint32_t leaf_slot = 0xFFFFFFFFu;    // ... the slot of that one leaf (the uploaded placeholder), whose box a refit fits again
     uint32_t n_slots = 0;                // nodes emitted
     float bb_min[3] = {0, 0, 0}, bb_max[3] = {0, 0, 0};
 };

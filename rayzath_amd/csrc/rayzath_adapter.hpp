@@ -45,15 +45,18 @@ class WorldAdapter {
     using OT = typename Api::ObjectType;
 
 public:
-    enum class Change { None, Shading, Scene };
+    // Moved: only vertices / transformations changed (same meshes, same triangles, same instances) AND the caller holds device-built
+    // trees: scene() then has the new triangle records in the UPLOADED order and the new instance records — what
+    // hiprz_update_triangles / hiprz_update_instances take; its nodes and leaf orders stay those of the uploaded snapshot.
+    enum class Change { None, Shading, Scene, Moved };
     World::GroupTransforms group_transforms = World::GroupTransforms::Cpu;  // see hip_engine.hpp: what the CPU engine does / the CUDA engine
 
     template <class RZWorld>
-    Change refresh(RZWorld& world) {
+    Change refresh(RZWorld& world, bool device_trees = false) {
         if (m_valid && !world.stateRegister().IsModified()) return Change::None;
-        const bool geometry = !m_valid || modified<OT::Mesh>(world) || modified<OT::Instance>(world) || modified<OT::Group>(world) ||
-                              modified<OT::Texture>(world) || modified<OT::NormalMap>(world) || modified<OT::MetalnessMap>(world) ||
-                              modified<OT::RoughnessMap>(world) || modified<OT::EmissionMap>(world);
+        const bool maps_modified = modified<OT::Texture>(world) || modified<OT::NormalMap>(world) || modified<OT::MetalnessMap>(world) ||
+                                   modified<OT::RoughnessMap>(world) || modified<OT::EmissionMap>(world);
+        const bool geometry = !m_valid || modified<OT::Mesh>(world) || modified<OT::Instance>(world) || modified<OT::Group>(world) || maps_modified;
         // the world's flag is the OR of all its containers' (updatable.cpp:23-27): a camera that moved its ray-cast pixel, say, sets it
         // too, and is none of the scene mirror's business
         const bool shading_modified = modified<OT::Material>(world) || modified<OT::SpotLight>(world) || modified<OT::DirectLight>(world);
@@ -62,7 +65,36 @@ public:
             return Change::None;
         }
         Change change = Change::Scene;
-        if (!geometry) {
+        if (m_valid && device_trees && geometry && !maps_modified && !shading_modified) {
+            // meshes / instances / groups only: if the world still has the uploaded shape — the same instances using the same meshes and
+            // material tables, every mesh with its triangle count — the new vertices and transformations go up in the uploaded order
+            FlatScene s;
+            std::vector<const void*> maps;
+            std::vector<std::pair<uint32_t, uint32_t>> ranges;
+            shading(world, s, maps, /*texels=*/false);
+            geometry_of(world, s, ranges);
+            if (maps == m_maps && same_shape(s, ranges)) {
+                std::vector<hiprz_tri> tris(s.tris.size());
+                std::vector<hiprz_tri_attr> attrs(s.tris.size());
+                bool permutation = true;
+                for (const auto& [first, count] : ranges) {
+                    std::vector<uint32_t> where(count, 0xFFFFFFFFu);  // triangle of the mesh -> its place in the NEW leaf order
+                    for (uint32_t k = 0; k < count; ++k)
+                        if (s.tris[first + k].source_index < count) where[s.tris[first + k].source_index] = k;
+                    for (uint32_t j = 0; j < count && permutation; ++j) {
+                        const uint32_t source = m_scene.tris[first + j].source_index;
+                        permutation = source < count && where[source] != 0xFFFFFFFFu;
+                        if (permutation) tris[first + j] = s.tris[first + where[source]], attrs[first + j] = s.tri_attrs[first + where[source]];
+                    }
+                }
+                if (permutation) {
+                    for (size_t i = 0; i < s.instances.size(); ++i) s.instances[i].blas_root = m_scene.instances[i].blas_root;
+                    m_scene.tris = std::move(tris), m_scene.tri_attrs = std::move(attrs), m_scene.instances = std::move(s.instances);
+                    change = Change::Moved;
+                }
+            }
+        }
+        if (change == Change::Scene && !geometry) {
             // materials and lights only — unless a material now points at a map the uploaded scene does not hold
             FlatScene s;
             std::vector<const void*> maps;
@@ -76,7 +108,7 @@ public:
             FlatScene s;
             std::vector<const void*> maps;
             shading(world, s, maps, /*texels=*/true);
-            geometry_of(world, s);
+            geometry_of(world, s, m_mesh_ranges);
             m_scene = std::move(s), m_maps = std::move(maps), m_valid = true;
         }
         clear<OT::Texture>(world), clear<OT::NormalMap>(world), clear<OT::MetalnessMap>(world), clear<OT::RoughnessMap>(world);
@@ -237,8 +269,26 @@ private:
         nodes[base + slot] = n;
     }
 
+    // the freshly mirrored geometry against the uploaded one: instance for instance the same mesh (by its place in the first-use order),
+    // the same material table; every mesh with the same number of triangles
+    bool same_shape(const FlatScene& s, const std::vector<std::pair<uint32_t, uint32_t>>& ranges) const {
+        if (ranges != m_mesh_ranges || s.tris.size() != m_scene.tris.size() || s.instances.size() != m_scene.instances.size() ||
+            s.inst_materials != m_scene.inst_materials || s.materials.size() != m_scene.materials.size())
+            return false;
+        std::map<uint32_t, uint32_t> root_of;  // uploaded mesh root -> new mesh root
+        for (size_t i = 0; i < s.instances.size(); ++i) {
+            const hiprz_instance &a = m_scene.instances[i], &b = s.instances[i];
+            if (a.material_base != b.material_base || a.material_count != b.material_count) return false;
+            const auto it = root_of.find(a.blas_root);
+            if (it == root_of.end()) root_of[a.blas_root] = b.blas_root;
+            else if (it->second != b.blas_root) return false;
+        }
+        return true;
+    }
+
     template <class RZWorld>
-    void geometry_of(RZWorld& world, FlatScene& s) {
+    void geometry_of(RZWorld& world, FlatScene& s, std::vector<std::pair<uint32_t, uint32_t>>& mesh_ranges) {
+        mesh_ranges.clear();
         auto& instances = world.template container<OT::Instance>();
         const uint32_t n_inst = instances.count();
         std::map<const void*, uint32_t> instance_index;
@@ -285,6 +335,7 @@ private:
                         [&](const auto* triangle) { order.push_back(uint32_t(triangle - first_triangle)); });
             for (size_t k = node_base; k < s.nodes.size(); ++k)
                 s.nodes[k].begin += (s.nodes[k].meta & HIPRZ_NODE_LEAF) ? uint32_t(tri_base) : uint32_t(node_base);
+            mesh_ranges.emplace_back(uint32_t(tri_base), uint32_t(order.size()));
             s.tris.resize(tri_base + order.size()), s.tri_attrs.resize(tri_base + order.size());
             if (hiprz_fill_triangles(&d, order.data(), uint32_t(order.size()), s.tris.data() + tri_base, s.tri_attrs.data() + tri_base) != HIPRZ_OK)
                 throw Exception(HIPRZ_ERR_INVALID, "mesh with out-of-range indices");
@@ -312,6 +363,7 @@ private:
     }
 
     FlatScene m_scene;
+    std::vector<std::pair<uint32_t, uint32_t>> m_mesh_ranges;  // (first triangle, count) of every distinct mesh in the uploaded snapshot
     std::vector<const void*> m_maps;                    // the uploaded maps, by identity, in texture-index order
     std::map<const void*, int32_t> m_material_index;    // material object -> index in hiprz_scene::materials
     bool m_valid = false;
@@ -342,7 +394,15 @@ public:
                 for (uint32_t i : enabled)
                     if (static_cast<const void*>(&*cameras[i]) == m_slots[k]) check(hiprz_select_camera(m_ctx, uint32_t(k))), readback(world, *cameras[i]);
         }
-        switch (m_adapter.refresh(world)) {
+        uint32_t tree = HIPRZ_TREE_REFERENCE;
+        const bool device_trees = hiprz_tree(m_ctx, &tree) == HIPRZ_OK && (tree == HIPRZ_TREE_DEVICE || tree == HIPRZ_TREE_DEVICE_SAH);
+        switch (m_adapter.refresh(world, device_trees)) {
+            case WorldAdapter<Api>::Change::Moved: {  // an animation frame: the device refits its trees and rebuilds the world tree
+                const FlatScene& s = m_adapter.scene();
+                if (!s.tris.empty()) check(hiprz_update_triangles(m_ctx, 0u, uint32_t(s.tris.size()), s.tris.data(), s.tri_attrs.data()));
+                if (!s.instances.empty()) check(hiprz_update_instances(m_ctx, s.instances.data(), uint32_t(s.instances.size())));
+                break;
+            }
             case WorldAdapter<Api>::Change::Scene: {
                 const hiprz_scene view = m_adapter.scene().view();
                 check(hiprz_upload_scene(m_ctx, &view));

@@ -26,6 +26,46 @@ static bool same_scene(const FlatScene& a, const FlatScene& b) {
     return ok;
 }
 
+
+using OT = Double::ObjectType;
+static void load_scene(const char* path, World& w) {
+    IO::LoadLog l;
+    IO::loadScene(path, w, l);
+}
+// vertices of the first real mesh and the first instance's transformation move; nothing else changes
+static void move_world(World& w) {
+    for (auto& inst : w.instances)
+        if (inst->mesh && inst->mesh->tri_materials.size() >= 2) {
+            auto& v = inst->mesh->vertices;
+            for (size_t k = 0; k + 2 < v.size(); k += 3) v[k] = v[k] * 1.25f + 0.1f * v[k + 2], v[k + 1] = v[k + 1] * 0.9f - 0.05f * v[k];
+            break;
+        }
+    w.instances[0]->position.x += 0.3f, w.instances[0]->rotation.y += 0.4f;
+}
+// the double follows the moved twin IN PLACE (the adapter knows maps and materials by identity): new vertices, new transformations and
+// boxes; its trees stay as they were, as a refit leaves them
+static void follow_twin(Double::World& w, const World& t, const FlatScene& f) {
+    std::map<const Mesh*, uint32_t> slot;
+    auto& meshes = w.container<OT::Mesh>();
+    auto& instances = w.container<OT::Instance>();
+    for (size_t i = 0; i < t.instances.size(); ++i) {
+        const hiprz_instance& r = f.instances[i];
+        Double::Transformation x;
+        x.m_position = Double::detail::v3(r.position), x.m_scale = Double::detail::v3(r.scale);
+        x.m_coord_system = Double::CoordSystem{Double::detail::v3(r.x_axis), Double::detail::v3(r.y_axis), Double::detail::v3(r.z_axis)};
+        instances[uint32_t(i)]->m_transformation = x, instances[uint32_t(i)]->m_transformation_in_group = x;
+        instances[uint32_t(i)]->m_bb = Double::BoundingBox{Double::detail::v3(r.bb_min), Double::detail::v3(r.bb_max)};
+        instances[uint32_t(i)]->stateRegister().MakeModified();
+        const auto& mesh = t.instances[i]->mesh;
+        if (!mesh || slot.count(mesh.get())) continue;
+        const uint32_t k = uint32_t(slot.size());
+        slot[mesh.get()] = k;
+        auto& items = meshes[k]->m_vertices.items;
+        for (size_t q = 0; q < items.size(); ++q) items[q] = Double::vec3f{mesh->vertices[3 * q], mesh->vertices[3 * q + 1], mesh->vertices[3 * q + 2]};
+        meshes[k]->stateRegister().MakeModified();
+    }
+}
+
 // GPU: WorldRenderer over the double == Hip::Engine over the twin, frame for frame (two cameras, sync and pipelined calls, a
 // shading-only change in between)
 static bool render_check(const char* scene_path) {
@@ -110,6 +150,55 @@ static bool render_check(const char* scene_path) {
     hiprz_graph_captures(ctx, &captures);
     std::printf("graph captures %u\n", captures);
     hiprz_destroy(ctx);
+    {   // a moved world over device-built trees: WorldRenderer refits on the device; the frame is a fresh engine's frame of the moved twin
+        World t0, t1;
+        load_scene(scene_path, t0), load_scene(scene_path, t1);
+        move_world(t1);
+        const FlatScene f0 = flatten(t0), f1 = flatten(t1);
+        auto w = Double::from_twin(t0, f0, f0);
+        auto cam = Double::add_camera(*w, t0.camera);
+        hiprz_ctx* c2 = nullptr;
+        if (hiprz_create(&c2, 0) != HIPRZ_OK || hiprz_set_tree(c2, HIPRZ_TREE_DEVICE_SAH) != HIPRZ_OK) return std::printf("no device\n"), false;
+        WorldRenderer<Double::Api> r2(c2);
+        r2.renderWorld(*w, dcfg);
+        follow_twin(*w, t1, f1);
+        r2.renderWorld(*w, dcfg);
+        char timings[4096] = {0};
+        hiprz_timings(c2, timings, sizeof timings);
+        const bool refitted = std::strstr(timings, "refit mesh trees (device)") != nullptr;
+        Engine fresh(0, 1);
+        fresh.renderWorld(t1, cfg);
+        const size_t n = size_t(t1.camera.width) * t1.camera.height;
+        bool eq = t1.camera.ray_count == cam->rayCount();
+        for (size_t i = 0; eq && i < n; ++i) {
+            const Double::Color& c = cam->m_image.data[i];
+            const uint8_t* p = &t1.camera.image_buffer[4 * i];
+            eq = c.red == p[0] && c.green == p[1] && c.blue == p[2] && c.alpha == p[3] && std::memcmp(&cam->m_depth.data[i], &t1.camera.depth_buffer[i], 4) == 0;
+        }
+        std::printf("%-28s %s, %s\n", "moved world, device trees", eq ? "frame equal" : "frame DIFFERENT", refitted ? "refitted on the device" : "NOT REFITTED");
+        if (!eq) {  // where: colours, depths, ray counts; and the twin's own makeMoved() path on the same scene
+            size_t colours = 0, depths = 0;
+            for (size_t i = 0; i < n; ++i) {
+                const Double::Color& c = cam->m_image.data[i];
+                const uint8_t* p = &t1.camera.image_buffer[4 * i];
+                colours += !(c.red == p[0] && c.green == p[1] && c.blue == p[2] && c.alpha == p[3]);
+                depths += std::memcmp(&cam->m_depth.data[i], &t1.camera.depth_buffer[i], 4) != 0;
+            }
+            std::printf("  differing colours %zu, depths %zu of %zu; rays %llu vs %llu\n", colours, depths, n, (unsigned long long)cam->rayCount(), (unsigned long long)t1.camera.ray_count);
+            World t2;
+            load_scene(scene_path, t2);
+            Engine twin_engine(0, 1);
+            twin_engine.tree(HIPRZ_TREE_DEVICE_SAH);
+            twin_engine.renderWorld(t2, cfg);
+            move_world(t2), t2.makeMoved();
+            twin_engine.renderWorld(t2, cfg);
+            size_t twin_colours = 0;
+            for (size_t i = 0; i < 4 * n; ++i) twin_colours += t2.camera.image_buffer[i] != t1.camera.image_buffer[i];
+            std::printf("  twin makeMoved vs fresh: %zu differing bytes\n", twin_colours);
+        }
+        ok &= eq && refitted;
+        hiprz_destroy(c2);
+    }
     return ok;
 }
 
@@ -124,7 +213,6 @@ int main(int argc, char** argv) {
     const FlatScene flat = flatten(twin);
     auto world = Double::from_twin(twin, flat, flat_cuda);
     using Adapter = WorldAdapter<Double::Api>;
-    using OT = Double::ObjectType;
     bool ok = true;
 
     Adapter adapter;
@@ -174,6 +262,41 @@ int main(int argc, char** argv) {
     twin.group_transforms = World::GroupTransforms::Cuda;
     ok &= adapter.refresh(*world) == Adapter::Change::Scene;
     ok &= same_scene(adapter.scene(), flatten(twin));
+
+    std::printf("# vertices and transformations moved while the context holds device-built trees: records in the UPLOADED order\n");
+    {
+        World before, after;
+        load_scene(argv[1], before), load_scene(argv[1], after);
+        move_world(after);
+        const FlatScene f0 = flatten(before), f1 = flatten(after);
+        auto w0 = Double::from_twin(before, f0, f0);
+        Adapter moving, rebuilding;
+        ok &= moving.refresh(*w0, /*device_trees=*/true) == Adapter::Change::Scene;
+        follow_twin(*w0, after, f1);
+        const bool moved = moving.refresh(*w0, /*device_trees=*/true) == Adapter::Change::Moved;
+        std::printf("%-16s %s\n", "change", moved ? "Moved" : "NOT Moved");
+        ok &= moved;
+        std::vector<uint32_t> sources(f0.tris.size());
+        for (size_t k = 0; k < sources.size(); ++k) sources[k] = f0.tris[k].source_index;
+        const FlatScene motion = flattenMotion(after, sources);
+        ok &= same("moved tris", moving.scene().tris, motion.tris) & same("moved tri_attrs", moving.scene().tri_attrs, motion.tri_attrs);
+        bool inst_eq = moving.scene().instances.size() == motion.instances.size();
+        for (size_t i = 0; inst_eq && i < motion.instances.size(); ++i) {  // transformation and box (flattenMotion leaves the tables empty)
+            const hiprz_instance &a = moving.scene().instances[i], &b = motion.instances[i];
+            inst_eq = !std::memcmp(a.position, b.position, 12) && !std::memcmp(a.scale, b.scale, 12) && !std::memcmp(a.x_axis, b.x_axis, 12) &&
+                      !std::memcmp(a.y_axis, b.y_axis, 12) && !std::memcmp(a.z_axis, b.z_axis, 12) && !std::memcmp(a.bb_min, b.bb_min, 12) &&
+                      !std::memcmp(a.bb_max, b.bb_max, 12) && a.blas_root == f0.instances[i].blas_root && a.material_base == f0.instances[i].material_base;
+        }
+        std::printf("%-16s %s\n", "moved instances", inst_eq ? "equal" : "DIFFERENT");
+        ok &= inst_eq;
+        ok &= std::memcmp(moving.scene().tris.data(), f0.tris.data(), f0.tris.size() * sizeof(hiprz_tri)) != 0;  // (something did move)
+        // the same change while the context holds host-built trees: a full refresh
+        auto w0b = Double::from_twin(before, f0, f0);
+        ok &= rebuilding.refresh(*w0b, false) == Adapter::Change::Scene;
+        follow_twin(*w0b, after, f1);
+        ok &= rebuilding.refresh(*w0b, false) == Adapter::Change::Scene;
+        ok &= same("tris after a full refresh", rebuilding.scene().tris, motion.tris);
+    }
 
     std::printf("# camera record\n");
     {

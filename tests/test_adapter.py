@@ -2,7 +2,8 @@
 the test double of tests/adapter_double.hpp (the reference's host library cannot be compiled in this image): the adapter's snapshot of
 a scene with a deep mesh, all five map kinds, lights, groups and unset material slots equals Hip::flatten() of the same scene byte for
 byte, and the reference's dirty flags (updatable.cpp:23-51) select nothing / a shading update / a full refresh as the CUDA backend's
-`reconstruct` would (cuda_world.cu:69-75)."""
+`reconstruct` would (cuda_world.cu:69-75) — plus, where the context holds device-built trees and only vertices / transformations moved,
+the records for a device-side refit in the uploaded order (Change::Moved)."""
 import os
 import subprocess
 
@@ -50,3 +51,5 @@ def test_world_renderer_over_the_double_renders_like_the_engine_over_the_twin(bu
     assert r.returncode == 0 and "ADAPTER OK" in r.stdout and "DIFFERENT" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert r.stdout.count("camera 0 equal") == 4 and r.stdout.count("camera 1 equal") == 4
     assert r.stdout.count("ray cast equal") == 4 and "accumulation went on         yes" in r.stdout
+    # ... and a moved world over device-built trees goes through hiprz_update_triangles / hiprz_update_instances (Change::Moved)
+    assert "moved world, device trees    frame equal, refitted on the device" in r.stdout

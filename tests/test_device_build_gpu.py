@@ -316,3 +316,46 @@ def test_python_engine_refits_a_moved_world_on_the_device(built):
     plain.mark_moved()
     host.renderWorld(plain, cfg)
     assert host.context.tree() == 0 and np.array_equal(plain.camera.image_buffer, fresh.camera.image_buffer)
+
+
+@pytest.mark.parametrize("device", [DEVICE, DEVICE_SAH])
+def test_refit_reaches_the_meshes_that_are_one_leaf(built, device):
+    """A mesh of at most 4 triangles (a wall of a Cornell box) is not built on the device: it stays the single leaf it was uploaded as, and
+    hiprz_update_triangles has to fit that leaf's box again too — a sheared wall rendered through its old box loses the hits outside it."""
+    def build(sheared):
+        world = scenes.cornell_box(160, 100)
+        if sheared:
+            seen = set()
+            for inst in world.instances:
+                if inst.mesh is None or id(inst.mesh) in seen:
+                    continue
+                seen.add(id(inst.mesh))
+                v = inst.mesh.vertices
+                inst.mesh.vertices = np.ascontiguousarray(v * np.array([1.2, 0.9, 1.1], dtype=np.float32) + v[:, [2, 0, 1]] * np.float32(0.15), dtype=np.float32)
+        return world
+    before, after = build(False), build(True)
+    flat0, flat1, cam = flatten(before), flatten(after), camera_struct(before.camera)
+    assert min(len(i.mesh.tri_vertices) for i in before.instances if i.mesh is not None) <= 4
+    cfg = RenderConfig(tracing=Tracing(6, 4)).struct()
+    dev = _render(flat0, cam, cfg, device)
+    # the new records in the uploaded order: the triangle with flat0's source index, mesh by mesh (a mesh's range is the same in both)
+    order = np.empty(len(flat0.tris), dtype=np.int64)
+    done = 0
+    seen = set()
+    for inst in before.instances:
+        if inst.mesh is None or id(inst.mesh) in seen:
+            continue
+        seen.add(id(inst.mesh))
+        T = len(inst.mesh.tri_vertices)
+        where = np.empty(T, dtype=np.int64)
+        where[flat1.tris["source_index"][done:done + T]] = np.arange(T)
+        order[done:done + T] = done + where[flat0.tris["source_index"][done:done + T]]
+        done += T
+    assert done == len(flat0.tris)
+    dev.update_triangles(0, flat1.tris[order], flat1.tri_attrs[order])
+    dev.update_instances(flat1.instances)
+    for n in (1, 5, 4):
+        dev.render(n)
+    fresh = _render(flat1, cam, cfg, 0)
+    _same_frames(fresh, dev)
+    assert not np.array_equal(fresh.read_depth(), _render(flat0, cam, cfg, 0).read_depth())
