@@ -379,6 +379,11 @@ int hiprz_update_triangles(hiprz_ctx* ctx, uint32_t first, uint32_t n, const hip
  * position, scale, axes and box are taken from the records, mesh and material tables stay as uploaded): the world tree is rebuilt on
  * the device.  Restarts accumulation. */
 int hiprz_update_instances(hiprz_ctx* ctx, const hiprz_instance* instances, uint32_t n);
+/* Scenes with device-built trees only.  Every mesh tree built again by the device over the vertices it holds NOW (after
+ * hiprz_update_triangles calls deformed a mesh far from the shape its tree was built for, a refitted tree keeps its topology and its
+ * boxes grow into each other): HIPRZ_TREE_DEVICE (Morton order, the fastest build) or HIPRZ_TREE_DEVICE_SAH.  Nothing crosses the bus;
+ * the uploaded order of the triangles — what hiprz_update_triangles addresses — stays.  Restarts accumulation. */
+int hiprz_rebuild_trees(hiprz_ctx* ctx, uint32_t tree);
 /* The trees the context walks now, as a snapshot would hold them (for validation and tests): node records with plain boxes, the world
  * tree's root and leaf order, every instance's mesh root, and for every triangle of the device order its position in the uploaded
  * order.  Any output may be NULL. */

@@ -124,6 +124,7 @@ ENTRY_POINTS = {
     "hiprz_update_shading": (C.c_int, [P, P, U32, P, U32, P, U32]),
     "hiprz_set_tree": (C.c_int, [P, U32]),
     "hiprz_tree": (C.c_int, [P, C.POINTER(U32)]),
+    "hiprz_rebuild_trees": (C.c_int, [P, U32]),
     "hiprz_rebuild_mesh_trees": (C.c_int, [C.POINTER(Scene), U32, P, U32, C.POINTER(U32), P, P, C.POINTER(U32)]),
     "hiprz_update_triangles": (C.c_int, [P, U32, U32, P, P]),
     "hiprz_update_instances": (C.c_int, [P, P, U32]),

@@ -427,6 +427,9 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
             if (motion.instances.size() == m_uploaded_instances && motion.tris.size() == m_uploaded_sources.size()) {
                 if (!motion.tris.empty()) check(hiprz_update_triangles(m_ctx, 0u, uint32_t(motion.tris.size()), motion.tris.data(), motion.tri_attrs.data()));
                 if (!motion.instances.empty()) check(hiprz_update_instances(m_ctx, motion.instances.data(), uint32_t(motion.instances.size())));
+                // a refitted tree keeps the topology it was built with: every kRebuildEvery-th moved frame the device builds the trees again
+                // over the vertices it holds (config D twisted by three radians per unit: 28 ms per step refitted, 12 ms rebuilt)
+                if (++m_moved_frames % kRebuildEvery == 0u) check(hiprz_rebuild_trees(m_ctx, tree));
                 moved_in_place = true;
             }
         }
@@ -443,6 +446,7 @@ void Engine::renderWorld(World& world, const RenderConfig& cfg, bool /*block*/, 
         m_uploaded_sources.resize(flat.tris.size());
         for (size_t k = 0; k < flat.tris.size(); ++k) m_uploaded_sources[k] = flat.tris[k].source_index;
         m_uploaded_instances = flat.instances.size();
+        m_moved_frames = 0;
     } else if (world.isShadingModified()) {  // materials / lights only: replaced in place, no tree is touched
         const FlatScene shading = flattenShading(world);
         // flattenShading numbers the maps in first-use order; those indices mean something only if they name the SAME map objects in

@@ -256,6 +256,8 @@ private:
     std::vector<const void*> m_uploaded_maps;   // the maps of the uploaded scene: hiprz_update_shading may only refer to these, by these indices
     std::vector<uint32_t> m_uploaded_sources;   // source_index of every uploaded triangle, in upload order (World::makeMoved: the order new vertices go up in)
     size_t m_uploaded_instances = 0;
+    uint32_t m_moved_frames = 0;                // consecutive frames that went through the refit (World::makeMoved)
+    static constexpr uint32_t kRebuildEvery = 16u;
 };
 
 }  // namespace RayZath::Hip

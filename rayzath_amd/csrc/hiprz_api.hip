@@ -1571,6 +1571,42 @@ int hiprz_update_triangles(hiprz_ctx* c, uint32_t first, uint32_t n, const hiprz
     return restart_after_geometry_change(c);
 }
 
+int hiprz_rebuild_trees(hiprz_ctx* c, uint32_t tree) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    RZ_FANOUT_OTHER_DEVICES(c, hiprz_rebuild_trees(p, tree));
+    struct Share {
+        hiprz_ctx* c;
+        ~Share() { share_scene_with_streams(c); }
+    } share{c};
+    for (hiprz_ctx* p : c->peers)
+        if (p->device == c->device) (void)hipStreamSynchronize(p->stream);
+    if (!c->have_scene || c->scene_tree != HIPRZ_TREE_DEVICE) return fail(c, HIPRZ_ERR_STATE, "rebuild_trees: the scene's trees were not built on the device");
+    if (tree != HIPRZ_TREE_DEVICE && tree != HIPRZ_TREE_DEVICE_SAH) return fail(c, HIPRZ_ERR_INVALID, "rebuild_trees: HIPRZ_TREE_DEVICE or HIPRZ_TREE_DEVICE_SAH");
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    invalidate_graphs(c);
+    c->build_sah = tree == HIPRZ_TREE_DEVICE_SAH;
+    // the meshes' bounds as they are now: the box of every root (exact after a refit)
+    std::vector<DeviceMesh> meshes = c->device_meshes;
+    for (DeviceMesh& m : meshes) {
+        const uint32_t root = m.region != RZ_END ? m.region : m.leaf_slot;
+        if (root == RZ_END || m.n_tris == 0u) continue;
+        float rec[8];
+        RZ_HIP(c, hipMemcpy(rec, c->dev_nodes.ptr + size_t(root) * sizeof(hiprz_node), sizeof rec, hipMemcpyDeviceToHost));
+        m.bb_min[0] = rec[0], m.bb_max[0] = rec[1], m.bb_min[1] = rec[2], m.bb_max[1] = rec[3], m.bb_min[2] = rec[4], m.bb_max[2] = rec[5];
+    }
+    const int rc = device_build_mesh_trees(c, meshes, c->instance_mesh, !std::getenv("HIPRZ_TRUST_DEVICE_TREES"));
+    if (rc != HIPRZ_OK) return rc;
+    for (size_t i = 0; i < c->device_instances.size(); ++i)
+        if (c->instance_mesh[i] != RZ_END && c->device_meshes[c->instance_mesh[i]].region != RZ_END)
+            c->device_instances[i].blas_root = c->device_meshes[c->instance_mesh[i]].region;
+    uint32_t emitted = c->world_slots;
+    for (const auto& m : c->device_meshes) emitted += m.n_slots;
+    c->n_nodes = emitted;
+    resolve_pipeline(c);
+    return restart_after_geometry_change(c);
+}
+
 int hiprz_update_instances(hiprz_ctx* c, const hiprz_instance* instances, uint32_t n) {
     if (!c) return HIPRZ_ERR_INVALID;
     RZ_FANOUT_OTHER_DEVICES(c, hiprz_update_instances(p, instances, n));

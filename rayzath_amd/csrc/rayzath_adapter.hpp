@@ -379,6 +379,7 @@ class WorldRenderer {
 
 public:
     explicit WorldRenderer(hiprz_ctx* ctx) : m_ctx(ctx) {}
+    uint32_t movedFrames() const { return m_moved_frames; }
     WorldAdapter<Api>& adapter() { return m_adapter; }
     uint32_t seed = 20240501u;
 
@@ -401,11 +402,13 @@ public:
                 const FlatScene& s = m_adapter.scene();
                 if (!s.tris.empty()) check(hiprz_update_triangles(m_ctx, 0u, uint32_t(s.tris.size()), s.tris.data(), s.tri_attrs.data()));
                 if (!s.instances.empty()) check(hiprz_update_instances(m_ctx, s.instances.data(), uint32_t(s.instances.size())));
+                if (++m_moved_frames % 16u == 0u) check(hiprz_rebuild_trees(m_ctx, tree));  // refitted trees keep their topology: now and then build again
                 break;
             }
             case WorldAdapter<Api>::Change::Scene: {
                 const hiprz_scene view = m_adapter.scene().view();
                 check(hiprz_upload_scene(m_ctx, &view));
+                m_moved_frames = 0;
                 break;
             }
             case WorldAdapter<Api>::Change::Shading: {
@@ -498,6 +501,7 @@ private:
     std::vector<uint8_t> m_rgba;
     std::vector<float> m_depth;
     bool m_pending_readback = false;
+    uint32_t m_moved_frames = 0;  // consecutive frames that went through the refit (Change::Moved)
 };
 
 #ifdef HIPRZ_RAYZATH_BUILD

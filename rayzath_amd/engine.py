@@ -161,6 +161,11 @@ class Context:
         assert len(tris) == len(attrs)
         self._check(self.lib.hiprz_update_triangles(self._ctx, first, len(tris), tris.ctypes.data, attrs.ctypes.data))
 
+    def rebuild_trees(self, tree=TREE_DEVICE_SAH):
+        """Every mesh tree built again by the device over the vertices it holds now (after update_triangles deformed a mesh far from the
+        shape its tree was built for); TREE_DEVICE or TREE_DEVICE_SAH.  Scenes with device-built trees only."""
+        self._check(self.lib.hiprz_rebuild_trees(self._ctx, tree))
+
     def update_instances(self, instances):
         """New transformations and world boxes of ALL instances (array of _abi.instance_dtype); the device rebuilds the world tree."""
         instances = np.ascontiguousarray(instances)
@@ -326,6 +331,8 @@ class Engine:
     """HIPGPU peer of CPU::Engine / Cuda::Engine.  Writes its results into the world's camera
     like the reference backends do (imageBuffer / depthBuffer / rayCount, camera.hpp:50-56,113-119)."""
 
+    REBUILD_EVERY = 16   # moved frames (World.mark_moved) between two device rebuilds of the refitted trees
+
     def __init__(self, device=0, streams=None):
         """`device`: a GPU id, or a list of ids (one context over several GPUs).  `streams` (single GPU only): how many contexts share
         the GPU, None = default_streams() of the first world rendered; asking for `engine.context` before that settles for one."""
@@ -379,8 +386,14 @@ class Engine:
                     ctx.update_triangles(0, tris, attrs)
                 if len(instances):
                     ctx.update_instances(instances)
+                # a refitted tree keeps the topology it was built with: every REBUILD_EVERY-th moved frame the device builds the trees
+                # again over the vertices it holds
+                self._moved_frames = getattr(self, "_moved_frames", 0) + 1
+                if self._moved_frames % self.REBUILD_EVERY == 0:
+                    ctx.rebuild_trees(ctx.tree())
         if self._world_key != world_key or getattr(world, "_dirty", True):
             self._flat = flatten(world, self.backend)
+            self._moved_frames = 0
             ctx.upload_scene(self._flat)
             self._world_key = world_key
             world._dirty = False

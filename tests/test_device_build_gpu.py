@@ -307,6 +307,17 @@ def test_python_engine_refits_a_moved_world_on_the_device(built):
     assert np.array_equal(world.camera.image_buffer, fresh.camera.image_buffer) and np.array_equal(world.camera.depth_buffer, fresh.camera.depth_buffer)
     assert world.camera.ray_count == fresh.camera.ray_count
     assert not np.array_equal(before, world.camera.image_buffer)
+    # moved frame after moved frame: every REBUILD_EVERY-th one the device builds the refitted trees again; frames stay a fresh engine's
+    engine.REBUILD_EVERY = 2
+    for k in range(3):
+        for w in (world, fresh):
+            inst = next(i for i in w.instances if i.name == "bugatti stand-in")
+            inst.mesh.vertices = np.ascontiguousarray(inst.mesh.vertices * np.float32(1.0 + 0.05 * (k + 1)), dtype=np.float32)
+        world.mark_moved()
+        fresh._dirty = True
+        engine.renderWorld(world, cfg), reference.renderWorld(fresh, cfg)
+        assert np.array_equal(world.camera.image_buffer, fresh.camera.image_buffer), k
+    assert "build mesh trees (device)" in engine.context.timings() and engine._moved_frames == 4
     # on host trees the same call is an ordinary modification
     plain = build(False)
     host = Engine(0, streams=1)
@@ -315,7 +326,9 @@ def test_python_engine_refits_a_moved_world_on_the_device(built):
     deform(plain)
     plain.mark_moved()
     host.renderWorld(plain, cfg)
-    assert host.context.tree() == 0 and np.array_equal(plain.camera.image_buffer, fresh.camera.image_buffer)
+    again = build(True)
+    Engine(0, streams=1).renderWorld(again, cfg)
+    assert host.context.tree() == 0 and np.array_equal(plain.camera.image_buffer, again.camera.image_buffer)
 
 
 @pytest.mark.parametrize("device", [DEVICE, DEVICE_SAH])
@@ -359,3 +372,64 @@ def test_refit_reaches_the_meshes_that_are_one_leaf(built, device):
     fresh = _render(flat1, cam, cfg, 0)
     _same_frames(fresh, dev)
     assert not np.array_equal(fresh.read_depth(), _render(flat0, cam, cfg, 0).read_depth())
+
+
+def _twisted(v, turns):
+    """The vertices turned about the y axis by an angle that grows with y: what a refitted tree copes with badly."""
+    a = (v[:, 1] * np.float32(turns)).astype(np.float32)
+    c, s_ = np.cos(a).astype(np.float32), np.sin(a).astype(np.float32)
+    return np.ascontiguousarray(np.stack([c * v[:, 0] + s_ * v[:, 2], v[:, 1], -s_ * v[:, 0] + c * v[:, 2]], 1), dtype=np.float32)
+
+
+def test_rebuild_on_the_device_after_a_deformation(built):
+    """hiprz_rebuild_trees: a mesh is twisted through hiprz_update_triangles (its refitted tree keeps the old topology), then the device
+    builds the trees again over the vertices it holds — Morton order and SAH; frames stay those of a fresh upload of the twisted world,
+    further updates keep addressing triangles in the uploaded order, and twisting back gives the first frame again."""
+    def build(turns):
+        world = scenes.textured_sphere_scene(200, 120, resolution=96, map_size=64)
+        inst = next(i for i in world.instances if i.name == "bugatti stand-in")
+        if turns:
+            inst.mesh.vertices = _twisted(inst.mesh.vertices, turns)
+        return world
+    worlds = [build(0.0), build(4.0)]
+    flats = [flatten(w) for w in worlds]
+    cam = camera_struct(worlds[0].camera)
+    cfg = RenderConfig(tracing=Tracing(6, 4)).struct()
+    sphere = next(k for k, i in enumerate(worlds[0].instances) if i.name == "bugatti stand-in")
+    def records_in_uploaded_order(new):
+        """flat `new`'s triangles, mesh by mesh, in flats[0]'s order (meshes keep their ranges: same meshes, same counts)."""
+        order, done, seen = np.empty(len(flats[0].tris), dtype=np.int64), 0, set()
+        for inst in worlds[0].instances:
+            if inst.mesh is None or id(inst.mesh) in seen:
+                continue
+            seen.add(id(inst.mesh))
+            T = len(inst.mesh.tri_vertices)
+            where = np.empty(T, dtype=np.int64)
+            where[new.tris["source_index"][done:done + T]] = np.arange(T)
+            order[done:done + T] = done + where[flats[0].tris["source_index"][done:done + T]]
+            done += T
+        return new.tris[order], new.tri_attrs[order]
+    dev = _render(flats[0], cam, cfg, DEVICE_SAH)
+    first = (dev.read_accum().copy(), dev.read_depth().copy())
+    fresh = _render(flats[1], cam, cfg, 0)
+    def frames():
+        for n in (1, 5, 4):
+            dev.render(n)
+    dev.update_triangles(0, *records_in_uploaded_order(flats[1])), dev.update_instances(flats[1].instances)
+    frames()
+    _same_frames(fresh, dev)                       # refitted
+    for tree in (DEVICE, DEVICE_SAH):
+        dev.rebuild_trees(tree)
+        assert dev.tree() == tree
+        frames()
+        _same_frames(fresh, dev)                   # rebuilt over the twisted vertices
+        nodes, root, order, roots, refpos = dev.download_trees(len(flats[0].instances), len(flats[0].tris), len(flats[0].tlas_order))
+        assert sorted(refpos.tolist()) == list(range(len(flats[0].tris)))
+    print(dev.timings())
+    dev.update_triangles(0, flats[0].tris, flats[0].tri_attrs), dev.update_instances(flats[0].instances)   # back, over the rebuilt trees
+    frames()
+    assert np.array_equal(dev.read_accum(), first[0]) and np.array_equal(dev.read_depth(), first[1])
+    host = Context(0)
+    host.upload_scene(flats[0])
+    with pytest.raises(Exception):
+        host.rebuild_trees()                       # host-built trees: refused
