@@ -1257,6 +1257,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     }
     std::vector<uint32_t> order, roots;
     uint32_t n_nodes = 0u, tlas_root = 0u;
+    bool identity_order = false;
     if (tree != HIPRZ_TREE_REFERENCE && sc->n_tris != 0u) {
         const uint32_t max_nodes = sc->n_nodes + 2u * sc->n_tris + sc->n_instances + 1u;
         rebuilt_nodes.resize(max_nodes);
@@ -1269,17 +1270,24 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     }
     if (tree != HIPRZ_TREE_REFERENCE && sc->n_tris != 0u) {
         rebuilt_nodes.resize(n_nodes);
-        rebuilt_tris.resize(sc->n_tris), rebuilt_attrs.resize(sc->n_tris);
-        for (uint32_t i = 0; i < sc->n_tris; ++i) {
-            rebuilt_tris[i] = sc->tris[order[i]];
-            rebuilt_tris[i].pad0 = order[i];
-            rebuilt_attrs[i] = sc->tri_attrs[order[i]];
+        // (the placeholder trees of a device build keep the snapshot's order when its meshes lie in first-use order, as the hosts'
+        // flatteners lay them out: then the 144 bytes per triangle are not copied, and position i is what triangle i is ranked by)
+        identity_order = true;
+        for (uint32_t i = 0; i < sc->n_tris && identity_order; ++i) identity_order = order[i] == i;
+        if (!identity_order) {
+            rebuilt_tris.resize(sc->n_tris), rebuilt_attrs.resize(sc->n_tris);
+            for (uint32_t i = 0; i < sc->n_tris; ++i) {
+                rebuilt_tris[i] = sc->tris[order[i]];
+                rebuilt_tris[i].pad0 = order[i];
+                rebuilt_attrs[i] = sc->tri_attrs[order[i]];
+            }
         }
         rebuilt_instances.assign(sc->instances, sc->instances + sc->n_instances);
         for (uint32_t i = 0; i < sc->n_instances; ++i) rebuilt_instances[i].blas_root = roots[i];
         rebuilt_scene = *sc;
         rebuilt_scene.n_nodes = n_nodes, rebuilt_scene.nodes = rebuilt_nodes.data(), rebuilt_scene.tlas_root = tlas_root;
-        rebuilt_scene.tris = rebuilt_tris.data(), rebuilt_scene.tri_attrs = rebuilt_attrs.data(), rebuilt_scene.instances = rebuilt_instances.data();
+        if (!identity_order) rebuilt_scene.tris = rebuilt_tris.data(), rebuilt_scene.tri_attrs = rebuilt_attrs.data();
+        rebuilt_scene.instances = rebuilt_instances.data();
         sc = &rebuilt_scene;
         if (check_scene(sc, chk) != HIPRZ_OK) return fail(c, HIPRZ_ERR_INVALID, "upload_scene: rebuilt trees: " + chk.error);
         c->timings.set("rebuild mesh trees", timer.ms());
@@ -1347,7 +1355,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     for (uint32_t i = 0; i < sc->n_tris; ++i) {
         hiprz_tri& t = dtris[i];
         hiprz_tri_attr& a = dattrs[i];
-        if (!own_trees) t.pad0 = i;  // position in the reference's leaf order: what equally distant hits are ranked by
+        if (!own_trees || identity_order) t.pad0 = i;  // position in the reference's leaf order: what equally distant hits are ranked by
         a.pad0 = t.v2[0], a.pad1 = t.v2[1], a.pad2 = t.v2[2], a.pad3 = t.v3[0], a.pad4[0] = t.v3[1], a.pad4[1] = t.v3[2];
         for (int k = 0; k < 3; ++k) {
             const float v2 = t.v2[k], v3 = t.v3[k];
@@ -1377,7 +1385,7 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
                 const hiprz_node& leaf = sc->nodes[root];  // the placeholder of hiprz_rebuild_mesh_trees(.., HIPRZ_TREE_DEVICE, ..): one leaf per mesh
                 DeviceMesh m;
                 m.tri_first = leaf.begin, m.n_tris = leaf.meta & HIPRZ_NODE_COUNT_MASK;
-                m.ref_first = m.n_tris ? sc->tris[leaf.begin].pad0 : 0u;
+                m.ref_first = m.n_tris ? (identity_order ? leaf.begin : sc->tris[leaf.begin].pad0) : 0u;
                 m.leaf_slot = new_index[root];
                 std::memcpy(m.bb_min, leaf.bb_min, 12), std::memcpy(m.bb_max, leaf.bb_max, 12);
                 mesh_of_root[root] = uint32_t(device_meshes.size());

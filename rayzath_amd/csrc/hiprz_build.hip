@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "hiprz_ctx.hpp"
@@ -861,33 +862,46 @@ __global__ void __launch_bounds__(256) rz_sah_emit_kernel(SahViews v, EmitViews 
 bool validate_region(const std::vector<uint32_t>& rec64, uint32_t region, uint32_t n_slots, uint32_t tri_first, uint32_t n_tris, uint32_t max_leaf, std::string& why) {
     auto word = [&](uint32_t slot, uint32_t w) { return rec64[16 * size_t(slot - region) + w]; };
     auto inside = [&](uint32_t slot) { return slot >= region && slot < region + n_slots; };
-    std::vector<uint8_t> covered(n_tris, 0);
-    for (uint32_t o = 0; o < 8u; ++o) {
+    // one walk per ray octant, each on a thread of its own (the walks only read): 8 x n_slots dependent steps are what an upload with
+    // device-built trees waits for (config D: 16 ms on one thread)
+    const char* failed[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<uint8_t> covered(n_tris, 0);  // written by octant 0's walk only
+    auto walk = [&](uint32_t o) {
         std::vector<uint8_t> seen(n_slots, 0);
         uint32_t x = region, steps = 0;
         while (x != RZ_END) {
-            if (!inside(x)) return why = "link leaves the mesh's region", false;
-            if (seen[x - region]) return why = "a node is visited twice", false;
+            if (!inside(x)) return void(failed[o] = "link leaves the mesh's region");
+            if (seen[x - region]) return void(failed[o] = "a node is visited twice");
             seen[x - region] = 1;
-            if (++steps > n_slots) return why = "walk does not end", false;
+            if (++steps > n_slots) return void(failed[o] = "walk does not end");
             const uint32_t begin = word(x, 6), meta = word(x, 7);
             if (meta & HIPRZ_NODE_LEAF) {
                 const uint32_t count = meta & HIPRZ_NODE_COUNT_MASK;
-                if (begin < tri_first || uint64_t(begin) + count > uint64_t(tri_first) + n_tris || count == 0u || count > max_leaf) return why = "leaf range outside the mesh", false;
+                if (begin < tri_first || uint64_t(begin) + count > uint64_t(tri_first) + n_tris || count == 0u || count > max_leaf) return void(failed[o] = "leaf range outside the mesh");
                 if (o == 0u)
                     for (uint32_t t = begin; t < begin + count; ++t) {
-                        if (covered[t - tri_first]) return why = "two leaves share a triangle", false;
+                        if (covered[t - tri_first]) return void(failed[o] = "two leaves share a triangle");
                         covered[t - tri_first] = 1;
                     }
                 x = word(x, 8u + o);
             } else {
                 const uint32_t ptype = (meta >> HIPRZ_NODE_PTYPE_SHIFT) & 3u;
-                if (!inside(begin) || !inside(begin + 1u)) return why = "children outside the region", false;
+                if (!inside(begin) || !inside(begin + 1u)) return void(failed[o] = "children outside the region");
                 x = begin + ((o >> ptype) & 1u);
             }
         }
-        if (steps != n_slots) return why = "a walk misses nodes", false;
+        if (steps != n_slots) failed[o] = "a walk misses nodes";
+    };
+    if (n_slots < 4096u) {
+        for (uint32_t o = 0; o < 8u; ++o) walk(o);
+    } else {
+        std::thread threads[7];
+        for (uint32_t o = 1; o < 8u; ++o) threads[o - 1u] = std::thread(walk, o);
+        walk(0u);
+        for (auto& t : threads) t.join();
     }
+    for (uint32_t o = 0; o < 8u; ++o)
+        if (failed[o]) return why = failed[o], false;
     for (uint32_t t = 0; t < n_tris; ++t)
         if (!covered[t]) return why = "a triangle is in no leaf", false;
     return true;
