@@ -1459,6 +1459,11 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     d.shadow_variant = 0u;
     if (const char* v = std::getenv("HIPRZ_SHADOW_KEY")) d.shadow_variant = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_SORT_KEY")) d.sort_variant = uint32_t(std::atoi(v));
+    // instance level of the cooperative walks: in a world that is ONE leaf of at most 8 instances a lane that misses an instance's box
+    // tests the next one in the same round (D's trace kernel 836 -> 803 us, C unchanged; 4 and more: D 1 045 us and worse — the lanes
+    // reach the big mesh in different rounds, each as long as its longest walk); in deeper world trees it does not pay (E 2 957 -> 2 982 us)
+    d.walk_advance = c->flat_world ? 1u : 0u;
+    if (const char* v = std::getenv("HIPRZ_WALK_ADVANCE")) d.walk_advance = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_K")) d.walk_k = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_L")) d.walk_l = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_H")) d.walk_h = uint32_t(std::atoi(v));

@@ -96,6 +96,7 @@ struct DScene {
     uint32_t top_count;            // MODE 3: the first top_count nodes (+ their links) are staged in LDS by every workgroup
     const uint32_t* node_skip;     // link to the node that follows a node's subtree (same numbering as `nodes`)
     uint32_t walk_k, walk_l;       // MODE 3 mesh walk: node steps / triangle tests per lane per round (0 = unbounded)
+    uint32_t walk_advance;         // cooperative walks: further instance boxes a lane may test in one round while it has found none to enter
     uint32_t walk_h;               // cooperative walks: the node phase of a round ends as soon as this many lanes hold a leaf
     // front-to-back mesh walk (hiprz_set_walk_order): 64-B records = node (32 B) + its skip link under each of the 8
     // ray-direction octants
@@ -1234,14 +1235,19 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
         while (__any(i < end)) {
             bool enter = false;
             uint32_t inst = 0u;
-            if (i < end) {
-                inst = s.tlas_order[i];
-                float4 ib0, ib1;
-                load_instance_box(s, inst, ib0, ib1);
-                RZ_PHASE(1);
-                RZ_COUNT(box_tests);
-                enter = box_hit_unpacked<RCP>(ib0, ib1, g);
-                i += 1u;
+            // a lane tests the boxes of its leaf's instances, in the reference's order, until it meets one it enters — at most
+            // 1 + walk_advance of them before the wave goes on (0: one box per lane and round, every lane at the same instance)
+            for (uint32_t r = 0u;; ++r) {
+                if (!enter && i < end) {
+                    const uint32_t candidate = s.tlas_order[i];
+                    float4 ib0, ib1;
+                    load_instance_box(s, candidate, ib0, ib1);
+                    RZ_PHASE(1);
+                    RZ_COUNT(box_tests);
+                    if (box_hit_unpacked<RCP>(ib0, ib1, g)) enter = true, inst = candidate;
+                    i += 1u;
+                }
+                if (r >= s.walk_advance || !__any(!enter && i < end)) break;
             }
             if (!__any(enter)) continue;
             WalkRay lr;
@@ -1409,14 +1415,17 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
         while (__any(i < end)) {
             bool enter = false;
             uint32_t inst = 0u;
-            if (i < end) {
-                inst = s.tlas_order[i];
-                float4 ib0, ib1;
-                load_instance_box(s, inst, ib0, ib1);
-                RZ_COUNT(box_tests);
-                RZ_COUNT(shadow_box_tests);
-                enter = box_hit_unpacked<RCP>(ib0, ib1, g);
-                i += 1u;
+            for (uint32_t r = 0u;; ++r) {  // (as in closest_hit_coop)
+                if (!enter && i < end) {
+                    const uint32_t candidate = s.tlas_order[i];
+                    float4 ib0, ib1;
+                    load_instance_box(s, candidate, ib0, ib1);
+                    RZ_COUNT(box_tests);
+                    RZ_COUNT(shadow_box_tests);
+                    if (box_hit_unpacked<RCP>(ib0, ib1, g)) enter = true, inst = candidate;
+                    i += 1u;
+                }
+                if (r >= s.walk_advance || !__any(!enter && i < end)) break;
             }
             if (!__any(enter)) continue;
             WalkRay lr;
