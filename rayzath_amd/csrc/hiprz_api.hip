@@ -1459,11 +1459,17 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     d.shadow_variant = 0u;
     if (const char* v = std::getenv("HIPRZ_SHADOW_KEY")) d.shadow_variant = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_SORT_KEY")) d.sort_variant = uint32_t(std::atoi(v));
-    // instance level of the cooperative walks: in a world that is ONE leaf of at most 8 instances a lane that misses an instance's box
-    // tests the next one in the same round (D's trace kernel 836 -> 803 us, C unchanged; 4 and more: D 1 045 us and worse — the lanes
-    // reach the big mesh in different rounds, each as long as its longest walk); in deeper world trees it does not pay (E 2 957 -> 2 982 us)
-    d.walk_advance = c->flat_world ? 1u : 0u;
+    // The world and instance levels of the cooperative walks ("while-while" one and two levels above the mesh walk; the order in which a
+    // lane meets its instances stays the reference's).  World level: a lane steps through up to 1 + 8 nodes of the world tree per round
+    // until it HOLDS a leaf with instances, so that the expensive part — the ray into an instance's space, the mesh walk — runs for many
+    // lanes at once instead of for the few that happened to reach a leaf in this step (E, 46 instances: trace kernel 3 010 -> 2 678 us,
+    // shade + shadow 2 711 -> 2 636; 1 / 2 / 4 / 8 / 64 further steps: 2 992 / 2 892 / 2 798 / 2 712 / 2 716 us).  Instance level: a lane
+    // that misses an instance's box tests the next one in the same round (D 836 -> 803 us; with 4 and more D's lanes reach the big mesh
+    // in different rounds, each as long as its longest walk: 1 045 us and worse).  profiles/r03/ab_instance_advance.txt, ab_world_advance.txt
+    d.walk_advance = 1u;
+    d.world_advance = 8u;
     if (const char* v = std::getenv("HIPRZ_WALK_ADVANCE")) d.walk_advance = uint32_t(std::atoi(v));
+    if (const char* v = std::getenv("HIPRZ_WORLD_ADVANCE")) d.world_advance = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_K")) d.walk_k = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_L")) d.walk_l = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_WALK_H")) d.walk_h = uint32_t(std::atoi(v));

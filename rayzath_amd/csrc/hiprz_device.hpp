@@ -97,6 +97,7 @@ struct DScene {
     const uint32_t* node_skip;     // link to the node that follows a node's subtree (same numbering as `nodes`)
     uint32_t walk_k, walk_l;       // MODE 3 mesh walk: node steps / triangle tests per lane per round (0 = unbounded)
     uint32_t walk_advance;         // cooperative walks: further instance boxes a lane may test in one round while it has found none to enter
+    uint32_t world_advance;        // ... and further world-tree nodes a lane may step through while it holds no leaf
     uint32_t walk_h;               // cooperative walks: the node phase of a round ends as soon as this many lanes hold a leaf
     // front-to-back mesh walk (hiprz_set_walk_order): 64-B records = node (32 B) + its skip link under each of the 8
     // ray-direction octants
@@ -1217,21 +1218,32 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
     bool root_missed = false;
     while (__any(n != RZ_END)) {
         RZ_GUARD(guard);
-        uint32_t i = 0u, end = 0u, link = RZ_END;
-        bool descended = false;
-        if (n != RZ_END) {
-            float4 n0, n1;
-            fetch_node_ordered(s, n, 0u, n0, n1, link);  // the world tree keeps the reference's order
-            RZ_PHASE(0);
-            RZ_COUNT(box_tests);
-            if (box_hit_unpacked<RCP>(n0, n1, g)) {
-                const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
-                if (!(meta & HIPRZ_NODE_LEAF)) n = begin, descended = true;
-                else i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
-            } else if (n == s.tlas_root) {
-                root_missed = true, link = RZ_END;  // root box missed (cpu_engine_kernel.cpp:283): this lane's walk is over
+        // world level, in the reference's order: a lane steps through the nodes of the world tree until it HOLDS a leaf with instances
+        // (at most 1 + world_advance steps per round; 0: one step, then the wave turns to the lanes that hold a leaf), `after` = where
+        // it goes on behind that leaf
+        uint32_t i = 0u, end = 0u, after = RZ_END;
+        for (uint32_t r = 0u;; ++r) {
+            if (n != RZ_END && i == end) {
+                float4 n0, n1;
+                uint32_t link;
+                fetch_node_ordered(s, n, 0u, n0, n1, link);  // the world tree keeps the reference's order
+                RZ_PHASE(0);
+                RZ_COUNT(box_tests);
+                if (box_hit_unpacked<RCP>(n0, n1, g)) {
+                    const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+                    if (!(meta & HIPRZ_NODE_LEAF)) n = begin;
+                    else {
+                        i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK), after = link;
+                        if (i == end) n = link;  // (an empty leaf)
+                    }
+                } else {
+                    if (n == s.tlas_root) root_missed = true, link = RZ_END;  // root box missed (cpu_engine_kernel.cpp:283): this lane's walk is over
+                    n = link;
+                }
             }
+            if (r >= s.world_advance || !__any(n != RZ_END && i == end)) break;
         }
+        const bool held = i < end;
         while (__any(i < end)) {
             bool enter = false;
             uint32_t inst = 0u;
@@ -1298,7 +1310,7 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
                 g.far_ = lr.far_ / len;
             }
         }
-        if (n != RZ_END && !descended) n = link;
+        if (held) n = after;
     }
     ray.near_ = g.near_, ray.far_ = g.far_;
     if (!active || root_missed) return 0;
@@ -1397,21 +1409,28 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
     bool occluded = false;
     while (__any(n != RZ_END)) {
         RZ_GUARD(guard);
-        uint32_t i = 0u, end = 0u, link = RZ_END;
-        bool descended = false;
-        if (n != RZ_END) {
-            float4 n0, n1;
-            fetch_node_ordered(s, n, 0u, n0, n1, link);
-            RZ_COUNT(box_tests);
-            RZ_COUNT(shadow_box_tests);
-            if (box_hit_unpacked<RCP>(n0, n1, g)) {
-                const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
-                if (!(meta & HIPRZ_NODE_LEAF)) n = begin, descended = true;
-                else i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
-            } else if (n == s.tlas_root) {
-                link = RZ_END;  // root box missed (:402): clear
+        uint32_t i = 0u, end = 0u, after = RZ_END;  // (the world level as in closest_hit_coop)
+        for (uint32_t r = 0u;; ++r) {
+            if (n != RZ_END && i == end) {
+                float4 n0, n1;
+                uint32_t link;
+                fetch_node_ordered(s, n, 0u, n0, n1, link);
+                RZ_COUNT(box_tests);
+                RZ_COUNT(shadow_box_tests);
+                if (box_hit_unpacked<RCP>(n0, n1, g)) {
+                    const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+                    if (!(meta & HIPRZ_NODE_LEAF)) n = begin;
+                    else {
+                        i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK), after = link;
+                        if (i == end) n = link;
+                    }
+                } else {
+                    n = n == s.tlas_root ? RZ_END : link;  // root box missed (:402): clear
+                }
             }
+            if (r >= s.world_advance || !__any(n != RZ_END && i == end)) break;
         }
+        bool held = i < end;
         while (__any(i < end)) {
             bool enter = false;
             uint32_t inst = 0u;
@@ -1498,13 +1517,13 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
                     tj += c;
                     if (lds.res[deal.pos].x != 0.0f || (deal.big && lds.res[deal.pos + 1u].x != 0.0f)) {  // occluded: this lane's walk is over (:465 "TODO: texture fetch" -> mask 0)
                         occluded = true;
-                        tj = tj_end = 0u, m = RZ_END, i = end = 0u, n = RZ_END, link = RZ_END, descended = false;
+                        tj = tj_end = 0u, m = RZ_END, i = end = 0u, n = RZ_END, held = false;
                     }
                 }
                 rz_wave_sync();
             }
         }
-        if (n != RZ_END && !descended) n = link;
+        if (held) n = after;
     }
     return occluded ? 0.0f : 1.0f;
 }
