@@ -1207,7 +1207,9 @@ RZ_DEV void coop_closest_triangles(const DScene& s, const CoopLds& lds, bool hol
     rz_wave_sync();  // the next phase rewrites rec / res
 }
 
-template <bool COUNT, bool RCP>
+// ONE_STEP: the world level as one node step per round and nothing else (what a world that is one leaf needs; the register budget of the
+// 5-wave trace kernel is tight enough that the general form's extra live values cost config D 3.5 %: 799 -> 827 us)
+template <bool COUNT, bool RCP, bool ONE_STEP = false>
 RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ray& ray, Hit& hit, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
     WalkRay g;
@@ -1222,28 +1224,45 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
         // (at most 1 + world_advance steps per round; 0: one step, then the wave turns to the lanes that hold a leaf), `after` = where
         // it goes on behind that leaf
         uint32_t i = 0u, end = 0u, after = RZ_END;
-        for (uint32_t r = 0u;; ++r) {
-            if (n != RZ_END && i == end) {
+        bool descended = false;  // (ONE_STEP)
+        if constexpr (ONE_STEP) {
+            if (n != RZ_END) {
                 float4 n0, n1;
-                uint32_t link;
-                fetch_node_ordered(s, n, 0u, n0, n1, link);  // the world tree keeps the reference's order
+                fetch_node_ordered(s, n, 0u, n0, n1, after);
                 RZ_PHASE(0);
                 RZ_COUNT(box_tests);
                 if (box_hit_unpacked<RCP>(n0, n1, g)) {
                     const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
-                    if (!(meta & HIPRZ_NODE_LEAF)) n = begin;
-                    else {
-                        i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK), after = link;
-                        if (i == end) n = link;  // (an empty leaf)
-                    }
-                } else {
-                    if (n == s.tlas_root) root_missed = true, link = RZ_END;  // root box missed (cpu_engine_kernel.cpp:283): this lane's walk is over
-                    n = link;
+                    if (!(meta & HIPRZ_NODE_LEAF)) n = begin, descended = true;
+                    else i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
+                } else if (n == s.tlas_root) {
+                    root_missed = true, after = RZ_END;  // root box missed (cpu_engine_kernel.cpp:283): this lane's walk is over
                 }
             }
-            if (r >= s.world_advance || !__any(n != RZ_END && i == end)) break;
+        } else {
+            for (uint32_t r = 0u;; ++r) {
+                if (n != RZ_END && i == end) {
+                    float4 n0, n1;
+                    uint32_t link;
+                    fetch_node_ordered(s, n, 0u, n0, n1, link);  // the world tree keeps the reference's order
+                    RZ_PHASE(0);
+                    RZ_COUNT(box_tests);
+                    if (box_hit_unpacked<RCP>(n0, n1, g)) {
+                        const uint32_t begin = __float_as_uint(n1.z), meta = __float_as_uint(n1.w);
+                        if (!(meta & HIPRZ_NODE_LEAF)) n = begin;
+                        else {
+                            i = begin, end = begin + (meta & HIPRZ_NODE_COUNT_MASK), after = link;
+                            if (i == end) n = link;  // (an empty leaf)
+                        }
+                    } else {
+                        if (n == s.tlas_root) root_missed = true, link = RZ_END;  // root box missed (cpu_engine_kernel.cpp:283): this lane's walk is over
+                        n = link;
+                    }
+                }
+                if (r >= s.world_advance || !__any(n != RZ_END && i == end)) break;
+            }
         }
-        const bool held = i < end;
+        const bool held = !ONE_STEP && i < end;
         while (__any(i < end)) {
             bool enter = false;
             uint32_t inst = 0u;
@@ -1310,7 +1329,11 @@ RZ_DEV int closest_hit_coop(const DScene& s, const CoopLds& lds, bool active, Ra
                 g.far_ = lr.far_ / len;
             }
         }
-        if (held) n = after;
+        if constexpr (ONE_STEP) {
+            if (n != RZ_END && !descended) n = after;
+        } else {
+            if (held) n = after;
+        }
     }
     ray.near_ = g.near_, ray.far_ = g.far_;
     if (!active || root_missed) return 0;

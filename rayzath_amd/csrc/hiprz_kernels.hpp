@@ -469,7 +469,8 @@ __global__ void __launch_bounds__(64, MINW) rz_trace_skip_kernel(const DScene s,
 
 // The front-to-back walk with the cooperative triangle phase (hiprz_device.hpp: closest_hit_coop): one wave per workgroup, all
 // 64 lanes go through the walk together (a lane without a ray only helps with other lanes' triangles).
-template <bool FIRST, bool COUNT, int MINW>
+// ONE_LEAF_WORLD: the world tree is one leaf (hiprz_device.hpp: closest_hit_coop<..., ONE_STEP>).
+template <bool FIRST, bool COUNT, int MINW, bool ONE_LEAF_WORLD = false>
 __global__ void __launch_bounds__(64, MINW) rz_trace_coop_kernel(const DScene s, const DCamera cam, const DFrame f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
@@ -479,7 +480,7 @@ __global__ void __launch_bounds__(64, MINW) rz_trace_coop_kernel(const DScene s,
     Hit hit;
     hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
     int found = 0;
-    if (s.n_instances != 0u) found = closest_hit_coop<COUNT, RZ_TRACE_SHARED_RCP != 0>(s, CoopLds(rz_lds), p.active, ray, hit, cnt);
+    if (s.n_instances != 0u) found = closest_hit_coop<COUNT, RZ_TRACE_SHARED_RCP != 0, ONE_LEAF_WORLD>(s, CoopLds(rz_lds), p.active, ray, hit, cnt);
     if (p.active) {
         f.hit0[p.local] = make_float4(ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
         f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
