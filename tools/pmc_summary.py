@@ -7,7 +7,7 @@ import sys
 agg = collections.defaultdict(list)
 for path in sys.argv[1:]:
     for r in csv.DictReader(open(path)):
-        name = r["Kernel_Name"].split("(")[0][-40:]
+        name = r["Kernel_Name"].split("(")[0][-56:]
         agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(agg.items()):
     if any(t in k for t in ("rz_pass_kernel<false, false", "rz_trace_kernel<false, false", "rz_shade_kernel<false, false", "rz_batch_kernel<false",
