@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256, WAVES) rz_batch_kernel(const DScene scene
 // per pass against 130 us of work).  Here the passes of a wave follow each other without any barrier — a slow pass of one wave runs
 // beside the fast passes of the others, and the launch lasts as long as the slowest SUM of passes.  Per pixel the arithmetic is that of
 // the split kernels (cooperative front-to-back walk, then shade_segment), the accumulator grows by the same additions in the same order.
-template <bool COUNT, int SHADING, int MINW>
+template <bool COUNT, int SHADING, int MINW, bool ONE_LEAF_WORLD = false>
 __global__ void __launch_bounds__(64, MINW) rz_wave_batch_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f, uint32_t n_passes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
@@ -380,7 +380,7 @@ __global__ void __launch_bounds__(64, MINW) rz_wave_batch_kernel(const DScene s,
         Hit hit;
         hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
         int found = 0;
-        if (s.n_instances != 0u) found = closest_hit_coop<COUNT, RZ_TRACE_SHARED_RCP != 0>(s, CoopLds(rz_lds), p.active, ps.ray, hit, cnt);
+        if (s.n_instances != 0u) found = closest_hit_coop<COUNT, RZ_TRACE_SHARED_RCP != 0, ONE_LEAF_WORLD>(s, CoopLds(rz_lds), p.active, ps.ray, hit, cnt);
         if (p.active) {
             col4 final_color;
             bool path_continues;

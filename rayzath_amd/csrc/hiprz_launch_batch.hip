@@ -36,7 +36,10 @@ void launch_batch_t(hiprz_ctx* c, const DFrame& f, uint32_t n) {
     if (wave_resident(c) && reference_counters) g.mode = 1, g.walk_lds = g.stack_lds;
     if (wave_resident(c) && !reference_counters) {  // scenes that are not staged in LDS, without lights: single-wave workgroups walk cooperatively, pass after pass
         const dim3 wgrid(c->n_local_tiles * 4u), wblock(64);
-        if (c->n_textures == 0u) hipLaunchKernelGGL((rz_wave_batch_kernel<COUNT, RZ_SHADOW_PLAIN, 4>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
+        const bool one_leaf_world = c->dscene.n_instances != 0u && c->flat_world;  // (hiprz_launch_trace.hip: the plain one-step world level)
+        if (c->n_textures == 0u && one_leaf_world) hipLaunchKernelGGL((rz_wave_batch_kernel<COUNT, RZ_SHADOW_PLAIN, 4, true>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
+        else if (c->n_textures == 0u) hipLaunchKernelGGL((rz_wave_batch_kernel<COUNT, RZ_SHADOW_PLAIN, 4>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
+        else if (one_leaf_world) hipLaunchKernelGGL((rz_wave_batch_kernel<COUNT, RZ_SHADOW_NONE, 4, true>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
         else hipLaunchKernelGGL((rz_wave_batch_kernel<COUNT, RZ_SHADOW_NONE, 4>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
         return;
     }
