@@ -914,6 +914,11 @@ T* carve(unsigned char*& cursor, size_t count) {
     return p;
 }
 
+// leaves of at most this many triangles (experiments: HIPRZ_SAH_LEAF, 1 .. kSahSmall; the walks take a leaf's triangles 8 per round)
+uint32_t sah_leaf_max() {
+    if (const char* e = std::getenv("HIPRZ_SAH_LEAF")) return std::min(kSahSmall, std::max(1u, uint32_t(std::atoi(e))));
+    return kSahLeaf;
+}
 constexpr size_t sah_workspace_bytes(size_t n) {
     return 256u * 40u + n * 4u * (3u + 6u + 2u + 2u + 1u) + 2u * n * 4u * (6u + 6u + 2u) + (n / kSahSmall + 2u) * (3u * kSahBins * 7u * 4u + 8u) + n * 16u * 9u;
 }
@@ -936,8 +941,7 @@ int build_mesh_sah(hiprz_ctx* c, DeviceMesh& m, float4* blob_tris, float4* blob_
     v.counters = carve<uint32_t>(cursor, 8);
     float4* tris_tmp = carve<float4>(cursor, 3 * n);
     float4* attrs_tmp = carve<float4>(cursor, 6 * n);
-    v.leaf_max = kSahLeaf, v.traversal = kSahTraversal;
-    if (const char* e = std::getenv("HIPRZ_SAH_LEAF")) v.leaf_max = std::min(kSahLeaf, std::max(1u, uint32_t(std::atoi(e))));
+    v.leaf_max = sah_leaf_max(), v.traversal = kSahTraversal;
     if (const char* e = std::getenv("HIPRZ_SAH_COST")) v.traversal = float(std::atof(e));
     const uint32_t blocks = (m.n_tris + 255u) / 256u;
     hipLaunchKernelGGL(rz_sah_prepare_kernel, dim3(blocks), dim3(256), 0, st, v, make_float3(m.bb_min[0], m.bb_min[1], m.bb_min[2]),
@@ -1026,7 +1030,7 @@ int device_build_mesh_trees(hiprz_ctx* c, std::vector<DeviceMesh>& meshes, const
                 std::vector<uint32_t> rec(16 * size_t(m.n_slots));
                 RZ_HIP(c, hipMemcpy(rec.data(), c->nodes64.ptr + 16 * size_t(m.region), rec.size() * 4u, hipMemcpyDeviceToHost));
                 std::string why;
-                if (!validate_region(rec, m.region, m.n_slots, m.tri_first, m.n_tris, kSahLeaf, why))
+                if (!validate_region(rec, m.region, m.n_slots, m.tri_first, m.n_tris, sah_leaf_max(), why))
                     return fail(c, HIPRZ_ERR_DEVICE, "device-built mesh tree refused (" + why + ")");
             }
             continue;
