@@ -536,10 +536,15 @@ extern "C" int hiprz_rebuild_mesh_trees(const hiprz_scene* sc, uint32_t method, 
     std::vector<uint32_t> new_root(sc->n_nodes, 0xFFFFFFFFu);
     uint32_t tri_cursor = 0u;
     std::vector<uint8_t> tri_seen(sc->n_tris, 0);
+    // an instance without a mesh is in no leaf of the world tree (bvh.hpp:40-47) and is never entered: whatever its blas_root field holds
+    // (the hosts leave it 0, which is a node of the WORLD tree) is not a mesh
+    std::vector<uint8_t> in_world(sc->n_instances, 0);
+    for (uint32_t k = 0; k < sc->n_tlas_order; ++k)
+        if (sc->tlas_order[k] < sc->n_instances) in_world[sc->tlas_order[k]] = 1;
     for (uint32_t i = 0; i < sc->n_instances; ++i) {
         const uint32_t root = sc->instances[i].blas_root;
-        blas_roots_out[i] = root;
-        if (root >= sc->n_nodes) continue;  // an instance without mesh: never entered (left out of the world tree)
+        blas_roots_out[i] = in_world[i] ? root : 0xFFFFFFFFu;
+        if (!in_world[i] || root >= sc->n_nodes) continue;
         if (new_root[root] == 0xFFFFFFFFu) {
             uint32_t lo = 0xFFFFFFFFu, total = 0u;
             std::vector<uint32_t> walk{root};

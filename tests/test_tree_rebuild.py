@@ -73,3 +73,27 @@ def test_rebuilt_scene_is_valid_and_cheaper():
             assert seen > 0
             if seen > 64:
                 assert sah_cost(nodes, new_root) < sah_cost(flat.nodes, old_root), i
+
+
+def test_instances_without_a_mesh_are_not_meshes():
+    """An instance without a mesh is in no leaf of the world tree; the hosts leave its blas_root field 0 — a node of the WORLD tree, which a
+    rebuild once took for a mesh root (and refused the scene: "leaves of a mesh must tile one range").  Both placeholder kinds of the
+    rebuild must leave such instances alone (root = none) and give a valid scene."""
+    from rayzath_amd.scene import Instance
+    world = scenes.living_room(64, 48, 10)
+    world.add(Instance(None, [], position=(0.3, 0.4, 0.5), name="no mesh"))
+    world.instances.insert(2, Instance(None, [], position=(-0.3, 0.2, 0.1), name="no mesh either"))
+    flat = flatten(world)
+    meshless = [i for i, inst in enumerate(world.instances) if inst.mesh is None]
+    assert len(meshless) == 2 and not set(meshless) & set(flat.tlas_order.tolist())
+    for tree in (1, 2):
+        nodes, order, roots, tlas = rebuild(flat, tree)
+        assert all(int(roots[i]) == 0xFFFFFFFF for i in meshless)
+        assert sorted(order.tolist()) == list(range(len(flat.tris)))
+        inst = flat.instances.copy()
+        inst["blas_root"] = roots
+        new = FlatScene(nodes=nodes, tlas_root=tlas, tlas_order=flat.tlas_order, tris=flat.tris[order], tri_attrs=flat.tri_attrs[order], instances=inst,
+                        inst_materials=flat.inst_materials, materials=flat.materials, textures=flat.textures, texels=flat.texels,
+                        spot_lights=flat.spot_lights, direct_lights=flat.direct_lights)
+        msg = C.create_string_buffer(256)
+        assert _lib.load().hiprz_validate_scene(C.byref(new.struct), msg, 256) == 0, msg.value
