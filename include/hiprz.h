@@ -296,7 +296,9 @@ int hiprz_select_camera(hiprz_ctx* ctx, uint32_t index);
  * 0 .. world - 1 every `world` rows: a column of tiles, a row or a slanted line of the image is dealt to all shards in turn — a thin
  * expensive feature (a lamp post, the edge of a wall) does not land on one or two of them, as it does with unrotated numbers whenever
  * `world` divides the tiles per row (rayzath_amd/csrc/hiprz_shard.hpp; rayzath_amd/distributed.py mirrors it).  Global pixel ids and
- * seeds are unchanged, so results are identical for any world size.  Default rank 0 of 1. */
+ * seeds are unchanged, so results are identical for any world size.  Default rank 0 of 1.  A context over n devices / streams
+ * (hiprz_create_multi) renders the sub-shards rank * n + k of world * n, k = 0 .. n - 1 — which tile for tile is another set than shard
+ * `rank` of `world` of a one-part context: all contexts of a job must have the same number of parts. */
 int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
 
 /* Tree-walk variant of the pass kernels.  -1 (default) = chosen per scene; 1 = nested loops with a per-lane stack in LDS;
