@@ -63,3 +63,19 @@ def test_walk_levels_over_world_trees_of_many_shapes(built, monkeypatch, n_insta
     for world_advance, walk_advance in (("0", "0"), ("1", "3"), ("64", "64")):
         got = _frames(flat, cam, cfg, monkeypatch, env={"HIPRZ_WORLD_ADVANCE": world_advance, "HIPRZ_WALK_ADVANCE": walk_advance}, tree=3)
         _same(reference, got, f"world advance {world_advance}, instance advance {walk_advance}")
+
+
+@pytest.mark.parametrize("flags", [1 | 2 | 8 | 16 | 32, 63])
+def test_compat_integrator_over_every_kind_of_tree(built, monkeypatch, flags):
+    """The CUDA-compat integrator (hiprz_set_mode) walks the same way (rz_trace_coop_compat_kernel, the deferred shadow walk; flag 4 — the
+    coloured shadow mask — walks inside the shade kernel): its frames must not depend on the trees either, nor on the walk's levels."""
+    world = _world(33, True, seed=7)
+    for m in world.materials[:6]:
+        m.scattering = max(m.scattering, 0.05)    # every medium scatters a little: the compat draws run
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(LightSampling(2, 1), Tracing(5, 4)).struct()
+    reference = _frames(flat, cam, cfg, monkeypatch, mode=flags)
+    for tree in (1, 2, 3):
+        _same(reference, _frames(flat, cam, cfg, monkeypatch, mode=flags, tree=tree), f"tree {tree}")
+    _same(reference, _frames(flat, cam, cfg, monkeypatch, env={"HIPRZ_WORLD_ADVANCE": "0", "HIPRZ_WALK_ADVANCE": "0"}, mode=flags, tree=3), "levels off")
+    _same(reference, _frames(flat, cam, cfg, monkeypatch, mode=flags, pipeline=0), "one fused kernel per pass")
