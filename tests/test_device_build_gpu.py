@@ -186,7 +186,7 @@ def test_the_hosts_default_trees_fall_back_where_a_rebuild_is_impossible(built):
     world = scenes.textured_sphere_scene(200, 120, resolution=96, map_size=64)
     flat, cam = flatten(world), camera_struct(world.camera)
     cfg = RenderConfig(tracing=Tracing(6, 4)).struct()
-    # a second copy of the biggest mesh tree's nodes, entered by a twin of its instance (moved aside)
+    # a second copy of the biggest mesh tree's nodes
     roots = flat.instances["blas_root"]
     def subtree(root):
         out, stack = [], [int(root)]
@@ -206,15 +206,13 @@ def test_the_hosts_default_trees_fall_back_where_a_rebuild_is_impossible(built):
         if not (copy[k]["meta"] & _abi.NODE_LEAF):
             assert where[int(copy[k]["begin"]) + 1] == where[int(copy[k]["begin"])] + 1
             copy[k]["begin"] = where[int(copy[k]["begin"])]
-    twin = flat.instances[big:big + 1].copy()
-    twin["blas_root"] = where[int(roots[big])]
-    twin["position"][0] += np.float32(0.0)        # the same place: every hit is an exact tie between the two instances
-    mats = np.concatenate([flat.inst_materials, flat.inst_materials[int(twin["material_base"][0]):int(twin["material_base"][0]) + int(twin["material_count"][0])]])
-    twin["material_base"] = len(flat.inst_materials)
+    # another instance of the world (one with a mesh of its own) now enters the COPY: two distinct trees over the same triangles, both in use
+    other = next(k for k in flat.tlas_order.tolist() if k != big and int(roots[k]) != int(roots[big]) and int(roots[k]) < len(flat.nodes))
+    instances = flat.instances.copy()
+    instances["blas_root"][other] = where[int(roots[big])]
     snap = FlatScene(nodes=np.concatenate([flat.nodes, copy]), tlas_root=flat.tlas_root, tlas_order=flat.tlas_order, tris=flat.tris, tri_attrs=flat.tri_attrs,
-                     instances=np.concatenate([flat.instances, twin]), inst_materials=mats, materials=flat.materials, textures=flat.textures,
+                     instances=instances, inst_materials=flat.inst_materials, materials=flat.materials, textures=flat.textures,
                      texels=flat.texels, spot_lights=flat.spot_lights, direct_lights=flat.direct_lights)
-    # (the twin is in no world-tree leaf: it is never entered, but its tree makes the triangles shared)
     for tree in (1, DEVICE, DEVICE_SAH):
         with pytest.raises(HiprzError):
             _render(snap, cam, cfg, tree)
