@@ -431,3 +431,69 @@ def test_rebuild_on_the_device_after_a_deformation(built):
     host.upload_scene(flats[0])
     with pytest.raises(Exception):
         host.rebuild_trees()                       # host-built trees: refused
+
+
+@pytest.mark.parametrize("scene", ["textured sphere", "living room"])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_engine_through_a_random_sequence_of_changes(built, seed, scene):
+    """Two engines over twin worlds through the same random sequence — frames, moved frames (vertices and transformations), ordinary
+    modifications, camera moves, ray-cast pixel moves: one takes the hosts' defaults (device SAH trees, the moved path with a device
+    rebuild every third moved frame), the other the snapshot's trees and a full upload at every change.  After every step the images,
+    depth buffers, ray counts and ray casts agree."""
+    from rayzath_amd.engine import Engine
+    rng = np.random.default_rng(seed)
+    def build():   # one leaf of 8 instances and no lights / a world tree a few levels deep, lights, instanced meshes
+        return scenes.textured_sphere_scene(160, 96, resolution=64, map_size=32) if scene == "textured sphere" else scenes.living_room(160, 96, 40)
+    a_world, b_world = build(), build()
+    a, b = Engine(0, streams=1), Engine(0, streams=1)
+    a.REBUILD_EVERY = 3
+    b.set_tree(0)
+    cfg = RenderConfig(tracing=Tracing(5, 3))
+    def both(fn):
+        fn(a_world), fn(b_world)
+    def compare(step):
+        a.renderWorld(a_world, cfg), b.renderWorld(b_world, cfg)
+        ca, cb = a_world.camera, b_world.camera
+        assert np.array_equal(ca.image_buffer, cb.image_buffer) and np.array_equal(ca.depth_buffer, cb.depth_buffer), step
+        assert ca.ray_count == cb.ray_count, step
+        ia = a_world.instances.index(ca.raycasted_instance) if getattr(ca, "raycasted_instance", None) is not None else -1
+        ib = b_world.instances.index(cb.raycasted_instance) if getattr(cb, "raycasted_instance", None) is not None else -1
+        assert ia == ib, step
+    compare("first frame")
+    assert a.context.tree() == DEVICE_SAH and b.context.tree() == 0
+    for step in range(14):
+        op = int(rng.integers(0, 6))
+        amount = float(rng.uniform(0.02, 0.2))
+        which = int(rng.integers(0, len(a_world.instances)))
+        if op == 0:      # another frame of the same world: accumulation goes on
+            pass
+        elif op == 1:    # a mesh deforms, an instance moves: the moved path on one side, an ordinary modification on the other
+            def deform(w):
+                inst = max((i for i in w.instances if i.mesh is not None), key=lambda i: len(i.mesh.tri_vertices))
+                v = inst.mesh.vertices
+                inst.mesh.vertices = np.ascontiguousarray(v * np.float32(1.0 + amount) + np.sin(v[:, [2, 0, 1]] * 5.0).astype(np.float32) * np.float32(0.02), dtype=np.float32)
+                w.instances[which].position = (w.instances[which].position + np.float32(amount)).astype(np.float32)
+            both(deform)
+            a_world.mark_moved()
+            b_world._dirty = True
+        elif op == 2:    # only a transformation
+            def turn(w):
+                w.instances[which].rotation = (w.instances[which].rotation + np.float32(amount)).astype(np.float32)
+            both(turn)
+            a_world.mark_moved()
+            b_world._dirty = True
+        elif op == 3:    # an ordinary modification on both sides (a material's colour)
+            def paint(w):
+                m = w.materials[which % len(w.materials)]
+                m.color = (int(m.color[0]) ^ 0x40, m.color[1], m.color[2], m.color[3])
+                w._dirty = True
+            both(paint)
+        elif op == 4:    # the camera moves: both restart
+            def move(w):
+                w.camera.position = (w.camera.position + np.array([amount, 0.0, -amount], dtype=np.float32)).astype(np.float32)
+            both(move)
+        else:            # the ray-cast pixel moves: accumulation goes on
+            x, y = int(rng.integers(0, 160)), int(rng.integers(0, 96))
+            both(lambda w: w.camera.ray_cast_at(x, y) if hasattr(w.camera, "ray_cast_at") else None)
+        compare(f"step {step} op {op}")
+    assert "refit mesh trees (device)" in a.context.timings()
