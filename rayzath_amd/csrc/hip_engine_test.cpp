@@ -170,6 +170,80 @@ int main(int argc, char** argv) {
             return 1;
         }
     }
+    if (mode == "sequence") {  // two engines over twin worlds through one random sequence of changes: the hosts' defaults against snapshot trees + full uploads
+        try {
+            const unsigned seed = argc > 3 ? unsigned(std::atoi(argv[3])) : 1u;
+            uint32_t state = 0x9E3779B9u * (seed + 1u);
+            auto rnd = [&]() { return state = state * 1664525u + 1013904223u, state >> 8; };
+            auto grid = [](int n) {
+                auto m = std::make_shared<Mesh>();
+                for (int j = 0; j <= n; ++j)
+                    for (int i = 0; i <= n; ++i) m->createVertex(float(i) / n - 0.5f, 0.05f * std::sin(9.0f * i / n) * std::cos(7.0f * j / n), float(j) / n - 0.5f);
+                for (int j = 0; j < n; ++j)
+                    for (int i = 0; i < n; ++i) {
+                        const uint32_t a = uint32_t(j * (n + 1) + i), b = a + 1, c = a + uint32_t(n + 1), d = c + 1;
+                        m->createTriangle({a, c, b}), m->createTriangle({b, c, d});
+                    }
+                return m;
+            };
+            auto scene = [&](World& w) {
+                build(w, 96, 64);
+                auto sheet = grid(40);
+                w.meshes.push_back(sheet);
+                instance(w, sheet, w.materials[4], {0.1f, 0.9f, 0.3f}, {0.5f, 0.2f, 0.1f}, {1.6f, 1.6f, 1.6f});
+                auto lamp = std::make_shared<SpotLight>();
+                lamp->position = {0.5f, 2.5f, -0.5f}, lamp->direction = {-0.2f, -1.0f, 0.3f}, lamp->emission = 40.0f;
+                w.spot_lights.push_back(lamp);
+            };
+            World a_world, b_world;
+            scene(a_world), scene(b_world);
+            RenderConfig cfg;
+            cfg.tracing.max_depth = 4, cfg.tracing.rpp = 2;
+            Engine a(0, 1), b(0, 1);
+            a.tree(HIPRZ_TREE_DEVICE_SAH);  // (the hosts' default would keep the snapshot's trees for a scene this small)
+            b.tree(HIPRZ_TREE_REFERENCE);
+            bool ok = true;
+            int moved = 0, shaded = 0;
+            for (int step = 0; step < 24 && ok; ++step) {
+                const uint32_t op = step == 0 ? 0u : rnd() % 6u;
+                const float amount = 0.02f + 0.01f * float(rnd() % 16u);
+                const size_t which = rnd() % a_world.instances.size();
+                for (World* w : {&a_world, &b_world}) {
+                    const bool first = w == &a_world;
+                    if (op == 1u) {  // vertices and a transformation move
+                        auto& v = w->meshes.back()->vertices;
+                        for (size_t k = 0; k < v.size(); k += 3) v[k + 1] = v[k + 1] * (1.0f + amount) + 0.02f * std::sin(13.0f * v[k]);
+                        w->instances[which]->position.x += amount;
+                        first ? w->makeMoved() : w->makeModified();
+                    } else if (op == 2u) {  // only a transformation
+                        w->instances[which]->rotation.y += amount;
+                        first ? w->makeMoved() : w->makeModified();
+                    } else if (op == 3u) {  // materials only: replaced in place on the first engine
+                        w->materials[which % w->materials.size()]->color.green = uint8_t(w->materials[which % w->materials.size()]->color.green ^ 0x30);
+                        first ? w->makeShadingModified() : w->makeModified();
+                    } else if (op == 4u) {  // a moved frame AND a material change in one call
+                        w->instances[which]->position.z -= amount;
+                        w->spot_lights[0]->emission += 5.0f;
+                        first ? (w->makeMoved(), w->makeShadingModified()) : w->makeModified();
+                    } else if (op == 5u) {  // the camera
+                        w->camera.position.x += amount;
+                        w->camera.makeModified();
+                    }
+                }
+                moved += op == 1u || op == 2u || op == 4u, shaded += op == 3u || op == 4u;
+                a.renderWorld(a_world, cfg), b.renderWorld(b_world, cfg);
+                ok = a_world.camera.image_buffer == b_world.camera.image_buffer && a_world.camera.depth_buffer == b_world.camera.depth_buffer &&
+                     a_world.camera.ray_count == b_world.camera.ray_count;
+                if (!ok) std::printf("step %d op %u: DIFFERENT\n", step, op);
+            }
+            const bool refitted = a.timingsString().find("refit mesh trees (device)") != std::string::npos;
+            std::printf("sequence %s (%d moved frames, %d shading changes, %s)\n", ok ? "equal" : "DIFFERENT", moved, shaded, refitted ? "refitted on the device" : "never refitted");
+            return ok && (moved == 0 || refitted) ? 0 : 1;
+        } catch (const Exception& e) {
+            std::fprintf(stderr, "Hip::Exception %d: %s\n", e.code, e.what());
+            return 1;
+        }
+    }
     FILE* out = std::fopen(argv[2], "wb");
     if (!out) return std::perror("open"), 2;
     World world;

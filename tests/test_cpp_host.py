@@ -91,6 +91,15 @@ def test_cpp_engine_refits_a_moved_world_on_the_device(built):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_cpp_engines_agree_through_a_random_sequence_of_changes(built, seed):
+    """Hip::Engine with device trees (moved frames through the refit, materials / lights in place, a rebuild now and then) against
+    Hip::Engine on the snapshot's trees with a full upload at every change, twin worlds, 24 random steps: images, depths, ray counts."""
+    proc = subprocess.run([EXE, "sequence", "-", str(seed)], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0 and "sequence equal" in proc.stdout and "DIFFERENT" not in proc.stdout, proc.stdout + proc.stderr
+
+
+@pytest.mark.gpu
 def test_cpp_engine_reuploads_when_a_material_is_repointed_at_another_uploaded_map(built):
     """World::makeShadingModified() after two materials swapped their (already uploaded) textures: the map indices of the in-place path
     are positions in the uploaded texture list, so the engine has to notice that the first-use order changed and upload the scene again."""
