@@ -305,7 +305,9 @@ def main():
             # dominant (only) kernel: the resident batch kernel — one launch takes every tile through the RPP passes of the
             # step.  Algorithmic bytes: SURVEY.md §8d's per-segment figure x the segments of the launch.  It walks in the
             # reference's order: executed work == the reference algorithm's work.
-            kernel_name = "rz_batch_kernel (resident: all passes of a step)"
+            # (scenes staged in LDS: rz_batch_kernel, a workgroup per tile, the reference's visiting order; scenes that are not: rz_wave_batch_kernel,
+            # a wave per 8x8 pixels on the cooperative front-to-back walk — `counters` are then the tests that walk executes)
+            kernel_name = "rz_batch_kernel (resident: all passes of a step)" if ctx.traversal_mode() != 3 else "rz_wave_batch_kernel (per-wave resident: all passes of a step)"
             # duration: the hip events the context records on its stream around EVERY render batch of the timed repeats (the batch
             # kernel + the one-thread kernel that advances the pass index) — the launches `value` was timed on, not a separate run
             kernel_s = kernel_ms / 1e3 / max(launches // RPP, 1)

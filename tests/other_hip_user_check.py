@@ -15,6 +15,7 @@ ctx = Context(0)
 ctx.upload_scene(flat); ctx.upload_camera(cam); ctx.set_config(RenderConfig(tracing=Tracing(8, 8)).struct())
 if os.environ.get("NOGRAPH"): ctx.set_graph(False)
 if os.environ.get("NOSORT"): ctx.set_ray_sort(0)
+if os.environ.get("PIPELINE"): ctx.set_pipeline(int(os.environ["PIPELINE"]))
 if os.environ.get("CFG"): pass
 def fence(): ctx.sync(); torch.cuda.synchronize()
 ctx.render(1)
