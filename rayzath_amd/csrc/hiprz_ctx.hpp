@@ -192,12 +192,12 @@ struct hiprz_ctx : hiprz_frame_state {
     // than fused on configs C, D; the resident kernel has no LDS room for the tree-top cache).
     int pipeline_setting = -1;
     int pipeline = 1;  // resolved by resolve_pipeline() at upload / set time and before a render call
-    uint32_t wave_resident_max = 40000u;  // HIPRZ_WAVE_RESIDENT_MAX: scenes without lights that are not staged in LDS run the resident pipeline
-                                         // (rz_wave_batch_kernel) while a shard has at most this many waves — a whole 1080p frame is 32 400.
-                                         // Measured on MI355X, split / resident, ms per step of 8 passes: an eighth of a frame C 1.18 / 0.61,
-                                         // D 3.78 / 2.69; half C 2.46 / 1.86, D 5.79 / 3.91; a whole frame, since the walk's instance level
-                                         // (round 3): C 3.69 / 3.38, D 7.28 / 7.19 (it was C 3.78 / 3.82 before).  Frames of more waves (4K) keep
-                                         // the split pipeline with its sorted rays: not measured
+    uint32_t wave_resident_max = 1u << 30;  // HIPRZ_WAVE_RESIDENT_MAX: scenes without lights that are not staged in LDS run the resident pipeline
+                                         // (rz_wave_batch_kernel) while a shard has at most this many waves — no limit since the end of round 3.
+                                         // Measured on MI355X, split / resident, ms per step of 8 passes: an eighth of a 1080p frame C 1.18 /
+                                         // 0.61, D 3.78 / 2.69; half C 2.46 / 1.86, D 5.79 / 3.91; a whole frame (32 400 waves), since the walk's
+                                         // instance level: C 3.69 / 3.38, D 7.28 / 7.19 (it was C 3.78 / 3.82 before); a 4K frame (129 600 waves):
+                                         // C 14.26 / 12.73, D 27.26 / 27.18
     // device-built trees (hiprz_set_tree(HIPRZ_TREE_DEVICE), hiprz_build.hip): the 32-byte node records of the whole scene in a buffer of
     // their own (the hot blob's node section only holds the uploaded prefix), the workspaces of build and refit, the meshes
     hiprz::DeviceArray<uint8_t> dev_nodes, has_mesh, build_temp;
