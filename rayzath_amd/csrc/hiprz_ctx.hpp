@@ -197,7 +197,8 @@ struct hiprz_ctx : hiprz_frame_state {
                                          // Measured on MI355X, split / resident, ms per step of 8 passes: an eighth of a 1080p frame C 1.18 /
                                          // 0.61, D 3.78 / 2.69; half C 2.46 / 1.86, D 5.79 / 3.91; a whole frame (32 400 waves), since the walk's
                                          // instance level: C 3.69 / 3.38, D 7.28 / 7.19 (it was C 3.78 / 3.82 before); a 4K frame (129 600 waves):
-                                         // C 14.26 / 12.73, D 27.26 / 27.18
+                                         // C 14.26 / 12.73, D 27.26 / 27.18.  (The kernel keeps the register budget of 4 waves per SIMD: with 5 — what
+                                         // D's trace kernel likes — the shading spills: D 7.18 -> 7.51, C 3.38 -> 3.81 ms per step.)
     // device-built trees (hiprz_set_tree(HIPRZ_TREE_DEVICE), hiprz_build.hip): the 32-byte node records of the whole scene in a buffer of
     // their own (the hot blob's node section only holds the uploaded prefix), the workspaces of build and refit, the meshes
     hiprz::DeviceArray<uint8_t> dev_nodes, has_mesh, build_temp;
