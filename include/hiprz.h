@@ -405,7 +405,8 @@ int hiprz_set_lds_scene(hiprz_ctx* ctx, int mode);
  * kernel, with a 20-byte hit record per pixel passed through device memory; 0 = per pass one fused kernel;
  * 2 = resident: ONE kernel per hiprz_render call — a workgroup takes its 32x8 tile through all the passes, path state
  * and accumulator stay on chip, the tone-mapped pixel is written on the way out (hiprz_tonemap then has nothing to do);
- * -1 (default) = 2 for scenes staged in LDS, else 1.  Identical results. */
+ * -1 (default) = 2 for scenes staged in LDS and for scenes without lights (those run per-wave chains of passes on the cooperative
+ * walk), else 1.  Identical results. */
 int hiprz_set_pipeline(hiprz_ctx* ctx, int pipeline);
 int hiprz_pipeline(hiprz_ctx* ctx, int* effective_pipeline_out); /* valid after hiprz_upload_scene */
 /* Reorder rays between passes (split pipeline): the shade kernel emits a sort key per pixel (cell of the next
