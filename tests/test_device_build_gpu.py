@@ -445,6 +445,10 @@ def test_engine_through_a_random_sequence_of_changes(built, seed, scene):
     def build():   # one leaf of 8 instances and no lights / a world tree a few levels deep, lights, instanced meshes
         return scenes.textured_sphere_scene(160, 96, resolution=64, map_size=32) if scene == "textured sphere" else scenes.living_room(160, 96, 40)
     a_world, b_world = build(), build()
+    for w in (a_world, b_world):   # a second, smaller camera: every enabled camera is rendered per call, each with a frame state of its own
+        second = scenes._camera(96, 64)
+        second.position = (second.position + np.array([0.6, 0.2, 0.3], dtype=np.float32)).astype(np.float32)
+        w.cameras.append(second)
     a, b = Engine(0, streams=1), Engine(0, streams=1)
     a.REBUILD_EVERY = 3
     b.set_tree(0)
@@ -453,9 +457,10 @@ def test_engine_through_a_random_sequence_of_changes(built, seed, scene):
         fn(a_world), fn(b_world)
     def compare(step):
         a.renderWorld(a_world, cfg), b.renderWorld(b_world, cfg)
+        for ca, cb in zip([a_world.camera] + a_world.cameras, [b_world.camera] + b_world.cameras):
+            assert np.array_equal(ca.image_buffer, cb.image_buffer) and np.array_equal(ca.depth_buffer, cb.depth_buffer), step
+            assert ca.ray_count == cb.ray_count, step
         ca, cb = a_world.camera, b_world.camera
-        assert np.array_equal(ca.image_buffer, cb.image_buffer) and np.array_equal(ca.depth_buffer, cb.depth_buffer), step
-        assert ca.ray_count == cb.ray_count, step
         ia = a_world.instances.index(ca.raycasted_instance) if getattr(ca, "raycasted_instance", None) is not None else -1
         ib = b_world.instances.index(cb.raycasted_instance) if getattr(cb, "raycasted_instance", None) is not None else -1
         assert ia == ib, step
