@@ -300,6 +300,24 @@ int hiprz_select_camera(hiprz_ctx* ctx, uint32_t index);
  * (hiprz_create_multi) renders the sub-shards rank * n + k of world * n, k = 0 .. n - 1 — which tile for tile is another set than shard
  * `rank` of `world` of a one-part context: all contexts of a job must have the same number of parts. */
 int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
+/* How the n parts (devices / streams) of a hiprz_create_multi context divide the context's share of the frame (tiles with a
+ * gather, "or per-sample reduce").  The reference has nothing to mirror (one device: cuda_engine_core.cu:17).
+ * HIPRZ_SHARD_TILES (default): part k renders sub-shard rank * n + k of world * n of the interleaved tiles; frames are the one-device frame
+ * bit for bit whatever n is, a frame of `rpp` passes arrives sooner — but a part's step lasts as long as the longest per-tile chain of
+ * passes, which caps the kernel-side speed-up of 8 parts at 5.1 - 5.6 (2.7 with one hot image region).
+ * HIPRZ_SHARD_SAMPLES: EVERY part renders the context's whole share, part k on the seed stream `config.seed + k` (hiprz_seed_value), and
+ * the parts' accumulators are SUMMED (colour sums and finished-path counts alike, in part order: deterministic) wherever the frame leaves
+ * the context: hiprz_tonemap tone-maps the sum, hiprz_read_accum / hiprz_export_accum_tiles return it (ONE tile-major slice of the share),
+ * hiprz_read_rgba8 / hiprz_export_rgba8_tiles the tone-mapped sum, hiprz_ray_count the rays of all parts (n * passes * pixels);
+ * hiprz_read_depth, hiprz_read_state, hiprz_ray_cast and hiprz_pass_count answer for part 0 (the first-pass depth is every part's).
+ * A call of hiprz_render(p) therefore adds n * p samples per pixel.  The frame equals the sum of n one-part frames rendered with the
+ * seeds seed .. seed + n - 1 — the same for a given n, another one for another n.  Changing the mode restarts accumulation.
+ * Processes that sample-shard a frame between them give each context its own `config.seed` (rank * n apart) and reduce the exported
+ * accumulators (rayzath_amd/distributed.py: ShardedFrame.reduce, one ncclReduce(sum) per readback). */
+#define HIPRZ_SHARD_TILES 0u
+#define HIPRZ_SHARD_SAMPLES 1u
+int hiprz_set_shard_mode(hiprz_ctx* ctx, uint32_t mode);
+int hiprz_shard_mode(hiprz_ctx* ctx, uint32_t* mode_out);
 
 /* Tree-walk variant of the pass kernels.  -1 (default) = chosen per scene; 1 = nested loops with a per-lane stack in LDS;
  * 2 = workgroup-binned (rays advance in rounds, the (ray, instance) visits of a round are compacted and sorted by instance
@@ -468,6 +486,8 @@ int hiprz_untile_gathered(hiprz_ctx* ctx, const void* src_parts, uint32_t world,
                           void* dst_device_image, void* stream);
 /* Tone-map a row-major W*H float4 device image into W*H RGBA8 (device pointers). */
 int hiprz_tonemap_image(hiprz_ctx* ctx, const void* src_device_image, void* dst_device_rgba8);
+/* The same on `stream` (a hipStream_t; NULL = the context's stream): the stream a reduce of the accumulators ran on. */
+int hiprz_tonemap_image_on(hiprz_ctx* ctx, const void* src_device_image, void* dst_device_rgba8, void* stream);
 void* hiprz_stream(hiprz_ctx* ctx); /* the hipStream_t all of the above are enqueued on */
 
 /* --- picking (Kernel::rayCast, cpu_engine_kernel.cpp:102-111, 483-501; Cuda: cuda_render_kernel.cu:130-144) ---

@@ -112,6 +112,8 @@ ENTRY_POINTS = {
     "hiprz_upload_camera": (C.c_int, [P, C.POINTER(Camera)]),
     "hiprz_set_config": (C.c_int, [P, C.POINTER(Config)]),
     "hiprz_set_shard": (C.c_int, [P, U32, U32]),
+    "hiprz_set_shard_mode": (C.c_int, [P, U32]),
+    "hiprz_shard_mode": (C.c_int, [P, C.POINTER(U32)]),
     "hiprz_set_traversal_mode": (C.c_int, [P, C.c_int]),
     "hiprz_set_walk_order": (C.c_int, [P, C.c_int]),
     "hiprz_set_mode": (C.c_int, [P, U32]),
@@ -155,6 +157,7 @@ ENTRY_POINTS = {
     "hiprz_untile_rgba8": (C.c_int, [P, P, U32, U32, P]),
     "hiprz_untile_accum": (C.c_int, [P, P, U32, U32, P]),
     "hiprz_tonemap_image": (C.c_int, [P, P, P]),
+    "hiprz_tonemap_image_on": (C.c_int, [P, P, P, P]),
     "hiprz_stream": (P, [P]),
     "hiprz_pick": (C.c_int, [P, U32, U32, C.POINTER(I32), C.POINTER(I32)]),
     "hiprz_ray_cast": (C.c_int, [P, U32, U32, C.POINTER(RayCast)]),

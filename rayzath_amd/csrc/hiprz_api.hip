@@ -46,6 +46,20 @@ __global__ void __launch_bounds__(256) rz_tonemap_image_kernel(const float4* ima
     rgba8[i] = tonemap(col4{a.x, a.y, a.z, a.w}, aperture, exposure_time);
 }
 
+// HIPRZ_SHARD_SAMPLES: the parts of a context rendered the same pixels on different seed streams; what leaves the context is the sum of
+// their accumulators (colour sums and finished-path counts), taken in part order — own + staged[0] + staged[1] + ... — so that the
+// result does not depend on when a part finished
+__global__ void __launch_bounds__(256) rz_sum_parts_kernel(const float4* own, const float4* staged, size_t stride, uint32_t n_staged, float4* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    float4 a = own[i];
+    for (uint32_t r = 0; r < n_staged; ++r) {
+        const float4 b = staged[size_t(r) * stride + i];
+        a.x += b.x, a.y += b.y, a.z += b.z, a.w += b.w;
+    }
+    out[i] = a;
+}
+
 // tile-major (owned tiles of shard rank/world) -> row-major full frame
 template <typename T>
 __global__ void __launch_bounds__(256) rz_untile_kernel(const T* tiles, T* image, uint32_t width, uint32_t height,
@@ -272,7 +286,7 @@ void release_frame(hiprz_frame_state* c) {
     c->sort_keys.release(), c->sort_perm.release();
     for (auto& t : c->sort_temp) t.keys_out.release(), t.vals_a.release(), t.vals_b.release(), t.counts.release(), t.digit_total.release();
     c->shadow_keys.release(), c->shadow_perm.release();
-    c->image_f4.release(), c->state_md.release(), c->state_ray.release(), c->gather.release();
+    c->image_f4.release(), c->state_md.release(), c->state_ray.release(), c->gather.release(), c->sum_accum.release();
 }
 
 // Camera::reproject (cuda_camera.cuh:390-426) for one pixel of the frame that has just had its first pass: the first hit point —
@@ -331,6 +345,7 @@ bool keep_history(hiprz_ctx* c) {
 // every device's tiles over the peer-to-peer path of the readbacks — as row-major images on the head, then a copy to every peer.
 int assemble_history(hiprz_ctx* c) {
     if (c->peers.empty() || !(c->mode_flags & HIPRZ_COMPAT_REPROJECTION) || !c->reset_pending || !c->frame_started || !c->have_camera) return HIPRZ_OK;
+    if (c->shard_mode == HIPRZ_SHARD_SAMPLES) return HIPRZ_OK;  // every part holds the context's whole share: each keeps its own history (keep_history)
     (void)hipSetDevice(c->device);
     const size_t n = size_t(c->camera.width) * c->camera.height;
     RZ_HIP(c, c->prev_accum.resize(n));
@@ -772,7 +787,7 @@ int read_untiled(hiprz_ctx* c, const T* tiles, T* dst, size_t bytes, const char*
     // the shards of this context cover the whole frame unless the caller split it further (hiprz_set_shard): only then are there
     // pixels nobody writes, and only then is the image cleared first
     if (c->user_world > 1u) RZ_HIP(c, hipMemsetAsync(image, 0, bytes, c->stream));
-    if (c->peers.empty()) {
+    if (c->peers.empty() || c->shard_mode == HIPRZ_SHARD_SAMPLES) {  // (sample mode: `tiles` is the head's own / the summed buffer of the whole share)
         if (c->n_local_tiles)
             hipLaunchKernelGGL((rz_untile_kernel<T>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, tiles, image,
                                c->camera.width, c->camera.height, c->tiles_x, c->rank, c->world);
@@ -1028,8 +1043,44 @@ namespace {
 size_t part_capacity(const hiprz_ctx* c) {  // pixels per slice: the largest sub-shard of the job (the lowest ranks own one tile more)
     return size_t(shard_local_tiles(c->tiles_x, c->tiles_y, 0u, c->world)) * 256u;  // c->world is already user_world * parts on a multi-device head
 }
+bool samples_head(const hiprz_ctx* c) { return c->shard_mode == HIPRZ_SHARD_SAMPLES && !c->peers.empty(); }
+// HIPRZ_SHARD_SAMPLES head: out = the sum of the parts' accumulators over the context's share (tile-major, n_local_tiles * 256 pixels).
+// Every peer pushes its accumulators into its slice of the head's staging buffer on ITS stream, behind its own rendering (peer-to-peer
+// over xGMI for another device), the head's stream waits for all of them and one launch adds them up in part order.  A peer's next push
+// waits for that launch (sum_done): nothing here synchronises with the host.
+int sum_parts(hiprz_ctx* c, float4* out) {
+    const size_t n = size_t(c->n_local_tiles) * 256u;
+    if (!n) return HIPRZ_OK;
+    (void)hipSetDevice(c->device);
+    const uint32_t n_staged = uint32_t(c->peers.size());
+    RZ_HIP(c, c->gather.resize(n * n_staged * sizeof(float4)));
+    float4* staged = reinterpret_cast<float4*>(c->gather.ptr);
+    if (!c->sum_done) RZ_HIP(c, hipEventCreateWithFlags(&c->sum_done, hipEventDisableTiming));
+    for (uint32_t r = 0; r < n_staged; ++r) {
+        hiprz_ctx* p = c->peers[r];
+        if (p->n_local_tiles != c->n_local_tiles || !p->accum.ptr) return fail(c, HIPRZ_ERR_STATE, "sample sharding: a part's share differs from the head's");
+        (void)hipSetDevice(p->device);
+        if (c->sum_recorded) RZ_HIP(c, hipStreamWaitEvent(p->stream, c->sum_done, 0));
+        RZ_HIP(c, hipMemcpyPeerAsync(staged + n * r, c->device, p->accum.ptr, p->device, n * sizeof(float4), p->stream));
+        RZ_HIP(c, hipEventRecord(p->peer_done, p->stream));
+        (void)hipSetDevice(c->device);
+        RZ_HIP(c, hipStreamWaitEvent(c->stream, p->peer_done, 0));
+    }
+    hipLaunchKernelGGL(rz_sum_parts_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->accum.ptr, staged, n, n_staged, out, uint32_t(n));
+    RZ_HIP(c, hipGetLastError());
+    RZ_HIP(c, hipEventRecord(c->sum_done, c->stream));
+    c->sum_recorded = true;
+    return HIPRZ_OK;
+}
 template <typename T, typename Tiles>
 int export_tiles(hiprz_ctx* c, void* dst_device, size_t bytes, const char* what, Tiles tiles_of) {
+    if (c->shard_mode == HIPRZ_SHARD_SAMPLES) {  // one slice: the head's buffer of the whole share (the caller summed / tone-mapped the parts into it)
+        const size_t own = size_t(c->n_local_tiles) * 256u * sizeof(T);
+        if (!dst_device || bytes < own) return fail(c, HIPRZ_ERR_INVALID, std::string(what) + ": destination too small");
+        (void)hipSetDevice(c->device);
+        if (own) RZ_HIP(c, hipMemcpyAsync(dst_device, tiles_of(c), own, hipMemcpyDeviceToDevice, c->stream));
+        return HIPRZ_OK;
+    }
     const uint32_t n_parts = uint32_t(c->peers.size()) + 1u;
     const size_t cap = c->peers.empty() ? size_t(c->n_local_tiles) * 256u : part_capacity(c);
     if (!dst_device || bytes < cap * n_parts * sizeof(T)) return fail(c, HIPRZ_ERR_INVALID, std::string(what) + ": destination too small");
@@ -1198,6 +1249,7 @@ int hiprz_destroy(hiprz_ctx* c) {
     }
     if (c->peer_done) (void)hipEventDestroy(c->peer_done);
     if (c->history_done) (void)hipEventDestroy(c->history_done);
+    if (c->sum_done) (void)hipEventDestroy(c->sum_done);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream), (void)hipStreamDestroy(c->aux_stream);
     if (c->aux_fork) (void)hipEventDestroy(c->aux_fork);
     if (c->aux_join) (void)hipEventDestroy(c->aux_join);
@@ -1732,8 +1784,14 @@ int hiprz_upload_camera(hiprz_ctx* c, const hiprz_camera* cam) {
 
 int hiprz_set_config(hiprz_ctx* c, const hiprz_config* cfg) {
     if (!c) return HIPRZ_ERR_INVALID;
-    RZ_FANOUT(c, hiprz_set_config(p, cfg));
     if (!cfg) return fail(c, HIPRZ_ERR_INVALID, "set_config: config is null");
+    for (size_t r = 0; r < c->peers.size(); ++r) {  // HIPRZ_SHARD_SAMPLES: part k of the context draws from the seed stream seed + k
+        hiprz_ctx* p = c->peers[r];
+        hiprz_config part = *cfg;
+        if (c->shard_mode == HIPRZ_SHARD_SAMPLES) part.seed += uint32_t(r) + 1u;
+        const int rz_rc = hiprz_set_config(p, &part);
+        if (rz_rc != HIPRZ_OK) return fail(c, rz_rc, "device " + std::to_string(p->device) + ": " + p->error);
+    }
     if (cfg->max_depth == 0 || cfg->max_depth > 254u) return fail(c, HIPRZ_ERR_INVALID, "max_depth must be 1..254 (u8, 255 = path ended)");
     // The CPU kernel divides by sample_count/light_count and yields NaN for 0 samples
     // (cpu_engine_kernel.cpp:742-743, 789-790); the CUDA backend clamps to >= 1 (cuda_kernel_data.cu:23-31).
@@ -1744,6 +1802,12 @@ int hiprz_set_config(hiprz_ctx* c, const hiprz_config* cfg) {
 }
 
 namespace {
+int reset_all_cameras(hiprz_ctx* c) {
+    for (hiprz_ctx* p : c->peers) (void)reset_all_cameras(p);
+    c->reset_pending = true;
+    for (auto& f : c->parked) f.reset_pending = true;
+    return HIPRZ_OK;
+}
 int set_shard_one(hiprz_ctx* c, uint32_t rank, uint32_t world) {
     const bool changed = rank != c->rank || world != c->world;
     c->rank = rank, c->world = world;
@@ -1768,13 +1832,38 @@ int hiprz_set_shard(hiprz_ctx* c, uint32_t rank, uint32_t world) {
     if (!c) return HIPRZ_ERR_INVALID;
     if (world == 0 || rank >= world) return fail(c, HIPRZ_ERR_INVALID, "set_shard: need rank < world");
     // a multi-device context splits ITS shard once more over its devices: device r of n renders shard rank * n + r of world * n
-    const uint32_t n = uint32_t(c->peers.size()) + 1u;
+    // (HIPRZ_SHARD_SAMPLES: every part renders the whole of the context's shard, on its own seed stream)
+    const bool samples = c->shard_mode == HIPRZ_SHARD_SAMPLES;
+    const uint32_t n = samples ? 1u : uint32_t(c->peers.size()) + 1u;
     c->user_rank = rank, c->user_world = world;
-    for (uint32_t r = 1; r < n; ++r) {
-        const int rc = set_shard_one(c->peers[r - 1u], rank * n + r, world * n);
+    for (uint32_t r = 1; r <= uint32_t(c->peers.size()); ++r) {
+        const int rc = set_shard_one(c->peers[r - 1u], samples ? rank : rank * n + r, world * n);
         if (rc != HIPRZ_OK) return fail(c, rc, "device " + std::to_string(c->peers[r - 1u]->device) + ": " + c->peers[r - 1u]->error);
     }
     return set_shard_one(c, rank * n, world * n);
+}
+
+int hiprz_set_shard_mode(hiprz_ctx* c, uint32_t mode) {
+    if (!c) return HIPRZ_ERR_INVALID;
+    if (mode > HIPRZ_SHARD_SAMPLES) return fail(c, HIPRZ_ERR_INVALID, "set_shard_mode: HIPRZ_SHARD_TILES or HIPRZ_SHARD_SAMPLES");
+    if (mode == c->shard_mode) return HIPRZ_OK;
+    c->shard_mode = mode;
+    if (c->peers.empty()) return HIPRZ_OK;  // one part: both modes are the same thing
+    // the parts' shards and seed streams follow the mode; whatever was accumulated under the other one does not mix with it
+    int rc = hiprz_set_shard(c, c->user_rank, c->user_world);
+    if (rc != HIPRZ_OK) return rc;
+    const hiprz_config cfg = c->config;
+    rc = hiprz_set_config(c, &cfg);
+    if (rc != HIPRZ_OK) return rc;
+    invalidate_graphs(c);
+    for (hiprz_ctx* p : c->peers) invalidate_graphs(p);
+    return reset_all_cameras(c);
+}
+
+int hiprz_shard_mode(hiprz_ctx* c, uint32_t* mode_out) {
+    if (!c || !mode_out) return HIPRZ_ERR_INVALID;
+    *mode_out = c->shard_mode;
+    return HIPRZ_OK;
 }
 
 int hiprz_set_traversal_mode(hiprz_ctx* c, int mode) {
@@ -1942,6 +2031,19 @@ int hiprz_render_counted(hiprz_ctx* c, uint32_t n_passes, hiprz_counters* out) {
 
 int hiprz_tonemap(hiprz_ctx* c) {
     if (!c) return HIPRZ_ERR_INVALID;
+    if (samples_head(c)) {  // the tone map of the SUM of the parts' accumulators, into the head's pixels
+        if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "tonemap before camera upload");
+        (void)hipSetDevice(c->device);
+        const uint32_t n = c->n_local_tiles * 256u;
+        if (!n) return HIPRZ_OK;
+        RZ_HIP(c, c->sum_accum.resize(n));
+        const int rc = sum_parts(c, c->sum_accum.ptr);
+        if (rc != HIPRZ_OK) return rc;
+        hipLaunchKernelGGL(rz_tonemap_tiles_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->sum_accum.ptr, c->rgba8.ptr, n, c->camera.aperture,
+                           c->camera.exposure_time);
+        RZ_HIP(c, hipGetLastError());
+        return HIPRZ_OK;
+    }
     RZ_FANOUT(c, hiprz_tonemap(p));
     if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "tonemap before camera upload");
     (void)hipSetDevice(c->device);
@@ -1975,6 +2077,12 @@ int hiprz_read_depth(hiprz_ctx* c, float* dst, size_t bytes) {
 int hiprz_read_accum(hiprz_ctx* c, float* dst, size_t bytes) {
     if (!c) return HIPRZ_ERR_INVALID;
     (void)hipSetDevice(c->device);
+    if (samples_head(c) && c->have_camera && c->n_local_tiles) {
+        RZ_HIP(c, c->sum_accum.resize(size_t(c->n_local_tiles) * 256u));
+        const int rc = sum_parts(c, c->sum_accum.ptr);
+        if (rc != HIPRZ_OK) return rc;
+        return read_untiled<float4>(c, c->sum_accum.ptr, reinterpret_cast<float4*>(dst), bytes, "read accum", [](hiprz_ctx* p) { return (const float4*)p->accum.ptr; });
+    }
     return read_untiled<float4>(c, c->accum.ptr, reinterpret_cast<float4*>(dst), bytes, "read accum", [](hiprz_ctx* p) { return (const float4*)p->accum.ptr; });
 }
 
@@ -1994,7 +2102,7 @@ int hiprz_read_state(hiprz_ctx* c, float* ray9, uint32_t* md2, size_t n_pixels) 
                            c->world);
     for (hiprz_ctx* p : c->peers) {  // multi-device head: the peers' path state, one peer at a time through the gather buffer
         const size_t n_local = size_t(p->n_local_tiles) * 256u;
-        if (!n_local) continue;
+        if (!n_local || c->shard_mode == HIPRZ_SHARD_SAMPLES) continue;  // (sample mode: the parts walk different paths through the same pixels — part 0 answers)
         RZ_HIP(c, c->gather.resize(n_local * 40u));
         float4* g0 = reinterpret_cast<float4*>(c->gather.ptr);
         float4* g1 = g0 + n_local;
@@ -2029,11 +2137,15 @@ int hiprz_pass_count(hiprz_ctx* c, uint32_t* out) {
 
 int hiprz_local_pixel_capacity(hiprz_ctx* c, size_t* out) {
     if (!c || !out) return HIPRZ_ERR_INVALID;
-    *out = c->peers.empty() ? size_t(c->n_local_tiles) * 256u : part_capacity(c) * (c->peers.size() + 1u);
+    *out = c->peers.empty() || c->shard_mode == HIPRZ_SHARD_SAMPLES ? size_t(c->n_local_tiles) * 256u : part_capacity(c) * (c->peers.size() + 1u);
     return HIPRZ_OK;
 }
 int hiprz_export_accum_tiles(hiprz_ctx* c, void* dst_device, size_t bytes) {
     if (!c) return HIPRZ_ERR_INVALID;
+    if (samples_head(c)) {  // the parts' sum, straight into the caller's buffer
+        if (!dst_device || bytes < size_t(c->n_local_tiles) * 256u * sizeof(float4)) return fail(c, HIPRZ_ERR_INVALID, "export_accum_tiles: destination too small");
+        return sum_parts(c, static_cast<float4*>(dst_device));
+    }
     return export_tiles<float4>(c, dst_device, bytes, "export_accum_tiles", [](hiprz_ctx* x) { return (const float4*)x->accum.ptr; });
 }
 int hiprz_export_rgba8_tiles(hiprz_ctx* c, void* dst_device, size_t bytes) {
@@ -2089,13 +2201,14 @@ int hiprz_untile_accum(hiprz_ctx* c, const void* src_tiles, uint32_t rank, uint3
     RZ_HIP(c, hipGetLastError());
     return HIPRZ_OK;
 }
-int hiprz_tonemap_image(hiprz_ctx* c, const void* src_image, void* dst_rgba8) {
+int hiprz_tonemap_image(hiprz_ctx* c, const void* src_image, void* dst_rgba8) { return hiprz_tonemap_image_on(c, src_image, dst_rgba8, nullptr); }
+int hiprz_tonemap_image_on(hiprz_ctx* c, const void* src_image, void* dst_rgba8, void* stream) {
     if (!c) return HIPRZ_ERR_INVALID;
     if (!c->have_camera) return fail(c, HIPRZ_ERR_STATE, "tonemap before camera upload");
     if (!src_image || !dst_rgba8) return fail(c, HIPRZ_ERR_INVALID, "tonemap_image: null pointer");
     (void)hipSetDevice(c->device);
     const uint32_t n = c->camera.width * c->camera.height;
-    hipLaunchKernelGGL(rz_tonemap_image_kernel, dim3((n + 255u) / 256u), dim3(256), 0, c->stream,
+    hipLaunchKernelGGL(rz_tonemap_image_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream ? static_cast<hipStream_t>(stream) : c->stream,
                        reinterpret_cast<const float4*>(src_image), reinterpret_cast<uint32_t*>(dst_rgba8), n, c->camera.aperture,
                        c->camera.exposure_time);
     RZ_HIP(c, hipGetLastError());

@@ -147,6 +147,7 @@ struct hiprz_frame_state {
     bool history_ready = false;   // prev_accum / prev_depth already hold the whole previous frame (a multi-device head assembled it)
     float temporal_blend = 0.75f;
     hiprz::DeviceArray<uint8_t> gather;  // multi-device head: the peers' tile buffers land here before one launch untiles them all
+    hiprz::DeviceArray<float4> sum_accum;  // HIPRZ_SHARD_SAMPLES head: the parts' accumulators summed, tile-major like `accum`
 };
 
 struct hiprz_ctx : hiprz_frame_state {
@@ -164,6 +165,9 @@ struct hiprz_ctx : hiprz_frame_state {
     hipEvent_t peer_done = nullptr;  // peer side: recorded on its stream when its tiles are ready, awaited by the head's stream
     hipEvent_t history_done = nullptr;  // head side: the assembled history of a restarted frame has reached every peer
     uint32_t user_rank = 0, user_world = 1;  // hiprz_set_shard as the caller sees it; peers refine it: (rank * n + r, world * n)
+    uint32_t shard_mode = 0;          // HIPRZ_SHARD_TILES | HIPRZ_SHARD_SAMPLES (head): how the parts divide the context's share
+    hipEvent_t sum_done = nullptr;    // head, sample mode: the last sum of the parts has read the staging slices (the peers' next copies wait for it)
+    bool sum_recorded = false;
 
     // cameras (hiprz_set_camera_count / hiprz_select_camera)
     std::vector<hiprz_frame_state> parked;  // slot [active_camera] is empty while that camera's state lives in the context itself

@@ -1,9 +1,17 @@
-"""Multi-GPU frame assembly: one process per GPU, the framebuffer sharded by interleaved
+"""Multi-GPU frame assembly: one process per GPU.  Two ways to divide a frame between the ranks (ShardedFrame(mode=...)):
+
+"tiles" — the framebuffer sharded by interleaved
 32x8-pixel tiles (numbered row by row, tile t to rank t % world, the rows rotated so that column c of row r goes to rank
 (c + shard_row_offset(r)) % world; include/hiprz.h: hiprz_set_shard), the
 scene replicated, and ONE collective per readback: a gather of the tile-major tone-mapped RGBA8
 tiles (or the RGBA32F accumulators) to rank 0 over RCCL (torch.distributed backend "nccl") —
-SURVEY.md §8e.  There is no collective on the per-pass data path: pixels are independent.
+SURVEY.md §8e.  There is no collective on the per-pass data path: pixels are independent.  Frames are the one-GPU frame bit for bit.
+
+"samples" — every rank renders the WHOLE frame on a seed stream of its own (`sample_shard_seed`) and ONE reduce per readback sums the
+RGBA32F accumulators (colour sums and finished-path counts alike) on rank 0, which tone-maps the sum: SURVEY.md §8e's "sample-sharding
+with per-frame ncclReduce of full accumulators" (33 MB per 1080p frame).  A rank's step is a whole-frame step whatever the job size, so
+aggregate rays per second grow with the ranks where tile sharding is held back by its slowest tile's chain of passes; the
+frame is the sum of the ranks' one-GPU frames — the same for a given job size, another one for another size.
 
 The reference has nothing to mirror here (single device: RayZath/cuda_engine_core.cu:17).
 """
@@ -77,6 +85,28 @@ def gather_tiles(local_tiles, rank, world, capacity_max, dist, dst=0):
     return gather_list
 
 
+def sample_shard_seed(seed, rank, parts=1):
+    """Base seed of rank `rank`'s context in a sample-sharded job: the ranks' seed streams must not overlap, and a context over `parts`
+    devices / streams in HIPRZ_SHARD_SAMPLES mode uses seed .. seed + parts - 1 itself (include/hiprz.h: hiprz_set_shard_mode)."""
+    return (int(seed) + int(rank) * int(parts)) & 0xFFFFFFFF
+
+
+def reduce_tiles(local_tiles, rank, world, dist, dst=0):
+    """Sum every rank's tile-major accumulator buffer (same layout on every rank) into `local_tiles` on `dst`: one reduce.  Works with
+    any backend (nccl on GPUs: ncclReduce over xGMI; gloo in the CPU tests and the one-GPU rehearsal, staged through the host).
+    Returns the summed tensor on dst, None elsewhere."""
+    if world == 1:
+        return local_tiles
+    if local_tiles.is_cuda and dist.get_backend() == "gloo":
+        host = local_tiles.cpu()
+        dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+        if rank == dst:
+            local_tiles.copy_(host)
+        return local_tiles if rank == dst else None
+    dist.reduce(local_tiles, dst=dst, op=dist.ReduceOp.SUM)
+    return local_tiles if rank == dst else None
+
+
 def total_ray_count(local_rays, dist, device=None):
     """Sum of the ranks' ray counters (Camera::rayCount of the whole frame): one all-reduce of a 64-bit integer — SURVEY.md §8e.
     Works with any backend (nccl: pass the rank's cuda device; gloo: CPU tensor)."""
@@ -99,13 +129,20 @@ class ShardedFrame:
     waits for the previous gather, so one tile buffer is enough.  `overlap=False` keeps everything on the
     render stream.  `sync()` waits for both.  The default readback gathers the tone-mapped RGBA8 tiles
     (8.3 MB per 1080p frame in total, 4x less than the RGBA32F accumulators); `gather_accum` moves the float
-    accumulators instead (parity checks, float output)."""
+    accumulators instead (parity checks, float output).
 
-    def __init__(self, ctx, rank, world, width, height, dist=None, device=None, overlap=True):
+    mode="samples": the context renders the whole frame (shard 0 of 1) on this rank's seed stream (`sample_shard_seed`); `reduce()` —
+    export accumulators -> ONE reduce(sum) to rank 0 -> untile -> tone map of the sum — replaces `gather()`, with the same stream
+    choreography (the reduce of frame k overlaps the rendering of frame k+1)."""
+
+    def __init__(self, ctx, rank, world, width, height, dist=None, device=None, overlap=True, mode="tiles"):
         import torch
 
         self.ctx, self.rank, self.world, self.dist = ctx, rank, world, dist
         self.width, self.height = width, height
+        self.mode = mode
+        if mode == "samples":
+            return self._init_samples(device, overlap)
         tiles_x, tiles_y = tile_grid(width, height)
         # a context over n devices / streams hands out n slices (sub-shard rank * n + r of world * n in slice r), each with the capacity of the
         # job's largest sub-shard: the ranks' buffers laid end to end are the sub-shards 0 .. world * n - 1 (include/hiprz.h)
@@ -124,6 +161,52 @@ class ShardedFrame:
         self.parts8 = [self.all8[r] for r in range(world)] if self.all8 is not None else None
         self.rgba8 = torch.empty((height, width), dtype=torch.int32, device=device) if root else None
         self.image = None
+
+    def _init_samples(self, device, overlap):
+        import torch
+
+        ctx, world = self.ctx, self.world
+        tiles_x, tiles_y = tile_grid(self.width, self.height)
+        # the context's export layout: one slice of the whole frame (one part, or a context in HIPRZ_SHARD_SAMPLES mode), or n slices =
+        # the sub-shards 0 .. n - 1 of n (a context over n streams in tile mode: the hosts' default packaging for scenes without lights)
+        sample_ctx = hasattr(ctx, "shard_mode") and ctx.shard_mode() == 1
+        self.n_parts = 1 if sample_ctx or not hasattr(ctx, "device_count") else ctx.device_count()
+        self.part_capacity = owned_tile_count(0, self.n_parts, tiles_x * tiles_y) * TILE_PIXELS
+        self.capacity_max = self.part_capacity * self.n_parts
+        self.device = device
+        on_gpu = device is not None and device.type == "cuda"
+        self.stream = torch.cuda.ExternalStream(ctx.stream(), device=device) if on_gpu else None
+        self.comm = torch.cuda.Stream(device=device, priority=-1) if on_gpu and overlap and world > 1 else self.stream
+        self.local = torch.zeros((self.capacity_max, 4), dtype=torch.float32, device=device)   # export buffer; on rank 0 the reduce sums into it
+        root = self.rank == 0
+        self.image = torch.empty((self.height, self.width, 4), dtype=torch.float32, device=device) if root else None
+        self.rgba8 = torch.empty((self.height, self.width), dtype=torch.int32, device=device) if root else None
+        self.local8 = None
+
+    def reduce(self):
+        """Sum the ranks' accumulators on rank 0 (one reduce), assemble the row-major RGBA32F frame and tone-map it.  Returns the RGBA8
+        frame on rank 0 (`self.image` holds the summed accumulators), None elsewhere.  Asynchronous like gather(): `sync()` waits."""
+        import torch
+
+        assert self.mode == "samples"
+        ctx = self.ctx
+        self._before_export()
+        ctx.export_accum_tiles(self.local.data_ptr(), self.local.numel() * 4)
+        if self.world > 1:
+            if self.dist.get_backend() == "gloo":  # one-GPU rehearsal / CPU tests: staged through the host
+                ctx.sync()
+                reduce_tiles(self.local, self.rank, self.world, self.dist)
+            else:
+                if self.comm is not self.stream:
+                    self.comm.wait_stream(self.stream)  # the export just enqueued on the render stream
+                with torch.cuda.stream(self.comm):
+                    self.dist.reduce(self.local, dst=0, op=self.dist.ReduceOp.SUM)
+        if self.rank != 0:
+            return None
+        stream = self.comm.cuda_stream if self.comm is not None and self.comm is not self.stream else None
+        ctx.untile_gathered(self.local.data_ptr(), self.n_parts, self.part_capacity * 16, 16, self.image.data_ptr(), stream)
+        ctx.tonemap_image(self.image.data_ptr(), self.rgba8.data_ptr(), stream)
+        return self.rgba8
 
     def _gather(self, local, parts):
         import torch

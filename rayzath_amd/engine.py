@@ -40,6 +40,7 @@ COMPAT_BEER_LAMBERT, COMPAT_SCATTERING, COMPAT_SHADOW_COLOR, COMPAT_TEXTURE_MULT
 
 
 TREE_REFERENCE, TREE_SAH, TREE_DEVICE, TREE_DEVICE_SAH, TREE_AUTO = range(5)   # hiprz_set_tree (include/hiprz.h)
+SHARD_TILES, SHARD_SAMPLES = 0, 1   # hiprz_set_shard_mode
 
 
 def default_streams(n_lights):
@@ -126,6 +127,17 @@ class Context:
 
     def set_shard(self, rank, world):
         self._check(self.lib.hiprz_set_shard(self._ctx, rank, world))
+
+    def set_shard_mode(self, mode):
+        """How the parts of a context over several devices / streams divide its share (hiprz_set_shard_mode): SHARD_TILES (default) —
+        interleaved tiles, the one-device frame bit for bit; SHARD_SAMPLES — every part renders the whole share on the seed stream
+        seed + part and the accumulators are summed wherever the frame leaves the context."""
+        self._check(self.lib.hiprz_set_shard_mode(self._ctx, mode))
+
+    def shard_mode(self):
+        v = C.c_uint32()
+        self._check(self.lib.hiprz_shard_mode(self._ctx, C.byref(v)))
+        return v.value
 
     def set_traversal_mode(self, mode):
         self._check(self.lib.hiprz_set_traversal_mode(self._ctx, mode))
@@ -320,8 +332,8 @@ class Context:
     def untile_accum(self, src_ptr, rank, world, dst_ptr):
         self._check(self.lib.hiprz_untile_accum(self._ctx, src_ptr, rank, world, dst_ptr))
 
-    def tonemap_image(self, src_ptr, dst_ptr):
-        self._check(self.lib.hiprz_tonemap_image(self._ctx, src_ptr, dst_ptr))
+    def tonemap_image(self, src_ptr, dst_ptr, stream=None):
+        self._check(self.lib.hiprz_tonemap_image_on(self._ctx, src_ptr, dst_ptr, stream))
 
     def stream(self):
         return self.lib.hiprz_stream(self._ctx)

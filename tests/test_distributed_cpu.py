@@ -110,3 +110,49 @@ def test_gather_assembles_the_frame_over_gloo(tmp_path, world, size):
     assert np.array_equal(image[..., 0], xx) and np.array_equal(image[..., 1], yy)
     assert np.array_equal(image[..., 3], yy * W + xx)
     assert np.array_equal(image[..., 2], tile_owner(xx // 32, yy // 8, tile_grid(W, H)[0], world))
+
+
+def _reduce_worker(rank, world, port, W, H, out_path):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from rayzath_amd.distributed import ShardedFrame, reduce_tiles, sample_shard_seed, tile_grid as tg, tile_pixel_coords as tpc, total_ray_count
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    # sample sharding: every rank holds the WHOLE frame, tile-major, in the same layout (shard 0 of 1)
+    x, y = tpc(W, H, 0, 1)
+    inside = x >= 0
+    local = torch.zeros((len(x), 4), dtype=torch.float32)
+    vals = np.stack([x * (rank + 1), y * (rank + 1), x * 0 + sample_shard_seed(100, rank) - 100, x * 0 + 3], axis=-1).astype(np.float32)
+    local[torch.from_numpy(inside)] = torch.from_numpy(vals[inside])
+    summed = reduce_tiles(local, rank, world, dist)
+    assert total_ray_count(5 * W * H, dist) == world * 5 * W * H     # every rank traces the whole frame
+    if rank == 0:
+        image = np.full((H, W, 4), -1, np.float32)
+        image[y[inside], x[inside]] = summed.numpy()[inside]
+        np.save(out_path, image)
+    else:
+        assert summed is None   # (a non-root rank's buffer is scratch after the collective: it is the export buffer, never the accumulators)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size", [(2, (200, 120)), (3, (97, 41))])
+def test_reduce_sums_the_ranks_accumulators_over_gloo(tmp_path, world, size):
+    """ShardedFrame.reduce's collective (rayzath_amd/distributed.py: reduce_tiles): one reduce(sum) of the tile-major RGBA32F accumulators to
+    rank 0; the ranks' seed streams are distinct; the ray counters add up to world * passes * W * H."""
+    import torch.multiprocessing as mp
+    from rayzath_amd.distributed import sample_shard_seed
+    W, H = size
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sum.npy")
+    mp.spawn(_reduce_worker, args=(world, port, W, H, out), nprocs=world, join=True)
+    image = np.load(out)
+    yy, xx = np.mgrid[0:H, 0:W]
+    k = world * (world + 1) // 2
+    assert np.array_equal(image[..., 0], xx * k) and np.array_equal(image[..., 1], yy * k)
+    assert np.array_equal(image[..., 2], np.full((H, W), sum(range(world)))) and np.array_equal(image[..., 3], np.full((H, W), 3 * world))
+    assert len({sample_shard_seed(7, r, 2) + k for r in range(8) for k in range(2)}) == 16     # 8 ranks x 2 parts: 16 distinct seed streams
+    assert sample_shard_seed(0xFFFFFFFF, 1) == 0                                               # the seed is a u32

@@ -373,7 +373,7 @@ def test_sharded_bench_path_rehearsal(built):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29671", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "A",
-           "--rehearse-on-one-gpu", "--no-cpu-baseline", "--verify-gather"]
+           "--rehearse-on-one-gpu", "--no-cpu-baseline", "--verify-gather", "--shard-mode", "tiles", "--no-other-mode"]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stderr[-2000:]
     line = [l for l in proc.stdout.splitlines() if l.startswith("{")][-1]
