@@ -568,6 +568,11 @@ void hiprz_axes_look_at(const float rotation[3], float x_axis[3], float y_axis[3
 float hiprz_seed_value(uint32_t seed, uint32_t pass, uint32_t i);
 
 const char* hiprz_version(void);
+/* How many kernel instantiations the library's launchers can select; each registered its host stub when the library was loaded.  The first
+ * hiprz_create on a device resolves every one of them in the loaded gfx950 code objects and fails with HIPRZ_ERR_DEVICE, naming the kernel,
+ * when one is missing (a launch of such a kernel would end the process inside the HIP runtime).  tools/check_kernels.py proves the same
+ * for the built files; its count is this one. */
+uint32_t hiprz_kernel_count(void);
 
 #ifdef __cplusplus
 }

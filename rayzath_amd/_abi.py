@@ -174,6 +174,7 @@ ENTRY_POINTS = {
     "hiprz_axes_look_at": (None, [P, P, P, P]),
     "hiprz_seed_value": (C.c_float, [U32, U32, U32]),
     "hiprz_version": (C.c_char_p, []),
+    "hiprz_kernel_count": (U32, []),
 }
 
 

@@ -196,6 +196,31 @@ int fail(hiprz_ctx* ctx, int code, const std::string& msg) {
     else g_create_error = msg;
     return code;
 }
+// the launch sites' kernel stubs (hiprz_ctx.hpp: RZ_LAUNCH); filled during static initialisation of the translation units
+std::vector<KernelEntry>& kernel_table() {
+    static std::vector<KernelEntry> table;
+    return table;
+}
+void register_kernel(const void* stub, const char* name) { kernel_table().push_back(KernelEntry{stub, name}); }
+// Every kernel a launcher can select must resolve in the code objects this process loaded, on the device a context is created for:
+// checked once per device, at the first hiprz_create.  (What it costs: the runtime loads every code object of the library up front
+// instead of at the first launch from it.)
+int resolve_kernels(int device) {
+    static std::vector<int> checked;
+    for (int d : checked)
+        if (d == device) return HIPRZ_OK;
+    for (const KernelEntry& e : kernel_table()) {
+        hipFuncAttributes attr;
+        const hipError_t err = hipFuncGetAttributes(&attr, e.stub);
+        if (err != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(nullptr, HIPRZ_ERR_DEVICE, std::string("libhiprz.so is inconsistent: the loaded gfx950 code objects do not hold a kernel the host side can launch (") +
+                                                       hipGetErrorString(err) + "): " + e.name + " — rebuild (make -C rayzath_amd/csrc; tools/check_kernels.py)");
+        }
+    }
+    checked.push_back(device);
+    return HIPRZ_OK;
+}
 // settings are shared by the cameras of a context: a change invalidates the graph of every one of them
 void invalidate_graphs(hiprz_ctx* c) {
     c->graph_valid = false;
@@ -333,9 +358,9 @@ bool keep_history(hiprz_ctx* c) {
             (void)hipMemsetAsync(c->prev_accum.ptr, 0, n * sizeof(float4), c->stream);
             (void)hipMemsetAsync(c->prev_depth.ptr, 0, n * sizeof(float), c->stream);
         }
-        hipLaunchKernelGGL((rz_untile_kernel<float4>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->accum.ptr, c->prev_accum.ptr, c->camera.width,
+        RZ_LAUNCH((rz_untile_kernel<float4>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->accum.ptr, c->prev_accum.ptr, c->camera.width,
                            c->camera.height, c->tiles_x, c->rank, c->world);
-        hipLaunchKernelGGL((rz_untile_kernel<float>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->depth.ptr, c->prev_depth.ptr, c->camera.width,
+        RZ_LAUNCH((rz_untile_kernel<float>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->depth.ptr, c->prev_depth.ptr, c->camera.width,
                            c->camera.height, c->tiles_x, c->rank, c->world);
     }
     c->history_ready = false;
@@ -375,9 +400,9 @@ int assemble_history(hiprz_ctx* c) {
         RZ_HIP(c, hipStreamWaitEvent(c->stream, p->peer_done, 0));
     }
     if (c->n_local_tiles) {
-        hipLaunchKernelGGL((rz_untile_gathered_kernel<float4>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts_a, stride, c->prev_accum.ptr,
+        RZ_LAUNCH((rz_untile_gathered_kernel<float4>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts_a, stride, c->prev_accum.ptr,
                            c->camera.width, c->camera.height, c->tiles_x, c->tiles_x * c->tiles_y, c->world, c->rank);
-        hipLaunchKernelGGL((rz_untile_gathered_kernel<float>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts_d, stride, c->prev_depth.ptr,
+        RZ_LAUNCH((rz_untile_gathered_kernel<float>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts_d, stride, c->prev_depth.ptr,
                            c->camera.width, c->camera.height, c->tiles_x, c->tiles_x * c->tiles_y, c->world, c->rank);
     }
     c->history_ready = true;
@@ -406,7 +431,7 @@ void reproject_after_first_pass(hiprz_ctx* c, const DFrame& f, const hiprz_camer
     std::memcpy(prev.y_axis, previous.y_axis, 12), std::memcpy(prev.z_axis, previous.z_axis, 12);
     prev.tan_half_fov = previous.tan_half_fov, prev.aspect_ratio = previous.aspect_ratio;
     const PassGeometry g = pass_geometry(c);
-    hipLaunchKernelGGL(rz_reproject_kernel, g.grid, dim3(256), 0, c->stream, f, c->dcamera, prev, c->prev_accum.ptr, c->prev_depth.ptr, c->temporal_blend);
+    RZ_LAUNCH(rz_reproject_kernel, g.grid, dim3(256), 0, c->stream, f, c->dcamera, prev, c->prev_accum.ptr, c->prev_depth.ptr, c->temporal_blend);
 }
 
 int allocate_frame(hiprz_ctx* c) {
@@ -524,7 +549,7 @@ void resolve_pipeline(hiprz_ctx* c) {
     const int before = c->pipeline;
     // a shard small enough to be ONE round of waves on the chip pays the slowest wave of every kernel of every pass in the split
     // pipeline; without lights it runs per-wave chains of passes instead (hiprz_kernels.hpp: rz_wave_batch_kernel)
-    const bool dark_capable = c->have_scene && !c->lds_scene && c->dscene.n_spot_lights + c->dscene.n_direct_lights == 0u && c->nolight_kernels && c->walk_order != 0 &&
+    const bool dark_capable = c->have_scene && !use_lds_scene(c) && c->dscene.n_spot_lights + c->dscene.n_direct_lights == 0u && c->nolight_kernels && c->walk_order != 0 &&
                               (c->traversal_mode == -1 || c->traversal_mode == 3);
     const bool small_dark_shard = dark_capable && c->have_camera && c->n_local_tiles != 0u && c->n_local_tiles * 4u <= c->wave_resident_max;
     if (c->mode_flags & kIntegratorFlags) c->pipeline = c->pipeline_setting == 0 ? 0 : 1;  // CUDA-compat integrator: split (sorted rays, cooperative walks, deferred shadow rays); 0 = one fused kernel per pass
@@ -589,7 +614,7 @@ void launch_pass(hiprz_ctx* c, const DFrame& f, bool first, bool counted, hipEve
 // resident pipeline: all `n` cumulative passes of the batch in one launch (+ one launch that advances the pass index)
 void launch_resident(hiprz_ctx* c, const DFrame& f, uint32_t n, bool counted, hipEvent_t before = nullptr, hipEvent_t after = nullptr) {
     launch_batch(c, f, n, counted, before, after);
-    hipLaunchKernelGGL(rz_pass_add_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr, n);
+    RZ_LAUNCH(rz_pass_add_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr, n);
     c->rgba8_valid = true;
 }
 
@@ -618,7 +643,7 @@ void enqueue_cumulative(hiprz_ctx* c, const DFrame& f, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) {
         launch_pass(c, f, false, false);
         launch_sort(c);
-        hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+        RZ_LAUNCH(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
     }
 }
 
@@ -679,10 +704,10 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
             const bool history = keep_history(c);
             const hiprz_camera previous = c->frame_camera;
             c->frame_camera = c->camera, c->frame_started = true;
-            hipLaunchKernelGGL(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+            RZ_LAUNCH(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
             launch_pass(c, f, true, counted);
             if (history) reproject_after_first_pass(c, f, previous);
-            hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+            RZ_LAUNCH(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
             c->reset_pending = false;
             c->passes = 1;
             c->ray_count = c->owned_pixels;
@@ -751,7 +776,7 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
             launch_pass(c, f, false, false, c->kernel_events[3 * i + 1]);
             (void)hipEventRecord(c->kernel_events[3 * i + 2], c->stream);
             launch_sort(c);
-            hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+            RZ_LAUNCH(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
             c->passes += 1;
             c->ray_count += c->owned_pixels;
             continue;
@@ -760,7 +785,7 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
             const bool history = keep_history(c);
             const hiprz_camera previous = c->frame_camera;
             c->frame_camera = c->camera, c->frame_started = true;
-            hipLaunchKernelGGL(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+            RZ_LAUNCH(rz_pass_reset_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
             launch_pass(c, f, true, counted);
             if (history) reproject_after_first_pass(c, f, previous);
             c->reset_pending = false;
@@ -770,7 +795,7 @@ int render_impl(hiprz_ctx* c, uint32_t n_passes, bool counted) {
             launch_pass(c, f, false, counted);
         }
         launch_sort(c);
-        hipLaunchKernelGGL(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
+        RZ_LAUNCH(rz_pass_update_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr);
         c->passes += 1;
         c->ray_count += c->owned_pixels;  // traced_rays += W*H per pass (cpu_engine_renderer.cpp:173), per shard
     }
@@ -789,7 +814,7 @@ int read_untiled(hiprz_ctx* c, const T* tiles, T* dst, size_t bytes, const char*
     if (c->user_world > 1u) RZ_HIP(c, hipMemsetAsync(image, 0, bytes, c->stream));
     if (c->peers.empty() || c->shard_mode == HIPRZ_SHARD_SAMPLES) {  // (sample mode: `tiles` is the head's own / the summed buffer of the whole share)
         if (c->n_local_tiles)
-            hipLaunchKernelGGL((rz_untile_kernel<T>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, tiles, image,
+            RZ_LAUNCH((rz_untile_kernel<T>), dim3(c->n_local_tiles), dim3(256), 0, c->stream, tiles, image,
                                c->camera.width, c->camera.height, c->tiles_x, c->rank, c->world);
     } else {
         // multi-device head: every device's tiles land in a slice of their own of ONE staging buffer — each peer pushes its slice on
@@ -811,7 +836,7 @@ int read_untiled(hiprz_ctx* c, const T* tiles, T* dst, size_t bytes, const char*
             RZ_HIP(c, hipStreamWaitEvent(c->stream, p->peer_done, 0));
         }
         if (c->n_local_tiles)
-            hipLaunchKernelGGL((rz_untile_gathered_kernel<T>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts, stride, image, c->camera.width,
+            RZ_LAUNCH((rz_untile_gathered_kernel<T>), dim3(c->n_local_tiles, n_parts), dim3(256), 0, c->stream, parts, stride, image, c->camera.width,
                                c->camera.height, c->tiles_x, c->tiles_x * c->tiles_y, c->world, c->rank);
     }
     RZ_HIP(c, hipMemcpyAsync(dst, image, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -1066,7 +1091,7 @@ int sum_parts(hiprz_ctx* c, float4* out) {
         (void)hipSetDevice(c->device);
         RZ_HIP(c, hipStreamWaitEvent(c->stream, p->peer_done, 0));
     }
-    hipLaunchKernelGGL(rz_sum_parts_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->accum.ptr, staged, n, n_staged, out, uint32_t(n));
+    RZ_LAUNCH(rz_sum_parts_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->accum.ptr, staged, n, n_staged, out, uint32_t(n));
     RZ_HIP(c, hipGetLastError());
     RZ_HIP(c, hipEventRecord(c->sum_done, c->stream));
     c->sum_recorded = true;
@@ -1129,6 +1154,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     if (e != hipSuccess) return fail(nullptr, HIPRZ_ERR_DEVICE, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, HIPRZ_ERR_DEVICE, std::string("hiprz is built for gfx950 only, device is ") + prop.gcnArchName);
+    if (const int rc = resolve_kernels(device_id); rc != HIPRZ_OK) return rc;
     auto* c = new hiprz_ctx();
     if (const char* w = std::getenv("HIPRZ_TRACE_WAVES")) c->trace_waves = std::atoi(w);
     if (const char* w = std::getenv("HIPRZ_DEFER_SHADOWS")) c->defer_shadow_rays = std::atoi(w) != 0;
@@ -1614,6 +1640,15 @@ int hiprz_update_shading(hiprz_ctx* c, const hiprz_material* materials, uint32_t
 
 // ---- geometry changes without a host-side tree build (scenes uploaded under HIPRZ_TREE_DEVICE; hiprz_build.hip) ----
 namespace {
+// An in-place change of the scene failed half way (a device-built tree the host refused to prove terminating, a device error): the node
+// tables, the triangle order or the instance roots may be part old, part new — there is no scene any more.  hiprz_render then returns
+// HIPRZ_ERR_STATE instead of walking tables nobody proved, and the streams that share this device's copy learn the same (Share's destructor).
+int scene_lost(hiprz_ctx* c, int rc) {
+    c->have_scene = false;
+    c->device_meshes.clear(), c->instance_mesh.clear();
+    invalidate_graphs(c);
+    return rc;
+}
 int restart_after_geometry_change(hiprz_ctx* c) {
     c->reset_pending = true;  // the world changed: accumulation restarts (cpu_engine_renderer.cpp:108-112), for every camera
     for (auto& f : c->parked) f.reset_pending = true;
@@ -1638,7 +1673,7 @@ int hiprz_update_triangles(hiprz_ctx* c, uint32_t first, uint32_t n, const hiprz
     (void)hipSetDevice(c->device);
     RZ_HIP(c, hipStreamSynchronize(c->stream));
     const int rc = device_update_triangles(c, first, n, tris, attrs);
-    if (rc != HIPRZ_OK) return rc;
+    if (rc != HIPRZ_OK) return scene_lost(c, rc);
     return restart_after_geometry_change(c);
 }
 
@@ -1666,8 +1701,9 @@ int hiprz_rebuild_trees(hiprz_ctx* c, uint32_t tree) {
         RZ_HIP(c, hipMemcpy(rec, c->dev_nodes.ptr + size_t(root) * sizeof(hiprz_node), sizeof rec, hipMemcpyDeviceToHost));
         m.bb_min[0] = rec[0], m.bb_max[0] = rec[1], m.bb_min[1] = rec[2], m.bb_max[1] = rec[3], m.bb_min[2] = rec[4], m.bb_max[2] = rec[5];
     }
-    const int rc = device_build_mesh_trees(c, meshes, c->instance_mesh, !std::getenv("HIPRZ_TRUST_DEVICE_TREES"));
-    if (rc != HIPRZ_OK) return rc;
+    const std::vector<uint32_t> instance_mesh = c->instance_mesh;
+    const int rc = device_build_mesh_trees(c, meshes, instance_mesh, !std::getenv("HIPRZ_TRUST_DEVICE_TREES"));
+    if (rc != HIPRZ_OK) return scene_lost(c, rc);  // nodes, links and the triangle order were being rewritten in place
     for (size_t i = 0; i < c->device_instances.size(); ++i)
         if (c->instance_mesh[i] != RZ_END && c->device_meshes[c->instance_mesh[i]].region != RZ_END)
             c->device_instances[i].blas_root = c->device_meshes[c->instance_mesh[i]].region;
@@ -1714,7 +1750,7 @@ int hiprz_update_instances(hiprz_ctx* c, const hiprz_instance* instances, uint32
     if (!fast_div && c->dscene.fast_div) c->dscene.fast_div = 0u, invalidate_graphs(c);
     if (c->n_tlas_order) {
         const int rc = device_build_world_tree(c, !std::getenv("HIPRZ_TRUST_DEVICE_TREES"));
-        if (rc != HIPRZ_OK) return rc;
+        if (rc != HIPRZ_OK) return scene_lost(c, rc);  // the new instance records and a world tree nobody proved are on the device
     }
     return restart_after_geometry_change(c);
 }
@@ -2039,7 +2075,7 @@ int hiprz_tonemap(hiprz_ctx* c) {
         RZ_HIP(c, c->sum_accum.resize(n));
         const int rc = sum_parts(c, c->sum_accum.ptr);
         if (rc != HIPRZ_OK) return rc;
-        hipLaunchKernelGGL(rz_tonemap_tiles_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->sum_accum.ptr, c->rgba8.ptr, n, c->camera.aperture,
+        RZ_LAUNCH(rz_tonemap_tiles_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->sum_accum.ptr, c->rgba8.ptr, n, c->camera.aperture,
                            c->camera.exposure_time);
         RZ_HIP(c, hipGetLastError());
         return HIPRZ_OK;
@@ -2050,7 +2086,7 @@ int hiprz_tonemap(hiprz_ctx* c) {
     if (c->rgba8_valid && !c->reset_pending) return HIPRZ_OK;  // the resident kernel already wrote this frame's pixels
     const uint32_t n = c->n_local_tiles * 256u;
     if (n)
-        hipLaunchKernelGGL(rz_tonemap_tiles_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->accum.ptr, c->rgba8.ptr, n,
+        RZ_LAUNCH(rz_tonemap_tiles_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->accum.ptr, c->rgba8.ptr, n,
                            c->camera.aperture, c->camera.exposure_time);
     RZ_HIP(c, hipGetLastError());
     return HIPRZ_OK;
@@ -2097,7 +2133,7 @@ int hiprz_read_state(hiprz_ctx* c, float* ray9, uint32_t* md2, size_t n_pixels) 
     RZ_HIP(c, hipMemsetAsync(c->state_ray.ptr, 0, 9 * n * sizeof(float), c->stream));
     RZ_HIP(c, hipMemsetAsync(c->state_md.ptr, 0, 2 * n * sizeof(uint32_t), c->stream));
     if (c->n_local_tiles)
-        hipLaunchKernelGGL(rz_untile_state_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->st0.ptr, c->st1.ptr,
+        RZ_LAUNCH(rz_untile_state_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->st0.ptr, c->st1.ptr,
                            c->st2.ptr, c->state_ray.ptr, c->state_md.ptr, c->camera.width, c->camera.height, c->tiles_x, c->rank,
                            c->world);
     for (hiprz_ctx* p : c->peers) {  // multi-device head: the peers' path state, one peer at a time through the gather buffer
@@ -2114,7 +2150,7 @@ int hiprz_read_state(hiprz_ctx* c, float* ray9, uint32_t* md2, size_t n_pixels) 
         RZ_HIP(c, hipMemcpyPeerAsync(g0, c->device, p->st0.ptr, p->device, n_local * 16u, c->stream));
         RZ_HIP(c, hipMemcpyPeerAsync(g1, c->device, p->st1.ptr, p->device, n_local * 16u, c->stream));
         RZ_HIP(c, hipMemcpyPeerAsync(g2, c->device, p->st2.ptr, p->device, n_local * 8u, c->stream));
-        hipLaunchKernelGGL(rz_untile_state_kernel, dim3(p->n_local_tiles), dim3(256), 0, c->stream, g0, g1, g2, c->state_ray.ptr, c->state_md.ptr,
+        RZ_LAUNCH(rz_untile_state_kernel, dim3(p->n_local_tiles), dim3(256), 0, c->stream, g0, g1, g2, c->state_ray.ptr, c->state_md.ptr,
                            c->camera.width, c->camera.height, c->tiles_x, p->rank, p->world);
     }
     RZ_HIP(c, hipMemcpyAsync(ray9, c->state_ray.ptr, 9 * n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
@@ -2159,7 +2195,7 @@ int hiprz_untile_rgba8(hiprz_ctx* c, const void* src_tiles, uint32_t rank, uint3
     (void)hipSetDevice(c->device);
     const uint32_t n_local = shard_local_tiles(c->tiles_x, c->tiles_y, rank, world);
     if (n_local)
-        hipLaunchKernelGGL((rz_untile_kernel<uint32_t>), dim3(n_local), dim3(256), 0, c->stream,
+        RZ_LAUNCH((rz_untile_kernel<uint32_t>), dim3(n_local), dim3(256), 0, c->stream,
                            reinterpret_cast<const uint32_t*>(src_tiles), reinterpret_cast<uint32_t*>(dst_image), c->camera.width,
                            c->camera.height, c->tiles_x, rank, world);
     RZ_HIP(c, hipGetLastError());
@@ -2179,10 +2215,10 @@ int hiprz_untile_gathered(hiprz_ctx* c, const void* src_parts, uint32_t world, s
     if (n_tiles) {
         const dim3 grid(per_rank, world);
         if (element_bytes == 4u)
-            hipLaunchKernelGGL((rz_untile_gathered_kernel<uint32_t>), grid, dim3(256), 0, st, reinterpret_cast<const uint32_t*>(src_parts),
+            RZ_LAUNCH((rz_untile_gathered_kernel<uint32_t>), grid, dim3(256), 0, st, reinterpret_cast<const uint32_t*>(src_parts),
                                part_stride_bytes / 4u, reinterpret_cast<uint32_t*>(dst_image), c->camera.width, c->camera.height, c->tiles_x, n_tiles, world, 0u);
         else
-            hipLaunchKernelGGL((rz_untile_gathered_kernel<float4>), grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src_parts),
+            RZ_LAUNCH((rz_untile_gathered_kernel<float4>), grid, dim3(256), 0, st, reinterpret_cast<const float4*>(src_parts),
                                part_stride_bytes / 16u, reinterpret_cast<float4*>(dst_image), c->camera.width, c->camera.height, c->tiles_x, n_tiles, world, 0u);
     }
     RZ_HIP(c, hipGetLastError());
@@ -2195,7 +2231,7 @@ int hiprz_untile_accum(hiprz_ctx* c, const void* src_tiles, uint32_t rank, uint3
     (void)hipSetDevice(c->device);
     const uint32_t n_local = shard_local_tiles(c->tiles_x, c->tiles_y, rank, world);
     if (n_local)
-        hipLaunchKernelGGL((rz_untile_kernel<float4>), dim3(n_local), dim3(256), 0, c->stream,
+        RZ_LAUNCH((rz_untile_kernel<float4>), dim3(n_local), dim3(256), 0, c->stream,
                            reinterpret_cast<const float4*>(src_tiles), reinterpret_cast<float4*>(dst_image), c->camera.width,
                            c->camera.height, c->tiles_x, rank, world);
     RZ_HIP(c, hipGetLastError());
@@ -2208,7 +2244,7 @@ int hiprz_tonemap_image_on(hiprz_ctx* c, const void* src_image, void* dst_rgba8,
     if (!src_image || !dst_rgba8) return fail(c, HIPRZ_ERR_INVALID, "tonemap_image: null pointer");
     (void)hipSetDevice(c->device);
     const uint32_t n = c->camera.width * c->camera.height;
-    hipLaunchKernelGGL(rz_tonemap_image_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream ? static_cast<hipStream_t>(stream) : c->stream,
+    RZ_LAUNCH(rz_tonemap_image_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream ? static_cast<hipStream_t>(stream) : c->stream,
                        reinterpret_cast<const float4*>(src_image), reinterpret_cast<uint32_t*>(dst_rgba8), n, c->camera.aperture,
                        c->camera.exposure_time);
     RZ_HIP(c, hipGetLastError());
@@ -2240,7 +2276,7 @@ int hiprz_ray_cast(hiprz_ctx* c, uint32_t x, uint32_t y, hiprz_raycast* out) {
     float depth = 0.0f;
     RZ_HIP(c, hipMemcpyAsync(&depth, c->depth.ptr + size_t(lt) * 256u + in_tile, sizeof(float), hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));
-    hipLaunchKernelGGL(rz_pick_kernel, dim3(1), dim3(1), 0, c->stream, c->dscene, c->dcamera, x, y, depth, c->pick_dev.ptr);
+    RZ_LAUNCH(rz_pick_kernel, dim3(1), dim3(1), 0, c->stream, c->dscene, c->dcamera, x, y, depth, c->pick_dev.ptr);
     int32_t out4[4] = {-1, -1, -1, 0};
     RZ_HIP(c, hipMemcpyAsync(out4, c->pick_dev.ptr, sizeof out4, hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));
@@ -2257,11 +2293,13 @@ int hiprz_pick(hiprz_ctx* c, uint32_t x, uint32_t y, int32_t* instance_out, int3
     return rc;
 }
 
+uint32_t hiprz_kernel_count(void) { return uint32_t(kernel_table().size()); }
+
 int hiprz_selftest(hiprz_ctx* c, uint32_t cases_per_thread, uint32_t seed, uint64_t* mismatches, uint64_t* tested) {
     if (!c || !mismatches || !tested) return HIPRZ_ERR_INVALID;
     (void)hipSetDevice(c->device);
     RZ_HIP(c, hipMemsetAsync(c->counters_dev.ptr, 0, 8 * sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL(rz_selftest_div_kernel, dim3(1024), dim3(256), 0, c->stream, cases_per_thread, seed, c->counters_dev.ptr);
+    RZ_LAUNCH(rz_selftest_div_kernel, dim3(1024), dim3(256), 0, c->stream, cases_per_thread, seed, c->counters_dev.ptr);
     unsigned long long v[3];
     RZ_HIP(c, hipMemcpyAsync(v, c->counters_dev.ptr, sizeof v, hipMemcpyDeviceToHost, c->stream));
     RZ_HIP(c, hipStreamSynchronize(c->stream));

@@ -860,6 +860,7 @@ __global__ void __launch_bounds__(256) rz_sah_emit_kernel(SahViews v, EmitViews 
 // that enters every box visits each of the region's nodes exactly once and ends; every index stays inside the region; the leaves
 // tile the mesh's triangle range exactly.
 bool validate_region(const std::vector<uint32_t>& rec64, uint32_t region, uint32_t n_slots, uint32_t tri_first, uint32_t n_tris, uint32_t max_leaf, std::string& why) {
+    if (std::getenv("HIPRZ_TEST_REFUSE_TREES")) return why = "refused on request (HIPRZ_TEST_REFUSE_TREES: the tests' stand-in for a tree the proof rejects)", false;
     auto word = [&](uint32_t slot, uint32_t w) { return rec64[16 * size_t(slot - region) + w]; };
     auto inside = [&](uint32_t slot) { return slot >= region && slot < region + n_slots; };
     // one walk per ray octant, each on a thread of its own (the walks only read): 8 x n_slots dependent steps are what an upload with
@@ -944,15 +945,15 @@ int build_mesh_sah(hiprz_ctx* c, DeviceMesh& m, float4* blob_tris, float4* blob_
     v.leaf_max = sah_leaf_max(), v.traversal = kSahTraversal;
     if (const char* e = std::getenv("HIPRZ_SAH_COST")) v.traversal = float(std::atof(e));
     const uint32_t blocks = (m.n_tris + 255u) / 256u;
-    hipLaunchKernelGGL(rz_sah_prepare_kernel, dim3(blocks), dim3(256), 0, st, v, make_float3(m.bb_min[0], m.bb_min[1], m.bb_min[2]),
+    RZ_LAUNCH(rz_sah_prepare_kernel, dim3(blocks), dim3(256), 0, st, v, make_float3(m.bb_min[0], m.bb_min[1], m.bb_min[2]),
                        make_float3(m.bb_max[0], m.bb_max[1], m.bb_max[2]));
     uint32_t cur = 0u, list = 0u, n_active = m.n_tris > kSahSmall ? 1u : 0u;
     for (uint32_t level = 0; n_active != 0u; ++level) {
         if (level > 256u) return fail(c, HIPRZ_ERR_DEVICE, "device surface-area build does not end");
-        hipLaunchKernelGGL(rz_sah_clear_kernel, dim3((n_active * 3u * kSahBins * 7u + 255u) / 256u), dim3(256), 0, st, v.hist, n_active);
-        hipLaunchKernelGGL(rz_sah_bin_kernel, dim3(blocks), dim3(256), 0, st, v, cur);
-        hipLaunchKernelGGL(rz_sah_split_kernel, dim3((n_active + 63u) / 64u), dim3(64), 0, st, v, list, n_active);
-        hipLaunchKernelGGL(rz_sah_partition_kernel, dim3(blocks), dim3(256), 0, st, v, cur);
+        RZ_LAUNCH(rz_sah_clear_kernel, dim3((n_active * 3u * kSahBins * 7u + 255u) / 256u), dim3(256), 0, st, v.hist, n_active);
+        RZ_LAUNCH(rz_sah_bin_kernel, dim3(blocks), dim3(256), 0, st, v, cur);
+        RZ_LAUNCH(rz_sah_split_kernel, dim3((n_active + 63u) / 64u), dim3(64), 0, st, v, list, n_active);
+        RZ_LAUNCH(rz_sah_partition_kernel, dim3(blocks), dim3(256), 0, st, v, cur);
         RZ_HIP(c, hipMemcpyAsync(&n_active, v.counters + 1, 4, hipMemcpyDeviceToHost, st));
         RZ_HIP(c, hipMemsetAsync(v.counters + 1, 0, 4, st));
         RZ_HIP(c, hipStreamSynchronize(st));
@@ -963,13 +964,13 @@ int build_mesh_sah(hiprz_ctx* c, DeviceMesh& m, float4* blob_tris, float4* blob_
     RZ_HIP(c, hipMemcpyAsync(&n_roots, v.counters + 2, 4, hipMemcpyDeviceToHost, st));
     RZ_HIP(c, hipStreamSynchronize(st));
     if (n_roots > m.n_tris) return fail(c, HIPRZ_ERR_DEVICE, "device surface-area build: more subtrees than triangles");
-    if (n_roots) hipLaunchKernelGGL(rz_sah_small_kernel, dim3((n_roots + 63u) / 64u), dim3(64), 0, st, v, cur, n_roots);
+    if (n_roots) RZ_LAUNCH(rz_sah_small_kernel, dim3((n_roots + 63u) / 64u), dim3(64), 0, st, v, cur, n_roots);
     EmitViews e{reinterpret_cast<float4*>(c->dev_nodes.ptr), c->slot_parent.ptr + m.region, m.region, m.tri_first};
     const uint32_t max_slots = 2u * m.n_tris - 1u;
-    hipLaunchKernelGGL(rz_sah_emit_kernel, dim3((max_slots + 255u) / 256u), dim3(256), 0, st, v, e);
+    RZ_LAUNCH(rz_sah_emit_kernel, dim3((max_slots + 255u) / 256u), dim3(256), 0, st, v, e);
     BuildViews b{};
     b.tris = v.tris, b.attrs = v.attrs, b.n = m.n_tris, b.perm = v.idx[cur];
-    hipLaunchKernelGGL(rz_build_permute_kernel, dim3(blocks), dim3(256), 0, st, b, tris_tmp, attrs_tmp);
+    RZ_LAUNCH(rz_build_permute_kernel, dim3(blocks), dim3(256), 0, st, b, tris_tmp, attrs_tmp);
     RZ_HIP(c, hipMemcpyAsync(const_cast<float4*>(v.tris), tris_tmp, size_t(m.n_tris) * 48u, hipMemcpyDeviceToDevice, st));
     RZ_HIP(c, hipMemcpyAsync(const_cast<float4*>(v.attrs), attrs_tmp, size_t(m.n_tris) * 96u, hipMemcpyDeviceToDevice, st));
     uint32_t n_nodes = 0u;
@@ -980,8 +981,8 @@ int build_mesh_sah(hiprz_ctx* c, DeviceMesh& m, float4* blob_tris, float4* blob_
     // exact boxes bottom-up over the emitted topology, then the skip links and the 64-byte walk records
     RZ_HIP(c, c->refit_visit.resize(m.n_slots));
     RZ_HIP(c, hipMemsetAsync(c->refit_visit.ptr, 0, size_t(m.n_slots) * 4u, st));
-    hipLaunchKernelGGL(rz_refit_kernel, dim3((m.n_slots + 255u) / 256u), dim3(256), 0, st, e, m.n_slots, blob_tris, blob_attrs, c->refit_visit.ptr, c->nodes64.ptr);
-    hipLaunchKernelGGL(rz_build_links_kernel, dim3((m.n_slots * 8u + 255u) / 256u), dim3(256), 0, st, e, v.counters + 3, c->nodes64.ptr, c->node_skip.ptr);
+    RZ_LAUNCH(rz_refit_kernel, dim3((m.n_slots + 255u) / 256u), dim3(256), 0, st, e, m.n_slots, blob_tris, blob_attrs, c->refit_visit.ptr, c->nodes64.ptr);
+    RZ_LAUNCH(rz_build_links_kernel, dim3((m.n_slots * 8u + 255u) / 256u), dim3(256), 0, st, e, v.counters + 3, c->nodes64.ptr, c->node_skip.ptr);
     RZ_HIP(c, hipStreamSynchronize(st));
     RZ_HIP(c, hipGetLastError());
     return HIPRZ_OK;
@@ -1050,17 +1051,17 @@ int device_build_mesh_trees(hiprz_ctx* c, std::vector<DeviceMesh>& meshes, const
         scale.x = m.bb_max[0] > m.bb_min[0] ? 1024.0f / (m.bb_max[0] - m.bb_min[0]) : 0.0f;
         scale.y = m.bb_max[1] > m.bb_min[1] ? 1024.0f / (m.bb_max[1] - m.bb_min[1]) : 0.0f;
         scale.z = m.bb_max[2] > m.bb_min[2] ? 1024.0f / (m.bb_max[2] - m.bb_min[2]) : 0.0f;
-        hipLaunchKernelGGL(rz_build_morton_kernel, dim3(blocks), dim3(256), 0, st, b, lo, scale);
+        RZ_LAUNCH(rz_build_morton_kernel, dim3(blocks), dim3(256), 0, st, b, lo, scale);
         sort_u32(st, b.keys, m.n_tris, 32, b.perm, b.sorted_keys, c->build_sort);
-        hipLaunchKernelGGL(rz_build_radix_tree_kernel, dim3(blocks), dim3(256), 0, st, b);
-        hipLaunchKernelGGL(rz_build_fit_kernel, dim3(blocks), dim3(256), 0, st, b);
-        hipLaunchKernelGGL(rz_build_decide_kernel, dim3(blocks), dim3(256), 0, st, b);
-        hipLaunchKernelGGL(rz_build_scan_kernel, dim3(1), dim3(1024), 0, st, b.survive, b.rank, m.n_tris - 1u);
+        RZ_LAUNCH(rz_build_radix_tree_kernel, dim3(blocks), dim3(256), 0, st, b);
+        RZ_LAUNCH(rz_build_fit_kernel, dim3(blocks), dim3(256), 0, st, b);
+        RZ_LAUNCH(rz_build_decide_kernel, dim3(blocks), dim3(256), 0, st, b);
+        RZ_LAUNCH(rz_build_scan_kernel, dim3(1), dim3(1024), 0, st, b.survive, b.rank, m.n_tris - 1u);
         EmitViews e{reinterpret_cast<float4*>(c->dev_nodes.ptr), c->slot_parent.ptr + m.region, m.region, m.tri_first};
-        hipLaunchKernelGGL(rz_build_emit_kernel, dim3(blocks), dim3(256), 0, st, b, e);
+        RZ_LAUNCH(rz_build_emit_kernel, dim3(blocks), dim3(256), 0, st, b, e);
         const uint32_t max_slots = 2u * m.n_tris - 1u;
-        hipLaunchKernelGGL(rz_build_links_kernel, dim3((max_slots * 8u + 255u) / 256u), dim3(256), 0, st, e, b.rank + (m.n_tris - 1u), c->nodes64.ptr, c->node_skip.ptr);
-        hipLaunchKernelGGL(rz_build_permute_kernel, dim3(blocks), dim3(256), 0, st, b, tris_tmp, attrs_tmp);
+        RZ_LAUNCH(rz_build_links_kernel, dim3((max_slots * 8u + 255u) / 256u), dim3(256), 0, st, e, b.rank + (m.n_tris - 1u), c->nodes64.ptr, c->node_skip.ptr);
+        RZ_LAUNCH(rz_build_permute_kernel, dim3(blocks), dim3(256), 0, st, b, tris_tmp, attrs_tmp);
         RZ_HIP(c, hipMemcpyAsync(const_cast<float4*>(b.tris), tris_tmp, size_t(m.n_tris) * 48u, hipMemcpyDeviceToDevice, st));
         RZ_HIP(c, hipMemcpyAsync(const_cast<float4*>(b.attrs), attrs_tmp, size_t(m.n_tris) * 96u, hipMemcpyDeviceToDevice, st));
         uint32_t surviving = 0u;
@@ -1083,7 +1084,7 @@ int device_build_mesh_trees(hiprz_ctx* c, std::vector<DeviceMesh>& meshes, const
         RZ_HIP(c, hipMemcpyAsync(c->hot.ptr + c->dscene.off_instances + sizeof(hiprz_instance) * i + offsetof(hiprz_instance, blas_root), &root, 4, hipMemcpyHostToDevice, st));
     }
     RZ_HIP(c, c->ref_to_dev.resize(c->n_tris));
-    if (c->n_tris) hipLaunchKernelGGL(rz_build_refpos_kernel, dim3((c->n_tris + 255u) / 256u), dim3(256), 0, st, blob_tris, c->n_tris, c->ref_to_dev.ptr);
+    if (c->n_tris) RZ_LAUNCH(rz_build_refpos_kernel, dim3((c->n_tris + 255u) / 256u), dim3(256), 0, st, blob_tris, c->n_tris, c->ref_to_dev.ptr);
     RZ_HIP(c, hipStreamSynchronize(st));
     c->device_meshes = meshes;
     c->timings.set("build mesh trees (device)", timer.ms());
@@ -1104,10 +1105,10 @@ int device_build_world_tree(hiprz_ctx* c, bool validate) {
     w.order = reinterpret_cast<uint32_t*>(c->hot.ptr + c->dscene.off_tlas_order);
     w.nodes32 = reinterpret_cast<float4*>(c->dev_nodes.ptr), w.slot_parent = c->slot_parent.ptr + c->world_region, w.region = c->world_region;
     w.n_pairs_out = c->world_items.ptr + n, w.n_order_out = c->world_items.ptr + n + 1u;
-    hipLaunchKernelGGL(rz_build_world_tree_kernel, dim3(1), dim3(64), 0, st, w);
+    RZ_LAUNCH(rz_build_world_tree_kernel, dim3(1), dim3(64), 0, st, w);
     EmitViews e{reinterpret_cast<float4*>(c->dev_nodes.ptr), c->slot_parent.ptr + c->world_region, c->world_region, 0u};
     const uint32_t max_slots = 2u * n + 1u;
-    hipLaunchKernelGGL(rz_build_links_kernel, dim3((max_slots * 8u + 255u) / 256u), dim3(256), 0, st, e, w.n_pairs_out, c->nodes64.ptr, c->node_skip.ptr);
+    RZ_LAUNCH(rz_build_links_kernel, dim3((max_slots * 8u + 255u) / 256u), dim3(256), 0, st, e, w.n_pairs_out, c->nodes64.ptr, c->node_skip.ptr);
     uint32_t out[2] = {0u, 0u};
     RZ_HIP(c, hipMemcpyAsync(out, w.n_pairs_out, 8, hipMemcpyDeviceToHost, st));
     RZ_HIP(c, hipStreamSynchronize(st));
@@ -1134,7 +1135,7 @@ int device_update_triangles(hiprz_ctx* c, uint32_t first, uint32_t n, const hipr
     float4* blob_attrs = reinterpret_cast<float4*>(c->hot.ptr + c->dscene.off_tri_attrs);
     RZ_HIP(c, c->update_tris.assign(tris, n, st));
     RZ_HIP(c, c->update_attrs.assign(attrs, n, st));
-    hipLaunchKernelGGL(rz_refit_scatter_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, c->update_tris.ptr, c->update_attrs.ptr, first, n, c->ref_to_dev.ptr, blob_tris, blob_attrs);
+    RZ_LAUNCH(rz_refit_scatter_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, c->update_tris.ptr, c->update_attrs.ptr, first, n, c->ref_to_dev.ptr, blob_tris, blob_attrs);
     for (const auto& m : c->device_meshes) {
         if (m.n_tris == 0u || m.ref_first + m.n_tris <= first || first + n <= m.ref_first) continue;
         // a mesh too small to have been built is one leaf (the uploaded placeholder): a region of one slot without a parent
@@ -1143,7 +1144,7 @@ int device_update_triangles(hiprz_ctx* c, uint32_t first, uint32_t n, const hipr
         RZ_HIP(c, c->refit_visit.resize(n_slots));
         RZ_HIP(c, hipMemsetAsync(c->refit_visit.ptr, 0, size_t(n_slots) * 4u, st));
         EmitViews e{reinterpret_cast<float4*>(c->dev_nodes.ptr), c->slot_parent.ptr + region, region, m.tri_first};
-        hipLaunchKernelGGL(rz_refit_kernel, dim3((n_slots + 255u) / 256u), dim3(256), 0, st, e, n_slots, blob_tris, blob_attrs, c->refit_visit.ptr, c->nodes64.ptr);
+        RZ_LAUNCH(rz_refit_kernel, dim3((n_slots + 255u) / 256u), dim3(256), 0, st, e, n_slots, blob_tris, blob_attrs, c->refit_visit.ptr, c->nodes64.ptr);
     }
     RZ_HIP(c, hipStreamSynchronize(st));
     RZ_HIP(c, hipGetLastError());

@@ -251,6 +251,28 @@ namespace hiprz {
 
 int fail(hiprz_ctx* ctx, int code, const std::string& msg);
 
+// Every kernel instantiation a launcher can select registers its host stub at load time (RZ_LAUNCH below); hiprz_create resolves each of
+// them against the loaded code objects once per device (hipFuncGetAttributes) and refuses to come up, naming the kernel, when one is
+// missing — a launch of such a kernel ends the process inside the HIP runtime ("Cannot find Symbol with name ...", round 3), which no
+// return code can report.  tools/check_kernels.py proves the same for the files at build time.
+struct KernelEntry {
+    const void* stub;
+    const char* name;  // __PRETTY_FUNCTION__ of the launch site's registration: holds the instantiation's name
+};
+void register_kernel(const void* stub, const char* name);
+template <auto Kernel>
+struct LaunchSite {
+    static const char* name() { return __PRETTY_FUNCTION__; }
+    static const bool registered;
+};
+template <auto Kernel>
+const bool LaunchSite<Kernel>::registered = (register_kernel(reinterpret_cast<const void*>(Kernel), LaunchSite<Kernel>::name()), true);
+#define RZ_LAUNCH(kernel, ...)                                  \
+    do {                                                        \
+        (void)hiprz::LaunchSite<&(kernel)>::registered;         \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);                \
+    } while (0)
+
 #define RZ_HIP(ctx, call)                                                                                       \
     do {                                                                                                        \
         hipError_t rz_e = (call);                                                                               \

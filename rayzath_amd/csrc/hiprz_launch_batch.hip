@@ -11,18 +11,18 @@ void launch_fused_t(hiprz_ctx* c, const DFrame& f) {
     const PassGeometry g = pass_geometry(c);
     const DConfig cfg = make_config(c);
     if (c->mode_flags & kIntegratorFlags) {  // CUDA-compat mode: its own fused kernel on the global scene
-        hipLaunchKernelGGL((rz_compat_pass_kernel<FIRST, COUNT>), g.grid, g.block, 0, c->stream, c->dscene, c->dcamera, cfg, f);
+        RZ_LAUNCH((rz_compat_pass_kernel<FIRST, COUNT>), g.grid, g.block, 0, c->stream, c->dscene, c->dcamera, cfg, f);
         return;
     }
     // the fused kernel's shadow rays use the stack walk: its columns must exist in every mode
     const size_t lds = g.mode == 2 ? g.walk_lds + 4096u : g.walk_lds;  // mode 2: + the parked path state
     if (g.mode == 2) {
-        if (g.lds_scene && c->flat_world) hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 4, true>), g.grid, g.block, g.blob + lds, c->stream, c->dscene, c->dcamera, cfg, f);
-        else if (g.lds_scene) hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 2, true>), g.grid, g.block, g.blob + lds, c->stream, c->dscene, c->dcamera, cfg, f);
-        else hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 2, false>), g.grid, g.block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
+        if (g.lds_scene && c->flat_world) RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 4, true>), g.grid, g.block, g.blob + lds, c->stream, c->dscene, c->dcamera, cfg, f);
+        else if (g.lds_scene) RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 2, true>), g.grid, g.block, g.blob + lds, c->stream, c->dscene, c->dcamera, cfg, f);
+        else RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 2, false>), g.grid, g.block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
     } else {
-        if (g.lds_scene) hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 1, true>), g.grid, g.block, g.blob + lds, c->stream, c->dscene, c->dcamera, cfg, f);
-        else hipLaunchKernelGGL((rz_pass_kernel<FIRST, COUNT, 1, false>), g.grid, g.block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
+        if (g.lds_scene) RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 1, true>), g.grid, g.block, g.blob + lds, c->stream, c->dscene, c->dcamera, cfg, f);
+        else RZ_LAUNCH((rz_pass_kernel<FIRST, COUNT, 1, false>), g.grid, g.block, lds, c->stream, c->dscene, c->dcamera, cfg, f);
     }
 }
 
@@ -37,10 +37,10 @@ void launch_batch_t(hiprz_ctx* c, const DFrame& f, uint32_t n) {
     if (wave_resident(c) && !reference_counters) {  // scenes that are not staged in LDS, without lights: single-wave workgroups walk cooperatively, pass after pass
         const dim3 wgrid(c->n_local_tiles * 4u), wblock(64);
         const bool one_leaf_world = c->dscene.n_instances != 0u && c->flat_world;  // (hiprz_launch_trace.hip: the plain one-step world level)
-        if (c->n_textures == 0u && one_leaf_world) hipLaunchKernelGGL((rz_wave_batch_kernel<COUNT, RZ_SHADOW_PLAIN, 4, true>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
-        else if (c->n_textures == 0u) hipLaunchKernelGGL((rz_wave_batch_kernel<COUNT, RZ_SHADOW_PLAIN, 4>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
-        else if (one_leaf_world) hipLaunchKernelGGL((rz_wave_batch_kernel<COUNT, RZ_SHADOW_NONE, 4, true>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
-        else hipLaunchKernelGGL((rz_wave_batch_kernel<COUNT, RZ_SHADOW_NONE, 4>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
+        if (c->n_textures == 0u && one_leaf_world) RZ_LAUNCH((rz_wave_batch_kernel<COUNT, RZ_SHADOW_PLAIN, 4, true>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
+        else if (c->n_textures == 0u) RZ_LAUNCH((rz_wave_batch_kernel<COUNT, RZ_SHADOW_PLAIN, 4>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
+        else if (one_leaf_world) RZ_LAUNCH((rz_wave_batch_kernel<COUNT, RZ_SHADOW_NONE, 4, true>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
+        else RZ_LAUNCH((rz_wave_batch_kernel<COUNT, RZ_SHADOW_NONE, 4>), wgrid, wblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f, n);
         return;
     }
     const dim3 grid = g.grid, block = g.block;
@@ -55,10 +55,10 @@ void launch_batch_t(hiprz_ctx* c, const DFrame& f, uint32_t n) {
     const bool five = lds * 5u <= 160u * 1024u && grid.x > 2u * 5u * 256u && c->batch_waves != 4;
 #define RZ_BATCH(M, L)                                                                                                                     \
     do {                                                                                                                                   \
-        if (plain && five) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_PLAIN, 5>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
-        else if (plain) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_PLAIN>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
-        else if (dark) hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_NONE>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
-        else hipLaunchKernelGGL((rz_batch_kernel<COUNT, M, L, 1>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);     \
+        if (plain && five) RZ_LAUNCH((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_PLAIN, 5>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
+        else if (plain) RZ_LAUNCH((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_PLAIN>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
+        else if (dark) RZ_LAUNCH((rz_batch_kernel<COUNT, M, L, RZ_SHADOW_NONE>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset); \
+        else RZ_LAUNCH((rz_batch_kernel<COUNT, M, L, 1>), grid, block, lds, c->stream, c->dscene, c->dcamera, cfg, f, n, park_offset);     \
     } while (0)
     if (g.mode == 2) {
         if (g.lds_scene && c->flat_world) RZ_BATCH(4, true);  // a one-leaf world: instance boxes tested up front

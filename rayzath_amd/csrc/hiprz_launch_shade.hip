@@ -18,44 +18,44 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
         // cooperative kernel in their own sorted order.  Only the coloured shadow mask (HIPRZ_COMPAT_SHADOW_COLOR: a texture fetch per
         // crossed triangle, no early out at the first hit) walks inside the shade kernel.
         if (lights && defer_shadows(c) && !(c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR)) {
-            hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_COMPAT_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+            RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_COMPAT_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
             launch_sort(c, f.shadow_key != nullptr);
             if (f.shadow_key) launch_shadow_sort(c);
-            hipLaunchKernelGGL((rz_shadow_coop_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
+            RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
             join_sort(c);
         } else {
-            hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_COMPAT>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+            RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_COMPAT>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
         }
         return;
     }
     if (!lights && c->nolight_kernels && c->n_textures == 0u) {  // no lights, no maps
-        if (g.lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_PLAIN>), grid, block, g.blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-        else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_PLAIN>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        if (g.lds_scene) RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_PLAIN>), grid, block, g.blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        else RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_PLAIN>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
     } else if (!lights && c->nolight_kernels) {  // no next-event estimation: the instantiation without it (no shadow walk, no LDS stack)
-        if (g.lds_scene) hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_NONE>), grid, block, g.blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-        else hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_NONE>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        if (g.lds_scene) RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, true, RZ_SHADOW_NONE>), grid, block, g.blob, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        else RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_NONE>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
     } else if (g.lds_scene) {  // shadow rays inline: LDS-stack walk on the staged scene
-        hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, true, 1>), grid, block, g.blob + g.stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, true, 1>), grid, block, g.blob + g.stack_lds, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
     } else if (lights && defer_shadows(c)) {
         // shading without shadow walks, then every shadow ray of the pass in a lean single-wave kernel
-        hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
+        RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
         // The next pass's ray order: needed by the shadow kernel only when it has no order of its own (HIPRZ_SHADOW_SORT=0) — otherwise
         // that sort runs on the auxiliary stream beside the shadow-ray sort and walk, and the main stream picks it up after them.
         launch_sort(c, f.shadow_key != nullptr);
         if (f.shadow_key) launch_shadow_sort(c);
         const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
         if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) || c->scene_tree != HIPRZ_TREE_REFERENCE) {
-            hipLaunchKernelGGL((rz_shadow_coop_kernel<FIRST, COUNT, 4>), sgrid, sblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
+            RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 4>), sgrid, sblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
         } else {
             const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;
             const uint32_t top_n = std::min<uint32_t>(c->dscene.top_count, big_trees ? 170u : 272u);
-            if (big_trees) hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 6>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
-            else hipLaunchKernelGGL((rz_shadow_kernel<FIRST, COUNT, 4>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
+            if (big_trees) RZ_LAUNCH((rz_shadow_kernel<FIRST, COUNT, 6>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
+            else RZ_LAUNCH((rz_shadow_kernel<FIRST, COUNT, 4>), sgrid, sblock, TopCache::bytes_host(top_n), c->stream, c->dscene, c->dcamera, cfg, f, top_n);
         }
         join_sort(c);
     } else {  // shadow rays inline on skip links with the tree tops staged in LDS
         const uint32_t shade_top = std::min<uint32_t>(c->dscene.top_count, kTopCacheNodes);
-        hipLaunchKernelGGL((rz_shade_kernel<FIRST, COUNT, false, 3>), grid, block, TopCache::bytes_host(shade_top), c->stream, c->dscene, c->dcamera, cfg, f, shade_top);
+        RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, 3>), grid, block, TopCache::bytes_host(shade_top), c->stream, c->dscene, c->dcamera, cfg, f, shade_top);
     }
 }
 

@@ -144,10 +144,10 @@ void radix_sort_n(hipStream_t stream, uint32_t* keys, uint32_t n, uint32_t first
         uint32_t* kout = last ? sorted_keys : key_buf[(p + 1) & 1];
         const uint32_t* vin = val_buf[p & 1];
         uint32_t* vout = last ? perm : val_buf[(p + 1) & 1];
-        hipLaunchKernelGGL(rz_radix_count_kernel, dim3(n_tiles), dim3(256), 0, stream, kin, n, shift, t.counts.ptr, n_tiles, t.digit_total.ptr);
-        hipLaunchKernelGGL(rz_radix_offsets_kernel, dim3(256), dim3(256), 0, stream, t.counts.ptr, n_tiles, t.digit_total.ptr);
-        if (p == 0) hipLaunchKernelGGL((rz_radix_scatter_kernel<true>), dim3(n_tiles), dim3(256), 0, stream, kin, vin, kout, vout, n, shift, t.counts.ptr, n_tiles, t.digit_total.ptr);
-        else hipLaunchKernelGGL((rz_radix_scatter_kernel<false>), dim3(n_tiles), dim3(256), 0, stream, kin, vin, kout, vout, n, shift, t.counts.ptr, n_tiles, t.digit_total.ptr);
+        RZ_LAUNCH(rz_radix_count_kernel, dim3(n_tiles), dim3(256), 0, stream, kin, n, shift, t.counts.ptr, n_tiles, t.digit_total.ptr);
+        RZ_LAUNCH(rz_radix_offsets_kernel, dim3(256), dim3(256), 0, stream, t.counts.ptr, n_tiles, t.digit_total.ptr);
+        if (p == 0) RZ_LAUNCH((rz_radix_scatter_kernel<true>), dim3(n_tiles), dim3(256), 0, stream, kin, vin, kout, vout, n, shift, t.counts.ptr, n_tiles, t.digit_total.ptr);
+        else RZ_LAUNCH((rz_radix_scatter_kernel<false>), dim3(n_tiles), dim3(256), 0, stream, kin, vin, kout, vout, n, shift, t.counts.ptr, n_tiles, t.digit_total.ptr);
     }
 }
 void radix_sort(hiprz_ctx* c, uint32_t* keys, uint32_t* perm, hiprz_frame_state::SortTemp& t, hipStream_t stream) {
@@ -206,7 +206,7 @@ void join_sort(hiprz_ctx* c) {
 // rays that have not been through a sort (reordering was switched on between two batches): the identity order
 void launch_sort_identity(hiprz_ctx* c) {
     if (c->n_local_tiles == 0) return;
-    hipLaunchKernelGGL(rz_sort_identity_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->n_local_tiles * 256u, c->sort_perm.ptr);
+    RZ_LAUNCH(rz_sort_identity_kernel, dim3(c->n_local_tiles), dim3(256), 0, c->stream, c->n_local_tiles * 256u, c->sort_perm.ptr);
     c->perm_valid = true;
 }
 

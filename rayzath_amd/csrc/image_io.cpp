@@ -313,10 +313,12 @@ bool decode_pnm(const uint8_t* b, size_t size, const std::string& name, Image& o
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// JPEG (ITU-T T.81): baseline / extended sequential DCT, Huffman coded, 8-bit samples, 1 or 3 components, restart intervals.
+// JPEG (ITU-T T.81): baseline / extended sequential and PROGRESSIVE DCT (spectral selection + successive approximation, Annex G), Huffman
+// coded, 8-bit samples, 1 or 3 components, interleaved and per-component scans, restart intervals — what the reference reads through
+// stb_image (loader.cpp:36-144).
 // Chroma is upsampled the way stb_image does it (3:1 triangle filter for factor 2, replication otherwise) and converted with its
 // 20-bit fixed-point YCbCr matrix; the inverse DCT is a separable double-precision one rounded to nearest, so a sample can differ
-// from stb_image's integer IDCT by one code value.  Progressive and arithmetic-coded files are refused.
+// from stb_image's integer IDCT by one code value.  Arithmetic-coded, lossless and hierarchical files are refused.
 // ---------------------------------------------------------------------------------------------------------------------
 struct JpegHuffman {
     uint8_t bits[17] = {0};
@@ -439,22 +441,47 @@ void jpeg_upsample_row(const uint8_t* near_row, const uint8_t* far_row, uint32_t
             for (int j = 0; j < hs; ++j) out[i * hs + j] = near_row[i];
     }
 }
+// One scan's entropy-coded segment decoded into the frame's coefficient arrays.  Sequential scans (Ss = 0, Se = 63, Ah = Al = 0) and
+// the four progressive procedures of T.81 Annex G: DC first / DC refinement (G.1.2.1), AC first with end-of-band runs (G.1.2.2),
+// AC refinement with its correction bits (G.1.2.3, Figure G.7).  Coefficients stay UNquantised (point-transformed by Al) until all
+// scans are in.
+struct JpegScan {
+    int n = 0;              // components of this scan
+    int comp[3] = {0, 0, 0};
+    int ss = 0, se = 63, ah = 0, al = 0;
+};
 bool decode_jpeg(const uint8_t* b, size_t size, const std::string& name, Image& out, std::string& why) {
     auto bad = [&](const std::string& m) { return why = name + ": " + m, false; };
     uint16_t quant[4][64] = {};
     JpegHuffman dc[4], ac[4];
     JpegComponent comp[3];
+    std::vector<int16_t> coefs[3];       // per component: blocks in raster order of its padded block grid, 64 coefficients each (natural order)
+    uint32_t blocks_w[3] = {0, 0, 0}, blocks_h[3] = {0, 0, 0};   // padded grid (whole MCUs)
+    uint32_t own_w[3] = {0, 0, 0}, own_h[3] = {0, 0, 0};         // the component's own extent in blocks: what a scan of this component alone covers (A.2.3)
     int n_comp = 0, hmax = 1, vmax = 1;
-    uint32_t width = 0, height = 0, restart_interval = 0;
-    bool have_frame = false;
+    uint32_t width = 0, height = 0, restart_interval = 0, mcus_x = 0, mcus_y = 0;
+    bool have_frame = false, progressive = false, any_scan = false;
     size_t pos = 2;
     while (true) {
-        if (pos + 4 > size) return bad("truncated JPEG");
-        if (b[pos] != 0xFF) return bad("JPEG marker expected");
+        if (pos + 4 > size) {
+            if (any_scan) break;  // no EOI: stb_image shows what it has, too
+            return bad("truncated JPEG");
+        }
+        if (b[pos] != 0xFF) {
+            if (any_scan) {  // stray bytes behind a scan: look for the next marker
+                ++pos;
+                continue;
+            }
+            return bad("JPEG marker expected");
+        }
         while (pos < size && b[pos] == 0xFF) ++pos;
+        if (pos >= size) break;
         const uint8_t marker = b[pos++];
-        if (marker == 0xD9) return bad("JPEG ends before its scan");
-        if (marker == 0x01 || (marker >= 0xD0 && marker <= 0xD7)) continue;
+        if (marker == 0xD9) {
+            if (any_scan) break;
+            return bad("JPEG ends before its scan");
+        }
+        if (marker == 0x00 || marker == 0x01 || (marker >= 0xD0 && marker <= 0xD7)) continue;
         if (pos + 2 > size) return bad("truncated JPEG");
         const size_t len = (size_t(b[pos]) << 8) | b[pos + 1];
         if (len < 2 || pos + len > size) return bad("truncated JPEG segment");
@@ -484,7 +511,8 @@ bool decode_jpeg(const uint8_t* b, size_t size, const std::string& name, Image& 
                 i += size_t(total);
                 h.build();
             }
-        } else if (marker == 0xC0 || marker == 0xC1) {  // SOF0 / SOF1
+        } else if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2) {  // SOF0 / SOF1 / SOF2 (progressive)
+            if (have_frame) return bad("a second JPEG frame header");
             if (n < 6 || d[0] != 8) return bad("only 8-bit JPEG files are decoded");
             height = (uint32_t(d[1]) << 8) | d[2], width = (uint32_t(d[3]) << 8) | d[4];
             n_comp = d[5];
@@ -495,75 +523,185 @@ bool decode_jpeg(const uint8_t* b, size_t size, const std::string& name, Image& 
                 if (comp[c].h < 1 || comp[c].h > 4 || comp[c].v < 1 || comp[c].v > 4 || comp[c].tq > 3) return bad("bad JPEG frame header");
                 hmax = std::max(hmax, comp[c].h), vmax = std::max(vmax, comp[c].v);
             }
+            if (n_comp == 1) comp[0].h = comp[0].v = hmax = vmax = 1;  // a single component is never interleaved: one block per MCU
+            mcus_x = (width + 8u * uint32_t(hmax) - 1) / (8u * uint32_t(hmax)), mcus_y = (height + 8u * uint32_t(vmax) - 1) / (8u * uint32_t(vmax));
+            for (int c = 0; c < n_comp; ++c) {
+                blocks_w[c] = mcus_x * uint32_t(comp[c].h), blocks_h[c] = mcus_y * uint32_t(comp[c].v);
+                const uint32_t cw = (width * uint32_t(comp[c].h) + uint32_t(hmax) - 1) / uint32_t(hmax), ch = (height * uint32_t(comp[c].v) + uint32_t(vmax) - 1) / uint32_t(vmax);
+                own_w[c] = (cw + 7) / 8, own_h[c] = (ch + 7) / 8;
+                if (size_t(blocks_w[c]) * blocks_h[c] > (size_t(1) << 26)) return bad("JPEG dimensions out of range");
+                coefs[c].assign(size_t(blocks_w[c]) * blocks_h[c] * 64u, 0);
+            }
+            progressive = marker == 0xC2;
             have_frame = true;
-        } else if (marker == 0xC2 || (marker >= 0xC3 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC)) {
-            return bad(marker == 0xC2 ? "progressive JPEG files are not decoded (baseline ones are)" : "this JPEG coding process is not decoded (baseline is)");
+        } else if (marker >= 0xC3 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC) {
+            return bad("this JPEG coding process is not decoded (Huffman-coded baseline, extended sequential and progressive DCT are)");
         } else if (marker == 0xDD) {
             if (n < 2) return bad("bad DRI");
             restart_interval = (uint32_t(d[0]) << 8) | d[1];
-        } else if (marker == 0xDA) {  // SOS: the one scan of a sequential file
+        } else if (marker == 0xDA) {  // SOS: one scan; its entropy-coded segment follows the header
             if (!have_frame) return bad("JPEG scan before its frame header");
-            if (n < 1 || d[0] != n_comp || n < size_t(1 + 2 * n_comp + 3)) return bad("only single-scan (interleaved) JPEG files are decoded");
-            for (int k = 0; k < n_comp; ++k) {
+            JpegScan scan;
+            scan.n = n ? d[0] : 0;
+            if (scan.n < 1 || scan.n > n_comp || n < size_t(1 + 2 * scan.n + 3)) return bad("bad JPEG scan header");
+            for (int k = 0; k < scan.n; ++k) {
                 int c = 0;
                 while (c < n_comp && comp[c].id != d[1 + 2 * k]) ++c;
                 if (c == n_comp) return bad("bad JPEG scan header");
+                for (int e = 0; e < k; ++e)
+                    if (scan.comp[e] == c) return bad("bad JPEG scan header");
+                scan.comp[k] = c;
                 comp[c].td = d[2 + 2 * k] >> 4, comp[c].ta = d[2 + 2 * k] & 15;
-                if (comp[c].td > 3 || comp[c].ta > 3 || !dc[comp[c].td].defined || !ac[comp[c].ta].defined) return bad("JPEG scan uses an undefined Huffman table");
+                if (comp[c].td > 3 || comp[c].ta > 3) return bad("bad JPEG scan header");
+            }
+            scan.ss = d[1 + 2 * scan.n], scan.se = d[2 + 2 * scan.n], scan.ah = d[3 + 2 * scan.n] >> 4, scan.al = d[3 + 2 * scan.n] & 15;
+            if (!progressive) {
+                if (scan.ss != 0 || scan.se != 63 || scan.ah != 0 || scan.al != 0) return bad("bad JPEG scan header (a sequential scan covers all 64 coefficients)");
+            } else if (scan.ss > scan.se || scan.se > 63 || scan.ah > 13 || scan.al > 13 || (scan.ss == 0 && scan.se != 0) || (scan.ss != 0 && scan.n != 1)) {
+                return bad("bad progressive JPEG scan header");  // G.1.1.1.1: DC scans hold only DC, AC scans one component
+            }
+            const bool dc_scan = scan.ss == 0, ac_scan = scan.se > 0;
+            for (int k = 0; k < scan.n; ++k) {
+                const JpegComponent& cc = comp[scan.comp[k]];
+                if ((dc_scan && scan.ah == 0 && !dc[cc.td].defined) || (ac_scan && !ac[cc.ta].defined)) return bad("JPEG scan uses an undefined Huffman table");
             }
             pos += len;
-            break;
-        }
-        pos += len;
-    }
-    const uint32_t mcu_w = 8u * uint32_t(hmax), mcu_h = 8u * uint32_t(vmax);
-    const uint32_t mcus_x = (width + mcu_w - 1) / mcu_w, mcus_y = (height + mcu_h - 1) / mcu_h;
-    if (n_comp == 1) comp[0].h = comp[0].v = 1;  // a single-component scan is not interleaved: one block per MCU
-    const uint32_t gx = n_comp == 1 ? (width + 7) / 8 : mcus_x, gy = n_comp == 1 ? (height + 7) / 8 : mcus_y;
-    for (int c = 0; c < n_comp; ++c) {
-        comp[c].w = gx * 8u * uint32_t(comp[c].h), comp[c].hgt = gy * 8u * uint32_t(comp[c].v);
-        comp[c].plane.assign(size_t(comp[c].w) * comp[c].hgt, 0);
-    }
-    JpegBits br{b + pos, b + size};
-    uint32_t until_restart = restart_interval;
-    int coef[64];
-    for (uint32_t my = 0; my < gy; ++my)
-        for (uint32_t mx = 0; mx < gx; ++mx) {
-            if (restart_interval && until_restart == 0) {  // RSTn: byte-align, skip the marker, reset the predictors
-                br.reset();
-                while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) ++br.p;
-                if (br.p + 1 >= br.end) return bad("JPEG restart marker missing");
-                br.p += 2;
-                for (int c = 0; c < n_comp; ++c) comp[c].pred = 0;
-                until_restart = restart_interval;
-            }
-            for (int c = 0; c < n_comp; ++c)
-                for (int by = 0; by < comp[c].v; ++by)
-                    for (int bx = 0; bx < comp[c].h; ++bx) {
-                        std::memset(coef, 0, sizeof coef);
+            JpegBits br{b + pos, b + size};
+            // the scan's units: MCUs of the interleaved components, or the single component's own blocks in raster order (A.2.2, A.2.3)
+            const bool interleaved = scan.n > 1;
+            const uint32_t units_x = interleaved ? mcus_x : own_w[scan.comp[0]], units_y = interleaved ? mcus_y : own_h[scan.comp[0]];
+            uint32_t until_restart = restart_interval, eob_run = 0;
+            for (int c = 0; c < n_comp; ++c) comp[c].pred = 0;
+            const int p1 = 1 << scan.al, m1 = -(1 << scan.al);
+            auto block = [&](int c, uint32_t bx, uint32_t by) -> bool {   // one 8x8 block of this scan
+                int16_t* q = &coefs[c][(size_t(by) * blocks_w[c] + bx) * 64u];
+                if (dc_scan) {
+                    if (scan.ah == 0) {
                         const int t = jpeg_decode_symbol(br, dc[comp[c].td]);
-                        if (t < 0 || t > 15) return bad("bad JPEG Huffman code");
+                        if (t < 0 || t > 15) return false;
                         comp[c].pred += jpeg_extend(br.receive(t), t);
-                        coef[0] = comp[c].pred * quant[comp[c].tq][0];
-                        for (int k = 1; k < 64;) {
-                            const int rs = jpeg_decode_symbol(br, ac[comp[c].ta]);
-                            if (rs < 0) return bad("bad JPEG Huffman code");
-                            const int r = rs >> 4, sz = rs & 15;
-                            if (sz == 0) {
-                                if (r != 15) break;  // end of block
+                        q[0] = int16_t(comp[c].pred * p1);
+                    } else if (br.bit()) {
+                        q[0] = int16_t(q[0] | p1);
+                    }
+                }
+                if (!ac_scan) return true;
+                const JpegHuffman& h = ac[comp[c].ta];
+                int k = std::max(scan.ss, 1);
+                if (scan.ah == 0) {  // first pass over this band
+                    if (eob_run) {
+                        --eob_run;
+                        return true;
+                    }
+                    while (k <= scan.se) {
+                        const int rs = jpeg_decode_symbol(br, h);
+                        if (rs < 0) return false;
+                        const int r = rs >> 4, sz = rs & 15;
+                        if (sz == 0) {
+                            if (r == 15) {
                                 k += 16;
                                 continue;
                             }
-                            k += r;
-                            if (k > 63) return bad("JPEG block overruns");
-                            coef[kZigzag[k]] = jpeg_extend(br.receive(sz), sz) * quant[comp[c].tq][kZigzag[k]];
-                            ++k;
+                            eob_run = (1u << r) - 1u;   // EOBn: this band ends here, in this block and in the next eob_run ones
+                            if (r) eob_run += uint32_t(br.receive(r));
+                            break;
                         }
-                        const size_t x0 = (size_t(mx) * comp[c].h + bx) * 8, y0 = (size_t(my) * comp[c].v + by) * 8;
-                        jpeg_idct(coef, &comp[c].plane[y0 * comp[c].w + x0], comp[c].w);
+                        k += r;
+                        if (k > scan.se) return false;
+                        q[kZigzag[k]] = int16_t(jpeg_extend(br.receive(sz), sz) * p1);
+                        ++k;
                     }
-            if (restart_interval) --until_restart;
+                    return true;
+                }
+                // refinement of the band: a correction bit for every coefficient that is already non-zero, new +-1 coefficients placed
+                // behind runs of coefficients that are still zero (Figure G.7)
+                auto correct = [&](int16_t& v) {
+                    if (br.bit() && (v & p1) == 0) v = int16_t(v >= 0 ? v + p1 : v + m1);
+                };
+                if (eob_run == 0) {
+                    while (k <= scan.se) {
+                        const int rs = jpeg_decode_symbol(br, h);
+                        if (rs < 0) return false;
+                        int r = rs >> 4;
+                        const int sz = rs & 15;
+                        int fresh = 0;
+                        if (sz == 0) {
+                            if (r < 15) {
+                                eob_run = (1u << r);   // this block included (the tail below consumes one)
+                                if (r) eob_run += uint32_t(br.receive(r));
+                                break;
+                            }
+                        } else {
+                            if (sz != 1) return false;
+                            fresh = br.bit() ? p1 : m1;
+                        }
+                        for (; k <= scan.se; ++k) {   // pass r zero-history coefficients, correcting the others on the way
+                            int16_t& v = q[kZigzag[k]];
+                            if (v != 0) {
+                                correct(v);
+                            } else if (r-- == 0) {
+                                if (fresh) v = int16_t(fresh);
+                                ++k;
+                                break;
+                            }
+                        }
+                    }
+                }
+                if (eob_run) {   // the rest of the band holds no new coefficients: corrections only
+                    for (; k <= scan.se; ++k) {
+                        int16_t& v = q[kZigzag[k]];
+                        if (v != 0) correct(v);
+                    }
+                    --eob_run;
+                }
+                return true;
+            };
+            for (uint32_t uy = 0; uy < units_y; ++uy)
+                for (uint32_t ux = 0; ux < units_x; ++ux) {
+                    if (restart_interval && until_restart == 0) {  // RSTn: byte-align, skip the marker, reset predictors and the EOB run
+                        br.reset();
+                        while (br.p + 1 < br.end && !(br.p[0] == 0xFF && br.p[1] >= 0xD0 && br.p[1] <= 0xD7)) ++br.p;
+                        if (br.p + 1 >= br.end) return bad("JPEG restart marker missing");
+                        br.p += 2;
+                        for (int c = 0; c < n_comp; ++c) comp[c].pred = 0;
+                        eob_run = 0;
+                        until_restart = restart_interval;
+                    }
+                    if (interleaved) {
+                        for (int k = 0; k < scan.n; ++k) {
+                            const int c = scan.comp[k];
+                            for (int by = 0; by < comp[c].v; ++by)
+                                for (int bx = 0; bx < comp[c].h; ++bx)
+                                    if (!block(c, ux * uint32_t(comp[c].h) + uint32_t(bx), uy * uint32_t(comp[c].v) + uint32_t(by))) return bad("bad JPEG Huffman code");
+                        }
+                    } else if (!block(scan.comp[0], ux, uy)) {
+                        return bad("bad JPEG Huffman code");
+                    }
+                    if (restart_interval) --until_restart;
+                }
+            any_scan = true;
+            pos = size_t(br.p - b);   // the next marker is at or behind the reader's position
+            if (!progressive && scan.n == n_comp) break;   // the one scan of an interleaved sequential file
+            continue;
         }
+        pos += len;
+    }
+    if (!any_scan) return bad("JPEG without a scan");
+    // all scans are in: dequantise, inverse DCT
+    {
+        int coef[64];
+        for (int c = 0; c < n_comp; ++c) {
+            comp[c].w = blocks_w[c] * 8u, comp[c].hgt = blocks_h[c] * 8u;
+            comp[c].plane.assign(size_t(comp[c].w) * comp[c].hgt, 0);
+            for (uint32_t by = 0; by < blocks_h[c]; ++by)
+                for (uint32_t bx = 0; bx < blocks_w[c]; ++bx) {
+                    const int16_t* q = &coefs[c][(size_t(by) * blocks_w[c] + bx) * 64u];
+                    for (int k = 0; k < 64; ++k) coef[k] = int(q[k]) * int(quant[comp[c].tq][k]);
+                    jpeg_idct(coef, &comp[c].plane[size_t(by) * 8u * comp[c].w + size_t(bx) * 8u], comp[c].w);
+                }
+            coefs[c] = std::vector<int16_t>();
+        }
+    }
     out.width = width, out.height = height, out.channels = uint32_t(n_comp);
     out.data.assign(size_t(width) * height * n_comp, 0);
     if (n_comp == 1) {

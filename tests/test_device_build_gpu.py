@@ -502,3 +502,34 @@ def test_engine_through_a_random_sequence_of_changes(built, seed, scene):
             both(lambda w: w.camera.ray_cast_at(x, y) if hasattr(w.camera, "ray_cast_at") else None)
         compare(f"step {step} op {op}")
     assert "refit mesh trees (device)" in a.context.timings()
+
+
+@pytest.mark.parametrize("devices", [0, [0, 0]])
+@pytest.mark.parametrize("call", ["rebuild_trees", "update_instances"])
+def test_a_refused_in_place_change_leaves_no_scene_behind(built, monkeypatch, devices, call):
+    """hiprz_rebuild_trees and hiprz_update_instances rewrite node tables, triangle order and instance roots IN PLACE.  When the host then
+    refuses to prove the device's output (here: on request — HIPRZ_TEST_REFUSE_TREES stands in for a tree the proof rejects), the call fails
+    AND the context has no scene any more: the next render returns HIPRZ_ERR_STATE instead of walking tables nobody proved terminating — on
+    every stream that shares the device's scene copy — and a fresh upload brings the context back to the frame it rendered before."""
+    from rayzath_amd._lib import HiprzError
+    world = scenes.living_room(128, 80, 16)
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(LightSampling(1, 1), Tracing(5, 4)).struct()
+    ctx = Context(devices)
+    ctx.set_tree(DEVICE_SAH)
+    ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(cfg)
+    ctx.render(1), ctx.render(4)
+    before = ctx.read_accum()
+    monkeypatch.setenv("HIPRZ_TEST_REFUSE_TREES", "1")
+    with pytest.raises(HiprzError) as e:
+        ctx.rebuild_trees(DEVICE_SAH) if call == "rebuild_trees" else ctx.update_instances(flat.instances)
+    assert e.value.code == _abi.ERR_DEVICE and "refused" in str(e.value)
+    monkeypatch.delenv("HIPRZ_TEST_REFUSE_TREES")
+    for attempt in (lambda: ctx.render(1), lambda: ctx.ray_cast(10, 10), lambda: ctx.update_instances(flat.instances), lambda: ctx.rebuild_trees(DEVICE_SAH)):
+        with pytest.raises(HiprzError) as e:
+            attempt()
+        assert e.value.code == _abi.ERR_STATE, str(e.value)
+    ctx.upload_scene(flat)
+    ctx.render(1), ctx.render(4)
+    assert np.array_equal(ctx.read_accum(), before)
+    ctx.close()

@@ -46,42 +46,84 @@ def digest(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-@pytest.mark.parametrize("name,rgb_close,alpha_equal", [("B", 1.0, 1.0), ("C", 0.9999, 0.9999), ("D", 0.9999, 0.9999), ("E", 0.999, 0.9999)])
-def test_full_size_frame_against_the_oracle(built, name, rgb_close, alpha_equal):
-    """Four passes of the whole frame on the GPU (default settings: what bench.py runs) and in the CPU oracle.  The Cornell box:
-    every one of the 2 073 600 pixels bit-exact.  The others: libm-vs-ocml ulps (sinf / cosf / powf / acosf of the sampling
-    routines) move a few paths across an edge — one pixel in two million on the sphere scene."""
+PASSES = 12   # max_depth (8) + 4: paths run into the depth limit, are ended there and start again with regenerated anti-aliased rays
+_ORACLE = {}
+
+
+def oracle_frame(name):
+    """PASSES passes of the whole frame in the CPU oracle (the first one counted), once per config: both packagings are compared with it."""
+    if name not in _ORACLE:
+        flat, cam, depth = scene(name)
+        ref = oracle.OracleRenderer(flat, cam, RenderConfig(tracing=Tracing(depth, 8)).struct())
+        first = ref.render(1, counted=True)
+        ref.render(PASSES - 1)
+        _ORACLE[name] = dict(first=first, accum=ref.accum, depth=ref.depth, rays=ref.traced_rays, state=ref.state if name == "B" else None)
+        ref.close()
+    return _ORACLE[name]
+
+
+@pytest.mark.parametrize("packaging", ["bare", "shipped"])
+@pytest.mark.parametrize("name,rgb_close,alpha_equal", [("B", 0.999999, 0.999999), ("C", 0.9999, 0.9999), ("D", 0.9997, 0.9997), ("E", 0.992, 0.9994)])
+def test_full_size_frame_against_the_oracle(built, name, packaging, rgb_close, alpha_equal):
+    """PASSES = max_depth + 4 passes of the whole frame on the GPU and in the CPU oracle — one first pass, then batches of 8 and 3 cumulative
+    passes (the second batch size is new to the context: another graph): every path that survives 8 segments is ended by the depth limit
+    and its pixel goes on with a regenerated anti-aliased ray; the sorted pipelines re-sort their rays eleven times.
+      bare     a plain hiprz_create context: the snapshot's (reference) trees, one stream; its first pass is counted and every work
+               counter compared with the oracle's
+      shipped  what bench.py's `hosts_default_packaging`, rayzath_amd.engine.Engine and Hip::Engine run: hiprz_set_tree(HIPRZ_TREE_AUTO)
+               (device-built surface-area trees for C, D, E) on engine.default_streams() streams (two for scenes without lights)
+    What differs between the two sides is glibc-vs-ocml libm (sinf / cosf / powf / acosf of the sampling routines, expf / cosf of the lights):
+    an ulp there moves a path across an edge — a discrete event per segment, so the share of touched pixels grows with the passes.  Measured
+    on MI355X at 12 passes (4 passes in brackets): the Cornell box ONE pixel of 2 073 600 (none), path state included; C 0.999998 within
+    1e-3 (1.0); D 0.99998, finished paths 0.99985 equal (0.99999); E 0.9938 within 1e-3, finished paths 0.9996 equal (0.9996 / 0.99998) —
+    its lights put expf and cosf into every segment.  Both packagings give the same figures (their frames are equal bit for bit).
+    Thresholds = measured minus a margin."""
+    from rayzath_amd.engine import TREE_AUTO, default_streams
     flat, cam, depth = scene(name)
-    cfg = RenderConfig(tracing=Tracing(depth, 4)).struct()
-    ctx = context(name)
-    first = ctx.render_counted(1)
-    ctx.render(3)
-    ref = oracle.OracleRenderer(flat, cam, cfg)
-    ref_first = ref.render(1, counted=True)
-    ref.render(3)
-    acc, racc = ctx.read_accum(), ref.accum
-    assert np.array_equal(ctx.read_depth(), ref.depth)                       # first-hit distances: no libm on that path
-    # the work counters of the first pass: everything of the closest-hit walk and the shading is exact; whether a light sample
-    # is worth a shadow ray hangs on `radiance < 1e-4` behind expf / cosf, so the shadow-ray counters may differ by a few rays in
-    # ten million (config E: one)
-    for k in ("segments", "hits", "light_samples", "texel_fetches", "finished"):
-        assert first[k] == ref_first[k], k
-    for total, shadow in (("box_tests", "shadow_box_tests"), ("tri_tests", "shadow_tri_tests")):
-        assert first[total] - first[shadow] == ref_first[total] - ref_first[shadow], total
-    for k in ("shadow_rays", "shadow_box_tests", "shadow_tri_tests"):
-        assert abs(first[k] - ref_first[k]) <= 1e-5 * max(ref_first[k], 1), k
-    if name in ("B", "C", "D"):
-        assert first == ref_first
+    ref = oracle_frame(name)
+    if packaging == "bare":
+        ctx = context(name, passes=8)
+        first, ref_first = ctx.render_counted(1), ref["first"]
+        # the work counters of the first pass: everything of the closest-hit walk and the shading is exact; whether a light sample
+        # is worth a shadow ray hangs on `radiance < 1e-4` behind expf / cosf, so the shadow-ray counters may differ by a few rays in
+        # ten million (config E: one)
+        for k in ("segments", "hits", "light_samples", "texel_fetches", "finished"):
+            assert first[k] == ref_first[k], k
+        for total, shadow in (("box_tests", "shadow_box_tests"), ("tri_tests", "shadow_tri_tests")):
+            assert first[total] - first[shadow] == ref_first[total] - ref_first[shadow], total
+        for k in ("shadow_rays", "shadow_box_tests", "shadow_tri_tests"):
+            assert abs(first[k] - ref_first[k]) <= 1e-5 * max(ref_first[k], 1), k
+        if name in ("B", "C", "D"):
+            assert first == ref_first
+    else:
+        k = default_streams(len(flat.spot_lights) + len(flat.direct_lights))
+        ctx = Context([0] * k) if k > 1 else Context(0)
+        ctx.set_tree(TREE_AUTO)
+        ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(RenderConfig(tracing=Tracing(depth, 8)).struct())
+        assert ctx.device_count() == (1 if name == "E" else 2) and ctx.tree() == (0 if name == "B" else 3)
+        ctx.render(1)
+    ctx.render(8), ctx.render(PASSES - 9)
+    acc, racc = ctx.read_accum(), ref["accum"]
+    assert np.array_equal(ctx.read_depth(), ref["depth"])                       # first-hit distances: no libm on that path
     close = (np.abs(acc[..., :3] - racc[..., :3]) <= 1e-3 * np.maximum(np.abs(racc[..., :3]), 1.0)).all(-1).mean()
     same_alpha = (acc[..., 3] == racc[..., 3]).mean()
     exact = (acc == racc).all(-1).mean()
-    print(f"config {name}: rgb within 1e-3 {close:.6f}, alpha equal {same_alpha:.6f}, bit-exact pixels {exact:.6f}")
+    print(f"config {name} ({packaging}), {PASSES} passes: rgb within 1e-3 {close:.6f}, alpha equal {same_alpha:.6f}, bit-exact pixels {exact:.6f}")
+    if name == "B":   # the pixels that differ, for the record (gpurun_out/.../pytest log with -s)
+        for y, x in np.argwhere((acc != racc).any(-1))[:4]:
+            print(f"  pixel ({x}, {y}): gpu {acc[y, x]} oracle {racc[y, x]}")
     assert close >= rgb_close and same_alpha >= alpha_equal
-    if rgb_close == 1.0:
-        assert exact == 1.0
+    assert racc[..., 3].max() >= 2.0      # paths ended and started again within the frame
+    if name == "B":
+        assert (acc != racc).any(-1).sum() <= 2
+        state = ctx.read_state()
+        for key, want in ref["state"].items():   # where every path stands after the depth limit and the regenerated rays
+            differs = state[key] != want
+            assert (differs.reshape(differs.shape[0], differs.shape[1], -1).any(-1)).sum() <= 2, key
     elif name == "C":
-        assert exact >= 0.9999
-    assert ctx.ray_count() == 4 * cam.width * cam.height == ref.traced_rays
+        assert exact >= 0.9998
+    assert ctx.ray_count() == PASSES * cam.width * cam.height == ref["rays"]
+    ctx.close()
 
 
 def test_config_e_with_several_samples_per_light_type(built):

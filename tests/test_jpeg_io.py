@@ -277,3 +277,52 @@ def test_jpeg_map_through_the_mtl_loader_and_refusals(tmp_path):
     (tmp_path / "cut.jpg").write_bytes(data[:60])
     with pytest.raises(HiprzError):
         scene_io.read_image(str(tmp_path / "cut.jpg"))
+
+
+GOLDEN_JPEG = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "jpeg")
+
+
+@pytest.mark.parametrize("name", ["rgb444", "rgb420", "rgb422_restart", "grey", "rgb420_tiny"])
+def test_progressive_jpeg_equals_the_baseline_file_of_the_same_coefficients(name):
+    """Progressive JPEG maps (the reference reads them through stb_image, loader.cpp:36-144).  tests/golden/make_progressive_jpeg.py saved
+    every picture twice with the same quantisation: as a progressive file — ten scans: DC with point transform, luma AC in two spectral
+    bands, full-band chroma, then the refinement scans; end-of-band runs and a restart interval among them — and as a baseline file.  The two
+    hold the same quantised coefficients, so the decoded pixels must be EQUAL; the baseline path is pinned above.  libjpeg's own decode of
+    the progressive file (stored beside them) is a looser second anchor: its integer IDCT and colour conversion round differently from
+    stb_image's, which the library follows."""
+    import os
+    data = open(os.path.join(GOLDEN_JPEG, name + "_progressive.jpg"), "rb").read()
+    assert b"\xFF\xC2" in data and data.count(b"\xFF\xDA") >= (6 if name == "grey" else 10)
+    progressive = scene_io.read_image(os.path.join(GOLDEN_JPEG, name + "_progressive.jpg"))
+    baseline = scene_io.read_image(os.path.join(GOLDEN_JPEG, name + "_baseline.jpg"))
+    assert np.array_equal(progressive, baseline)
+    expected = np.load(os.path.join(GOLDEN_JPEG, "jpeg_expected.npz"))
+    diff = np.abs(progressive.astype(int) - expected[name].astype(int))
+    assert progressive.shape == expected[name].shape and diff.max() <= 4 and diff.mean() < 0.4
+    assert np.abs(progressive.astype(int) - expected[name + "_source"].astype(int)).mean() < 6.0      # and it is the picture
+
+
+def test_progressive_jpeg_cut_short_and_malformed(tmp_path):
+    """A progressive file that ends after some of its scans still decodes — coarser, as stb_image shows it — and gets closer to the picture
+    with every scan it keeps; nonsense in a scan header is refused."""
+    import os
+    data = open(os.path.join(GOLDEN_JPEG, "rgb420_progressive.jpg"), "rb").read()
+    full = scene_io.read_image(os.path.join(GOLDEN_JPEG, "rgb420_progressive.jpg")).astype(int)
+    scans = [i for i in range(len(data) - 1) if data[i] == 0xFF and data[i + 1] == 0xDA]
+    errors = []
+    for keep in (1, 4, 7, len(scans)):
+        cut = data[:scans[keep]] if keep < len(scans) else data
+        (tmp_path / "cut.jpg").write_bytes(cut)
+        got = scene_io.read_image(str(tmp_path / "cut.jpg")).astype(int)
+        assert got.shape == full.shape
+        errors.append(np.abs(got - full).mean())
+    assert errors[0] > errors[1] > errors[2] > errors[3] == 0.0
+    sos = scans[1]   # second scan: luma AC band; make it claim two components (AC scans hold one)
+    broken = bytearray(data)
+    broken[sos + 4] = 2
+    (tmp_path / "broken.jpg").write_bytes(bytes(broken))
+    with pytest.raises(HiprzError):
+        scene_io.read_image(str(tmp_path / "broken.jpg"))
+    (tmp_path / "noscan.jpg").write_bytes(data[:scans[0]] + b"\xFF\xD9")
+    with pytest.raises(HiprzError, match="scan"):
+        scene_io.read_image(str(tmp_path / "noscan.jpg"))

@@ -11,4 +11,4 @@ B="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_THREAD
 rocprofv3 --pmc $A --kernel-trace --output-format csv -d $OUT/a -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 1 --min-seconds 0 --repeats 1 "$@" > $OUT/a.log 2>&1
 rocprofv3 --pmc $B --kernel-trace --output-format csv -d $OUT/b -o pmc -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 1 --min-seconds 0 --repeats 1 "$@" > $OUT/b.log 2>&1
 python3 $R/tools/pmc_summary.py $OUT/a/pmc_counter_collection.csv $OUT/b/pmc_counter_collection.csv | tee $OUT/summary.txt
-python3 $R/tools/sq_json.py $OUT/summary.txt $OUT/sq.json
+python3 $R/tools/sq_json.py $OUT/summary.txt $OUT/sq.json "${ROUND:-r04}: rocprofv3 --pmc passes of bench.py $* --streams 1 on an MI355X box of the builder's pool"

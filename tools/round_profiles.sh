@@ -1,11 +1,11 @@
 #!/bin/bash
 # On the GPU box: the round's profile set — for every config the SQ counter passes (-> profiles/sq_<config>.json), the rocprofv3 kernel stats
 # of the bench command, the HBM traffic from the FETCH_SIZE / WRITE_SIZE passes (-> profiles/traffic_<config>.json), and then the bench line
-# itself, which quotes both.  Summaries land in gpurun_out/$ROUND/ (ROUND=r03 by default).
-# usage: [ROUND=r03] tools/round_profiles.sh [configs...]
+# itself, which quotes both.  Summaries land in gpurun_out/$ROUND/ (ROUND=r04 by default).
+# usage: [ROUND=r04] tools/round_profiles.sh [configs...]
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/${ROUND:-r03}; mkdir -p $OUT
+OUT=$R/gpurun_out/${ROUND:-r04}; mkdir -p $OUT
 for c in ${@:-B C D E}; do
   echo "== config $c"
   bash $R/tools/pmc_sq.sh $c --config $c > $OUT/sq_$c.log 2>&1 || { tail -5 $OUT/sq_$c.log; exit 1; }
