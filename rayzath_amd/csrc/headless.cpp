@@ -94,7 +94,7 @@ std::vector<RenderTask> prepareTasks(const std::string& task_file) {
     }
 }
 
-std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& report_dir, bool save_images, const std::vector<int>& devices, bool quiet) {
+std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& report_dir, bool save_images, const std::vector<int>& devices, bool quiet, bool sample_sharding) {
     World world;
     {
         if (!quiet) std::printf("Loading \"%s\"\n", file_name(task.scene_path).c_str());
@@ -113,6 +113,10 @@ std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& r
         // picks its stream count by the world like every other host (Hip::Engine::defaultStreams)
         std::unique_ptr<Engine> engine_owner = devices.size() == 1 ? std::make_unique<Engine>(devices[0]) : std::make_unique<Engine>(devices);
         Engine& engine = *engine_owner;
+        // the runner converges a frame and reports rays per second: several GPUs each render whole frames on their own seed streams
+        // (their accumulators summed at the readback) — a device's step stays a whole-frame step whatever their number
+        if (devices.size() > 1 && sample_sharding) engine.shardMode(Engine::ShardMode::Samples);
+        const size_t rays_per_pass_scale = devices.size() > 1 && sample_sharding ? devices.size() : 1u;
         RenderConfig config;
         config.tracing.max_depth = uint8_t(task.max_depth);
         config.tracing.rpp = 1;
@@ -148,7 +152,7 @@ std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& r
             last_stop = stop;
             traced += this_call;
             // the pipelined call enqueued `this_call` passes of W*H rays each (cpu_engine_renderer.cpp:173)
-            const size_t diff = size_t(this_call) * world.camera.width * world.camera.height;
+            const size_t diff = size_t(this_call) * world.camera.width * world.camera.height * rays_per_pass_scale;
             result.total_traced_rays += diff;
             if (!quiet)
                 std::printf("\rRendering... %u/%u +%u [rpp] (%.2f%%) | %s rps | %.3fs (timeout: %.3fs)   ", traced, task.rpp, config.tracing.rpp,
@@ -159,7 +163,7 @@ std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& r
         // buffers, and the clock stops when it is there
         config.tracing.rpp = 1;
         engine.renderWorld(world, config, true, true);
-        result.total_traced_rays += size_t(world.camera.width) * world.camera.height;
+        result.total_traced_rays += size_t(world.camera.width) * world.camera.height * rays_per_pass_scale;
         result.duration = seconds_since(start);
         if (!quiet) std::printf("\nRendered in: %ss\n\n", fixed3(result.duration).c_str());
         if (save_images) {
@@ -186,7 +190,7 @@ std::string reportText(const std::vector<TaskResult>& results) {
     return out;
 }
 
-int run(const std::string& task_file, std::string report_dir, bool save_images, const std::vector<int>& devices, bool quiet) {
+int run(const std::string& task_file, std::string report_dir, bool save_images, const std::vector<int>& devices, bool quiet, bool sample_sharding) {
     try {
         if (report_dir.empty()) report_dir = parent_dir(task_file);
         if (!report_dir.empty() && report_dir.back() != '/') report_dir.push_back('/');
@@ -199,7 +203,7 @@ int run(const std::string& task_file, std::string report_dir, bool save_images, 
         const auto tasks = prepareTasks(task_file);
         std::vector<TaskResult> results;
         for (const auto& task : tasks) {
-            auto r = executeTask(task, report_dir, save_images, devices, quiet);
+            auto r = executeTask(task, report_dir, save_images, devices, quiet, sample_sharding);
             results.insert(results.end(), r.begin(), r.end());
         }
         const std::string path = report_dir + "report.txt";

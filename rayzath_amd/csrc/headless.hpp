@@ -32,10 +32,12 @@ struct TaskResult {  // headless.hpp:18-33
 // relative scene paths are relative to the task file.  "max depth" is an extension (the reference renders at 16).
 std::vector<RenderTask> prepareTasks(const std::string& task_file);
 // Headless::executeTask (headless.cpp:163-276) for the engines this host side has ("HIPGPU"; others are reported and skipped)
-std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& report_dir, bool save_images, const std::vector<int>& devices, bool quiet);
+std::vector<TaskResult> executeTask(const RenderTask& task, const std::string& report_dir, bool save_images, const std::vector<int>& devices, bool quiet, bool sample_sharding = true);
 // Headless::generateReport (headless.cpp:297-330): the same three lines per result
 std::string reportText(const std::vector<TaskResult>& results);
 // Headless::run (headless.cpp:17-55)
-int run(const std::string& task_file, std::string report_dir, bool save_images, const std::vector<int>& devices, bool quiet);  // devices: one context over all of them
+// devices: one context over all of them; sample_sharding (several devices): Engine::ShardMode::Samples — whole frames per device on its own
+// seed stream, summed — instead of interleaved tiles (`--shard-mode tiles`)
+int run(const std::string& task_file, std::string report_dir, bool save_images, const std::vector<int>& devices, bool quiet, bool sample_sharding = true);
 
 }  // namespace RayZath::Hip::Headless

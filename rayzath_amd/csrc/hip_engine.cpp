@@ -352,6 +352,11 @@ void Engine::mode(uint32_t compat_flags) {
     check(hiprz_set_mode(m_ctx, compat_flags));  // reprojection works over several streams / devices: the context assembles the whole previous frame
     m_mode = compat_flags;
 }
+void Engine::shardMode(ShardMode mode) {
+    std::lock_guard<std::mutex> lock(m_mutex);
+    m_streams_pending = false;  // the context stays as it is: the mode is about ITS parts
+    check(hiprz_set_shard_mode(m_ctx, uint32_t(mode)));
+}
 void Engine::tree(uint32_t tree) {
     std::lock_guard<std::mutex> lock(m_mutex);
     check(hiprz_set_tree(m_ctx, tree));

@@ -222,6 +222,14 @@ public:
     static int defaultStreams(const World& world) { return world.spot_lights.empty() && world.direct_lights.empty() ? 2 : 1; }
     void mode(uint32_t compat_flags);  // hiprz_set_mode: behaviours of the CUDA engine (default 0 = the CPU kernel)
     void tree(uint32_t tree);          // hiprz_set_tree, applied at the next scene upload
+    // How the devices of Engine(devices) divide a frame (hiprz_set_shard_mode; no counterpart in the reference, which drives one device:
+    // cuda_engine_core.cu:17).  Tiles (default): interleaved 32x8 tiles — the one-device frame bit for bit, a frame of `rpp` passes arrives
+    // sooner: what an interactive host wants.  Samples: every device renders the whole frame on its own seed stream and the accumulators are
+    // summed — a renderWorld call adds devices * rpp samples per pixel and rayCount() grows by as many rays; aggregate rays per second scale
+    // with the devices where tile sharding is held back by its slowest tile: what a converging (headless / offline) host
+    // wants — hiprz_headless --devices picks it.  Restarts accumulation.
+    enum class ShardMode : uint32_t { Tiles = HIPRZ_SHARD_TILES, Samples = HIPRZ_SHARD_SAMPLES };
+    void shardMode(ShardMode mode);
     ~Engine();
     Engine(const Engine&) = delete;
     Engine& operator=(const Engine&) = delete;

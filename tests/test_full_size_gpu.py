@@ -74,7 +74,8 @@ def test_full_size_frame_against_the_oracle(built, name, packaging, rgb_close, a
                (device-built surface-area trees for C, D, E) on engine.default_streams() streams (two for scenes without lights)
     What differs between the two sides is glibc-vs-ocml libm (sinf / cosf / powf / acosf of the sampling routines, expf / cosf of the lights):
     an ulp there moves a path across an edge — a discrete event per segment, so the share of touched pixels grows with the passes.  Measured
-    on MI355X at 12 passes (4 passes in brackets): the Cornell box ONE pixel of 2 073 600 (none), path state included; C 0.999998 within
+    on MI355X at 12 passes (4 passes in brackets): the Cornell box ONE pixel of 2 073 600 (none) — (1105, 470): a path that picks up the lamp's
+    45.098 in the oracle and nothing on the GPU; C 0.999998 within
     1e-3 (1.0); D 0.99998, finished paths 0.99985 equal (0.99999); E 0.9938 within 1e-3, finished paths 0.9996 equal (0.9996 / 0.99998) —
     its lights put expf and cosf into every segment.  Both packagings give the same figures (their frames are equal bit for bit).
     Thresholds = measured minus a margin."""
@@ -116,10 +117,15 @@ def test_full_size_frame_against_the_oracle(built, name, packaging, rgb_close, a
     assert racc[..., 3].max() >= 2.0      # paths ended and started again within the frame
     if name == "B":
         assert (acc != racc).any(-1).sum() <= 2
+        # where every path stands after the depth limit and the regenerated rays: the discrete part (material, depth) equal but for the
+        # pixels above; origins, directions and colours are products of sinf / cosf / powf and agree to the tolerance, not to the bit
+        # (a hit point an ulp away changes no radiance in a scene without lights: what a segment adds is material constants)
         state = ctx.read_state()
-        for key, want in ref["state"].items():   # where every path stands after the depth limit and the regenerated rays
-            differs = state[key] != want
-            assert (differs.reshape(differs.shape[0], differs.shape[1], -1).any(-1)).sum() <= 2, key
+        for key in ("material", "depth"):
+            assert (state[key] != ref["state"][key]).sum() <= 2, key
+        for key in ("origin", "direction", "color"):
+            near = (np.abs(state[key] - ref["state"][key]) <= 1e-3 * np.maximum(np.abs(ref["state"][key]), 1.0)).all(-1)
+            assert (~near).sum() <= 2, key
     elif name == "C":
         assert exact >= 0.9998
     assert ctx.ray_count() == PASSES * cam.width * cam.height == ref["rays"]
