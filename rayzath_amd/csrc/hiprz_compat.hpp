@@ -82,6 +82,25 @@ RZ_DEV col4 compat_opacity_color(const DScene& s, const Material& m, float u, fl
     return c * t;
 }
 
+// The factor a crossed triangle contributes to a shadow mask: opacityColor of its material at the crossing's texture coordinates
+// (cuda_instance.cuh:105-112) — the tester's half of the cooperative mask walk (hiprz_device.hpp: any_hit_coop_mask).
+template <bool COUNT>
+RZ_DEV col4 compat_crossing_color(const DScene& s, uint32_t inst, uint32_t tri, uint32_t tri_flags, float b1, float b2, bool filtering, Counters& cnt) {
+    const uint32_t material_base = __float_as_uint(s.instances[7 * inst + 1].w), material_count = __float_as_uint(s.instances[7 * inst + 2].w);
+    float u = 0.0f, v = 0.0f;
+    if (tri_flags & HIPRZ_TRI_HAS_TEXCRDS) {  // Triangle::texcrdFromBarycenter, mesh_component.cpp:115-123
+        const float4 uv12 = s.tri_attrs[6 * size_t(tri) + 4], uv3 = s.tri_attrs[6 * size_t(tri) + 5];
+        const float b3 = 1.0f - b1 - b2;
+        u = uv12.x * b3 + uv12.z * b1 + uv3.x * b2;
+        v = uv12.y * b3 + uv12.w * b1 + uv3.y * b2;
+    }
+    uint32_t slot = tri_flags & HIPRZ_TRI_MATERIAL_MASK;
+    if (slot > 63u) slot = 63u;
+    const int32_t mat = slot < material_count ? s.inst_materials[material_base + slot] : -1;
+    const Material material = load_material(s, mat < 0 ? HIPRZ_MATERIAL_DEFAULT : uint32_t(mat));
+    return compat_opacity_color<COUNT>(s, material, u, v, true, filtering, cnt);
+}
+
 // Shadow mask of the CUDA engine (cuda_bvh.cuh:172-232, cuda_instance.cuh:92-164, 215-229): starts white, every triangle the
 // shadow ray crosses multiplies it by that triangle's opacityColor(uv); the walk ends early once the mask's alpha drops below 1e-4.
 template <bool COUNT>
@@ -115,7 +134,6 @@ RZ_DEV col4 compat_shadow_mask(const DScene& s, const Ray& ray, bool filtering, 
                 RZ_COUNT(shadow_box_tests);
                 if (!box_hit<false>(ib0, ib1, g)) continue;
                 const InstanceXform x = load_instance_xform(s, inst);
-                const uint32_t material_base = __float_as_uint(s.instances[7 * inst + 1].w), material_count = __float_as_uint(s.instances[7 * inst + 2].w);
                 WalkRay lr;
                 to_local<false>(x, g, lr, false);
                 uint32_t m = x.blas_root;
@@ -137,19 +155,7 @@ RZ_DEV col4 compat_shadow_mask(const DScene& s, const Ray& ray, bool filtering, 
                             RZ_COUNT(tri_tests);
                             RZ_COUNT(shadow_tri_tests);
                             if (!tri_hit(xyz(ta), xyz(tb), xyz(tc), lr, t, b1, b2, det)) continue;
-                            const uint32_t flags = __float_as_uint(ta.w);
-                            float u = 0.0f, v = 0.0f;
-                            if (flags & HIPRZ_TRI_HAS_TEXCRDS) {  // Triangle::texcrdFromBarycenter, mesh_component.cpp:115-123
-                                const float4 uv12 = s.tri_attrs[6 * size_t(tj) + 4], uv3 = s.tri_attrs[6 * size_t(tj) + 5];
-                                const float b3 = 1.0f - b1 - b2;
-                                u = uv12.x * b3 + uv12.z * b1 + uv3.x * b2;
-                                v = uv12.y * b3 + uv12.w * b1 + uv3.y * b2;
-                            }
-                            uint32_t slot = flags & HIPRZ_TRI_MATERIAL_MASK;
-                            if (slot > 63u) slot = 63u;
-                            const int32_t mat = slot < material_count ? s.inst_materials[material_base + slot] : -1;
-                            const Material material = load_material(s, mat < 0 ? HIPRZ_MATERIAL_DEFAULT : uint32_t(mat));
-                            mask = mask * compat_opacity_color<COUNT>(s, material, u, v, true, filtering, cnt);
+                            mask = mask * compat_crossing_color<COUNT>(s, inst, tj, __float_as_uint(ta.w), b1, b2, filtering, cnt);
                             if (mask.a < 1.0e-4f) return mask;
                         }
                     }

@@ -1420,8 +1420,21 @@ RZ_DEV float any_hit_skip(const DScene& s, const TopCache& top, const Ray& ray, 
 // ray), the triangles of the lanes that hold a leaf are dealt out over the wave in groups of 8, and a holder is occluded as soon as
 // ANY of its items hits (a ballot per group instead of the minimum).  A shadow ray's range is fixed, so the answer does not depend
 // on the order of the tests.
-template <bool COUNT, bool RCP>
-RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, const Ray& ray, Counters& cnt) {
+// MASK (HIPRZ_COMPAT_SHADOW_COLOR, cuda_instance.cuh:92-164): the ray goes THROUGH the triangles it crosses and the result is the product
+// of their opacity colours (white where nothing is crossed); a tester that hits fetches its triangle's colour (hiprz_compat.hpp:
+// compat_crossing_color), the four testers of an entry multiply theirs over the quad (two DPP exchanges, a fixed order), the holder
+// multiplies its mask by its entries' products and stops once the mask's alpha is below 1e-4, as the CUDA engine's walk does.  The order of
+// the factors is this walk's (front to back, entries in leaf order), not the inline walk's: products agree to rounding, not to the bit.
+template <bool COUNT>
+RZ_DEV col4 compat_crossing_color(const DScene& s, uint32_t inst, uint32_t tri, uint32_t tri_flags, float b1, float b2, bool filtering, Counters& cnt);  // hiprz_compat.hpp
+RZ_DEV float quad_product(float v) {
+    float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xF, 0xF, false));  // quad_perm:[1,0,3,2]
+    v = v * o;
+    o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xF, 0xF, false));        // quad_perm:[2,3,0,1]
+    return v * o;
+}
+template <bool COUNT, bool RCP, bool MASK = false>
+RZ_DEV col4 any_hit_coop_mask(const DScene& s, const CoopLds& lds, bool active, const Ray& ray, bool filtering, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
     const uint32_t lane = lane_id();
     WalkRay g;
@@ -1430,6 +1443,7 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
     const uint32_t kmax = s.walk_k ? s.walk_k : 0xFFFFFFFFu, lmax = s.walk_l ? (s.walk_l < 8u ? s.walk_l : 8u) : 8u, hmin = s.walk_h;
     uint32_t n = active ? s.tlas_root : RZ_END, guard = 0u;
     bool occluded = false;
+    col4 shadow = splat(1.0f);  // (MASK)
     while (__any(n != RZ_END)) {
         RZ_GUARD(guard);
         uint32_t i = 0u, end = 0u, after = RZ_END;  // (the world level as in closest_hit_coop)
@@ -1507,18 +1521,19 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
                 if (holding) {
                     const f4 r0 = F4(lr.o.x, lr.o.y, lr.o.z, lr.near_), r1 = F4(lr.d.x, lr.d.y, lr.d.z, lr.far_);
                     lds.rec[deal.pos] = r0, lds.rec[CoopLds::kEntries + deal.pos] = r1;
-                    lds.rec[2u * CoopLds::kEntries + deal.pos] = F4(__uint_as_float(tj), __uint_as_float(c < 4u ? c : 4u), 0.0f, 0.0f);
-                    lds.res[deal.pos] = F4(0.0f, 0.0f, 0.0f, 0.0f);  // .x != 0: one of the entry's triangles was hit
+                    lds.rec[2u * CoopLds::kEntries + deal.pos] = F4(__uint_as_float(tj), __uint_as_float(c < 4u ? c : 4u), __uint_as_float(inst), 0.0f);
+                    lds.res[deal.pos] = MASK ? F4(1.0f, 1.0f, 1.0f, 1.0f) : F4(0.0f, 0.0f, 0.0f, 0.0f);  // .x != 0: one of the entry's triangles was hit (MASK: the entry's product)
                     if (deal.big) {
                         lds.rec[deal.pos + 1u] = r0, lds.rec[CoopLds::kEntries + deal.pos + 1u] = r1;
-                        lds.rec[2u * CoopLds::kEntries + deal.pos + 1u] = F4(__uint_as_float(tj + 4u), __uint_as_float(c - 4u), 0.0f, 0.0f);
-                        lds.res[deal.pos + 1u] = F4(0.0f, 0.0f, 0.0f, 0.0f);
+                        lds.rec[2u * CoopLds::kEntries + deal.pos + 1u] = F4(__uint_as_float(tj + 4u), __uint_as_float(c - 4u), __uint_as_float(inst), 0.0f);
+                        lds.res[deal.pos + 1u] = MASK ? F4(1.0f, 1.0f, 1.0f, 1.0f) : F4(0.0f, 0.0f, 0.0f, 0.0f);
                     }
                 }
                 rz_wave_sync();
                 for (uint32_t base = 0u; base < deal.n_entries * 4u; base += 64u) {
                     const uint32_t e = (base + lane) >> 2, j = lane & 3u;
                     bool item_hit = false;
+                    col4 crossing = splat(1.0f);  // (MASK) this tester's factor
                     if (e < deal.n_entries) {
                         const f4 r2 = lds.rec[2u * CoopLds::kEntries + e];
                         if (j < __float_as_uint(r2.y)) {
@@ -1531,14 +1546,34 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
                             RZ_COUNT(tri_tests);
                             RZ_COUNT(shadow_tri_tests);
                             item_hit = tri_hit(xyz(a), xyz(b), xyz(cc), hr, t, b1, b2, det);
+                            if constexpr (MASK) {
+                                if (item_hit) crossing = compat_crossing_color<COUNT>(s, __float_as_uint(r2.z), tri, __float_as_uint(a.w), b1, b2, filtering, cnt);
+                            }
                         }
                     }
-                    if (item_hit) lds.res[e] = F4(1.0f, 0.0f, 0.0f, 0.0f);  // every writer of a slot writes the same value
+                    if constexpr (MASK) {  // the entry's product, in every lane of its quad; lane 0 of the quad hands it over
+                        crossing = col4{quad_product(crossing.r), quad_product(crossing.g), quad_product(crossing.b), quad_product(crossing.a)};
+                        if (e < deal.n_entries && j == 0u) lds.res[e] = F4(crossing.r, crossing.g, crossing.b, crossing.a);
+                    } else {
+                        if (item_hit) lds.res[e] = F4(1.0f, 0.0f, 0.0f, 0.0f);  // every writer of a slot writes the same value
+                    }
                 }
                 rz_wave_sync();
                 if (holding) {
                     tj += c;
-                    if (lds.res[deal.pos].x != 0.0f || (deal.big && lds.res[deal.pos + 1u].x != 0.0f)) {  // occluded: this lane's walk is over (:465 "TODO: texture fetch" -> mask 0)
+                    bool done;
+                    if constexpr (MASK) {
+                        const f4 p0 = lds.res[deal.pos];
+                        shadow = shadow * col4{p0.x, p0.y, p0.z, p0.w};
+                        if (deal.big) {
+                            const f4 p1 = lds.res[deal.pos + 1u];
+                            shadow = shadow * col4{p1.x, p1.y, p1.z, p1.w};
+                        }
+                        done = shadow.a < 1.0e-4f;  // nothing gets through any more (cuda_instance.cuh: the walk returns)
+                    } else {
+                        done = lds.res[deal.pos].x != 0.0f || (deal.big && lds.res[deal.pos + 1u].x != 0.0f);  // occluded (:465 "TODO: texture fetch" -> mask 0)
+                    }
+                    if (done) {  // this lane's walk is over
                         occluded = true;
                         tj = tj_end = 0u, m = RZ_END, i = end = 0u, n = RZ_END, held = false;
                     }
@@ -1548,7 +1583,12 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
         }
         if (held) n = after;
     }
-    return occluded ? 0.0f : 1.0f;
+    if constexpr (MASK) return shadow;
+    return splat(occluded ? 0.0f : 1.0f);
+}
+template <bool COUNT, bool RCP>
+RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, const Ray& ray, Counters& cnt) {
+    return any_hit_coop_mask<COUNT, RCP, false>(s, lds, active, ray, false, cnt).a;
 }
 
 template <int MODE, bool COUNT, bool RCP>

@@ -631,7 +631,9 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_kernel(const DScene s, con
 
 // rz_shadow_kernel with the cooperative any-hit walk (hiprz_device.hpp: any_hit_coop): the sample loop is wave-uniform, a lane
 // whose pixel has no shadow ray in slot k walks along as a helper.  Sums, order and accumulation are those of rz_shadow_kernel.
-template <bool FIRST, bool COUNT, int MINW>
+// MASK: the coloured shadow masks of the CUDA engine (HIPRZ_COMPAT_SHADOW_COLOR) — V_PL is the product of the crossed triangles' opacity
+// colours instead of 0 / 1; everything else as above.
+template <bool FIRST, bool COUNT, int MINW, bool MASK = false>
 __global__ void __launch_bounds__(64, MINW) rz_shadow_coop_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
     const CoopLds lds(rz_lds);
@@ -658,10 +660,9 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_coop_kernel(const DScene s
         Ray sr;
         sr.o = V3(o.x, o.y, o.z), sr.d = V3(d.x, d.y, d.z), sr.near_ = 0.0f, sr.far_ = d.w;
         if (has) { RZ_COUNT(shadow_rays); }
-        float v = 0.0f;
-        if (s.n_instances != 0u) v = any_hit_coop<COUNT, RZ_SHADE_SHARED_RCP != 0>(s, lds, has, sr, cnt);
+        col4 V_PL = splat(MASK ? 1.0f : 0.0f);
+        if (s.n_instances != 0u) V_PL = any_hit_coop_mask<COUNT, RZ_SHADE_SHARED_RCP != 0, MASK>(s, lds, has, sr, MASK && (cfg.flags & HIPRZ_COMPAT_FILTERING) != 0u, cnt);
         if (has) {
-            const col4 V_PL = splat(v);
             const col4 term = (col4{t.x, t.y, t.z, t.w} * V_PL) * V_PL.a;
             if (k < cfg.direct_samples) direct_total = direct_total + term;
             else spot_total = spot_total + term;

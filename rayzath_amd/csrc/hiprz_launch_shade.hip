@@ -15,13 +15,15 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
     const bool lights = c->dscene.n_spot_lights + c->dscene.n_direct_lights != 0u;
     if (c->mode_flags & kIntegratorFlags) {
         // CUDA-compat integrator: the same packaging as below — shading, then (scenes with lights) the pass's shadow rays in the lean
-        // cooperative kernel in their own sorted order.  Only the coloured shadow mask (HIPRZ_COMPAT_SHADOW_COLOR: a texture fetch per
-        // crossed triangle, no early out at the first hit) walks inside the shade kernel.
-        if (lights && defer_shadows(c) && !(c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR)) {
+        // cooperative kernel in their own sorted order; with HIPRZ_COMPAT_SHADOW_COLOR its mask-collecting instantiation (round 4).
+        if (lights && defer_shadows(c)) {
             RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_COMPAT_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
             launch_sort(c, f.shadow_key != nullptr);
             if (f.shadow_key) launch_shadow_sort(c);
-            RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
+            if (c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR)  // coloured masks: the same kernel, its rays go through what they cross and collect the opacity colours
+                RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 3, true>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
+            else
+                RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
             join_sort(c);
         } else {
             RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_COMPAT>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
