@@ -747,6 +747,19 @@ __global__ void __launch_bounds__(64) rz_sah_small_kernel(SahViews v, uint32_t c
     uint32_t stack[2 * kSahSmall];
     uint32_t sp = 0u;
     stack[sp++] = v.small_roots[r];
+    {   // The top phase places triangles with per-wave atomic cursors: WHICH triangles a small root holds is decided by planes (deterministic),
+        // the ORDER inside its run by wave scheduling.  The bottom phase reads that order twice (the two-pointer partition fixes the leaf
+        // order; coincident centroids are cut "as the run stands"), so the run is put into triangle order first: the subtree is then a function
+        // of its triangle set, the same from run to run and on every device of a context.  (What stays order-dependent: a LARGE node whose
+        // centroids no plane separates is cut in half as its run stands — rz_sah_split_kernel; meshes with > 32 coincident centroids only.)
+        const uint32_t first = v.n_first[stack[0]], count = v.n_count[stack[0]];
+        for (uint32_t i = 1u; i < count; ++i) {
+            const uint32_t t = idx[first + i];
+            uint32_t j = i;
+            for (; j > 0u && idx[first + j - 1u] > t; --j) idx[first + j] = idx[first + j - 1u];
+            idx[first + j] = t;
+        }
+    }
     while (sp) {
         const uint32_t node = stack[--sp], first = v.n_first[node], count = v.n_count[node];
         float cbox[6];

@@ -533,3 +533,25 @@ def test_a_refused_in_place_change_leaves_no_scene_behind(built, monkeypatch, de
     ctx.render(1), ctx.render(4)
     assert np.array_equal(ctx.read_accum(), before)
     ctx.close()
+
+
+@pytest.mark.parametrize("name", ["textured", "living room"])
+def test_device_sah_trees_are_the_same_from_run_to_run(built, name):
+    """The binned surface-area build places triangles with per-wave atomic cursors, so the order inside a node's run depends on wave
+    scheduling; the bottom phase puts every small root's run into triangle order before it reads it (rz_sah_small_kernel), which makes the
+    emitted trees — topology, boxes, leaf order — a function of the mesh: two builds (and the devices of one context) hold the same tables,
+    and executed-work counters under device SAH trees are reproducible."""
+    build, samples = _worlds(name)
+    world = build()
+    flat, cam = flatten(world), camera_struct(world.camera)
+    cfg = RenderConfig(LightSampling(*samples), Tracing(6, 4)).struct()
+    tables, counters = [], []
+    for _ in range(3):
+        c = _render(flat, cam, cfg, DEVICE_SAH, passes=(1,))
+        nodes, root, order, roots, refpos = c.download_trees(len(flat.instances), len(flat.tris), len(flat.tlas_order))
+        tables.append((nodes.tobytes(), root, order.tobytes(), roots.tobytes(), refpos.tobytes()))
+        c.set_walk_order(2)
+        counters.append(c.render_counted(2))
+        c.close()
+    assert tables[0] == tables[1] == tables[2]
+    assert counters[0] == counters[1] == counters[2]
