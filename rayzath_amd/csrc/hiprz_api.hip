@@ -24,6 +24,12 @@ using namespace hiprz;
 // Small kernels: pass index, tone map, tile <-> image, picking, self-test
 // =======================================================================================
 
+// resident kernels, heaviest first: sort keys from the units' measured costs (falling cost = rising key)
+__global__ void __launch_bounds__(256) rz_order_keys_kernel(const uint32_t* cost, uint32_t* keys, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) keys[i] = 0x00FFFFFFu - (cost[i] < 0x00FFFFFFu ? cost[i] : 0x00FFFFFFu);
+}
+
 // passUpdate / segmentUpdate (cuda_postprocess_kernel.cu:95-104, cuda_render_kernel.cu:122-129):
 // the pass index lives on the device so a captured graph replays without new arguments.
 __global__ void rz_pass_update_kernel(uint32_t* pass) { *pass += 1u; }
@@ -308,6 +314,8 @@ void release_frame(hiprz_frame_state* c) {
     c->st0.release(), c->st1.release(), c->st2.release(), c->accum.release(), c->depth.release(), c->rgba8.release();
     c->hit0.release(), c->hit1.release();
     c->nee.release(), c->prev_accum.release(), c->prev_depth.release();
+    c->unit_cost.release(), c->launch_order.release(), c->order_keys.release();
+    c->order_sort.keys_out.release(), c->order_sort.vals_a.release(), c->order_sort.vals_b.release(), c->order_sort.counts.release(), c->order_sort.digit_total.release();
     c->sort_keys.release(), c->sort_perm.release();
     for (auto& t : c->sort_temp) t.keys_out.release(), t.vals_a.release(), t.vals_b.release(), t.counts.release(), t.digit_total.release();
     c->shadow_keys.release(), c->shadow_perm.release();
@@ -469,6 +477,18 @@ int allocate_frame(hiprz_ctx* c) {
     RZ_HIP(c, c->depth.resize(n));
     RZ_HIP(c, c->rgba8.resize(n));
     RZ_HIP(c, c->image_f4.resize(size_t(W) * H));
+    {   // heaviest-first launch order of the resident kernels: at most one unit per wave of the shard
+        const size_t units = size_t(c->n_local_tiles) * 4u;
+        RZ_HIP(c, c->unit_cost.resize(units));
+        RZ_HIP(c, c->launch_order.resize(units));
+        RZ_HIP(c, c->order_keys.resize(units));
+        if (units) {
+            RZ_HIP(c, hipMemsetAsync(c->unit_cost.ptr, 0, units * sizeof(uint32_t), c->stream));
+            const int orc = sort_temp_resize(c, c->order_sort, units);
+            if (orc != HIPRZ_OK) return orc;
+        }
+        c->order_units = 0u, c->batches_since_order = 0u;
+    }
     if (n) {
         RZ_HIP(c, hipMemsetAsync(c->accum.ptr, 0, n * sizeof(float4), c->stream));
         RZ_HIP(c, hipMemsetAsync(c->depth.ptr, 0, n * sizeof(float), c->stream));
@@ -513,6 +533,10 @@ DFrame make_frame(hiprz_ctx* c, bool counted) {
     const bool shadow_sorting = sorting && c->shadow_sort != 0 && c->pipeline == 1 && defer_shadows(c);
     f.shadow_key = shadow_sorting ? c->shadow_keys.ptr : nullptr;
     f.shadow_perm = shadow_sorting ? c->shadow_perm.ptr : nullptr;
+    // resident kernels: units by falling cost once an order for THIS kind of unit exists; costs are always collected (not while counting)
+    const uint32_t units = c->pipeline == 2 ? (wave_resident(c) ? c->n_local_tiles * 4u : c->n_local_tiles) : 0u;
+    f.unit_cost = c->heavy_first && units && !counted ? c->unit_cost.ptr : nullptr;
+    f.launch_order = c->heavy_first && units && !counted && c->order_units == units ? c->launch_order.ptr : nullptr;
     return f;
 }
 
@@ -616,6 +640,18 @@ void launch_resident(hiprz_ctx* c, const DFrame& f, uint32_t n, bool counted, hi
     launch_batch(c, f, n, counted, before, after);
     RZ_LAUNCH(rz_pass_add_kernel, dim3(1), dim3(1), 0, c->stream, c->pass_dev.ptr, n);
     c->rgba8_valid = true;
+    // Heaviest first: the batch that just ran left every unit's cost behind.  The order is derived after the first batch that measured
+    // (and whenever the kind of unit changed) and refreshed every 64th batch — per-tile costs of a fixed view are stable, paths
+    // regenerate at the same pixels — by one key kernel + a 24-bit radix sort of a few thousand keys on the render stream.
+    if (f.unit_cost && n >= 2u) {
+        const uint32_t units = wave_resident(c) ? c->n_local_tiles * 4u : c->n_local_tiles;
+        c->batches_since_order += 1u;
+        if (c->order_units != units || c->batches_since_order >= 64u) {
+            RZ_LAUNCH(rz_order_keys_kernel, dim3((units + 255u) / 256u), dim3(256), 0, c->stream, c->unit_cost.ptr, c->order_keys.ptr, units);
+            sort_u32(c->stream, c->order_keys.ptr, units, 24, c->launch_order.ptr, nullptr, c->order_sort);
+            c->order_units = units, c->batches_since_order = 0u;
+        }
+    }
 }
 
 hipEvent_t take_event(hiprz_ctx* c) {
@@ -1158,6 +1194,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     auto* c = new hiprz_ctx();
     if (const char* w = std::getenv("HIPRZ_TRACE_WAVES")) c->trace_waves = std::atoi(w);
     if (const char* w = std::getenv("HIPRZ_DEFER_SHADOWS")) c->defer_shadow_rays = std::atoi(w) != 0;
+    if (const char* w = std::getenv("HIPRZ_HEAVY_FIRST")) c->heavy_first = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_BATCH_WAVES")) c->batch_waves = std::atoi(w);
     if (const char* w = std::getenv("HIPRZ_NOLIGHT_KERNELS")) c->nolight_kernels = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SORT_BITS")) c->sort_bits = std::min(24, std::max(0, std::atoi(w)));

@@ -139,6 +139,12 @@ struct hiprz_frame_state {
     hiprz::DeviceArray<uint32_t> shadow_keys, shadow_perm;  // deferred shadow rays follow their own order (hiprz_device.hpp: DFrame::shadow_key)
     bool sorted_this_pass = false;  // the deferred shadow kernel wants the NEXT pass's ray order: the sort then runs before it
     hiprz::DeviceArray<float4> nee;  // DFrame::nee
+    // resident kernels, heaviest first (DFrame::launch_order): what every unit (a tile of rz_batch_kernel, a wave of rz_wave_batch_kernel)
+    // cost in the last batch, the units by falling cost, the workspace of the sort that orders them
+    hiprz::DeviceArray<uint32_t> unit_cost, launch_order, order_keys;
+    SortTemp order_sort;
+    uint32_t order_units = 0;           // how many units launch_order permutes (0: none yet)
+    uint32_t batches_since_order = 0;   // resident batches since the order was last derived
     // HIPRZ_COMPAT_REPROJECTION: the frame a restart replaces (accumulator, first-hit depth, the camera it was rendered from)
     hiprz::DeviceArray<float4> prev_accum;
     hiprz::DeviceArray<float> prev_depth;
@@ -233,6 +239,7 @@ struct hiprz_ctx : hiprz_frame_state {
     int shadow_sort = 1;  // HIPRZ_SHADOW_SORT=0: the shadow kernel follows the next pass's ray order instead
     int sort_rays = -1;  // -1 auto (on for scenes walked with MODE 3), 0 off, 1 on
     bool defer_shadow_rays = true;  // HIPRZ_DEFER_SHADOWS=0: walk them inside the shade kernel
+    int heavy_first = 1;            // HIPRZ_HEAVY_FIRST=0: resident kernels launch their units in unit order (rounds 1 - 3)
     int trace_waves = 0;  // 0 = by tree size; HIPRZ_TRACE_WAVES = 4 | 6 forces the register budget
     uint32_t n_nodes = 0;
     bool time_kernels = false;  // record events around the trace and the shade kernel of every pass of a batch

@@ -160,6 +160,12 @@ struct DFrame {
     uint32_t nee_quads;
     uint32_t* shadow_key;         // deferred shadow rays: sort key of the pixel's shadow rays (origin cell + direction towards the light)
     const uint32_t* shadow_perm;  // rz_shadow_kernel: thread i finishes local pixel shadow_perm[i] (nullptr: follow `perm`)
+    // Resident kernels, heaviest first (round 4): a launch lasts until its slowest unit (a tile's / a wave's chain of passes) is done, and a
+    // unit that starts late ends late.  Every unit writes what its batch cost (clock ticks) into unit_cost; the host sorts the units by
+    // falling cost now and then, and workgroup b of the next launches works on unit launch_order[b] — the long chains start first, the
+    // short ones fill the end.  Execution order only: storage stays indexed by the unit.  nullptr = in unit order.
+    const uint32_t* launch_order;
+    uint32_t* unit_cost;
 };
 
 struct v3 {

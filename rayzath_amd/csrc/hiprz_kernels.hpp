@@ -296,7 +296,9 @@ template <bool COUNT, int MODE, bool LDS_SCENE, int SHADING, int WAVES = RZ_MIN_
 __global__ void __launch_bounds__(256, WAVES) rz_batch_kernel(const DScene scene_in, const DCamera cam, const DConfig cfg, const DFrame f,
                                                                       uint32_t n_passes, uint32_t park_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    const PixelId p = pixel_of_thread(f, cam, blockIdx.x, threadIdx.x);
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    const uint32_t unit = (f.launch_order && !f.xcd_swizzle) ? f.launch_order[blockIdx.x] : blockIdx.x;  // heaviest tiles first (DFrame::launch_order)
+    const PixelId p = pixel_of_thread(f, cam, unit, threadIdx.x);
     if (!p.tile_inside) return;  // (the whole workgroup: the padding of the swizzled grid)
     DScene s = scene_in;
     unsigned char* workspace = rz_lds + stage_scene<LDS_SCENE>(s, rz_lds);
@@ -350,6 +352,10 @@ __global__ void __launch_bounds__(256, WAVES) rz_batch_kernel(const DScene scene
         f.st2[p.local] = make_float2(ps.color.b, __uint_as_float((ps.material & 0xFFFFu) | (ps.depth << 16)));
         f.rgba8[p.local] = tonemap(col4{acc.x, acc.y, acc.z, acc.w}, cam.aperture, cam.exposure_time);
     }
+    if (f.unit_cost && threadIdx.x == 0u) {  // what this unit's batch cost: the next launches start the expensive units first
+        const unsigned long long dt = (__builtin_readcyclecounter() - t_start) >> 4;
+        f.unit_cost[unit] = dt < 0x00FFFFFFull ? uint32_t(dt) : 0x00FFFFFFu;
+    }
     flush_counters<COUNT>(f, p.active ? n_passes : 0u, cnt);
 }
 
@@ -363,7 +369,9 @@ __global__ void __launch_bounds__(256, WAVES) rz_batch_kernel(const DScene scene
 template <bool COUNT, int SHADING, int MINW, bool ONE_LEAF_WORLD = false>
 __global__ void __launch_bounds__(64, MINW) rz_wave_batch_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f, uint32_t n_passes) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];
-    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    const uint32_t unit = f.launch_order ? f.launch_order[blockIdx.x] : blockIdx.x;  // heaviest waves first (DFrame::launch_order)
+    const uint32_t slot = unit * 64u + threadIdx.x;
     const PixelId p = pixel_of_local(f, cam, slot);
     if (!p.tile_inside) return;  // (the whole wave)
     Counters cnt;
@@ -394,6 +402,10 @@ __global__ void __launch_bounds__(64, MINW) rz_wave_batch_kernel(const DScene s,
         f.st1[p.local] = make_float4(ps.ray.d.y, ps.ray.d.z, ps.color.r, ps.color.g);
         f.st2[p.local] = make_float2(ps.color.b, __uint_as_float((ps.material & 0xFFFFu) | (ps.depth << 16)));
         f.rgba8[p.local] = tonemap(col4{acc.x, acc.y, acc.z, acc.w}, cam.aperture, cam.exposure_time);
+    }
+    if (f.unit_cost && threadIdx.x == 0u) {  // what this unit's batch cost: the next launches start the expensive units first
+        const unsigned long long dt = (__builtin_readcyclecounter() - t_start) >> 4;
+        f.unit_cost[unit] = dt < 0x00FFFFFFull ? uint32_t(dt) : 0x00FFFFFFu;
     }
     flush_counters<COUNT>(f, p.active ? n_passes : 0u, cnt);
 }

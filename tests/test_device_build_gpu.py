@@ -535,23 +535,43 @@ def test_a_refused_in_place_change_leaves_no_scene_behind(built, monkeypatch, de
     ctx.close()
 
 
+def _canonical_trees(nodes, roots, refpos):
+    """The mesh trees as a walk sees them, free of slot numbers: per distinct root the depth-first sequence of (box, leaf?, the leaf's
+    triangles by uploaded position in leaf order)."""
+    out = []
+    for root in sorted(set(int(r) for r in roots)):
+        seq, stack = [], [root]
+        while stack:
+            n = nodes[stack.pop()]
+            meta, begin = int(n["meta"]), int(n["begin"])
+            box = (tuple(n["bb_min"].tolist()), tuple(n["bb_max"].tolist()))
+            if meta & 0x80000000:
+                seq.append((box, True, tuple(refpos[begin:begin + (meta & 0x1FFFFFFF)].tolist())))
+            else:
+                seq.append((box, False, (meta >> 29) & 3))
+                stack += [begin + 1, begin]
+        out.append(seq)
+    return sorted(out, key=lambda q: (len(q), q[0][0]))
+
+
 @pytest.mark.parametrize("name", ["textured", "living room"])
 def test_device_sah_trees_are_the_same_from_run_to_run(built, name):
     """The binned surface-area build places triangles with per-wave atomic cursors, so the order inside a node's run depends on wave
     scheduling; the bottom phase puts every small root's run into triangle order before it reads it (rz_sah_small_kernel), which makes the
-    emitted trees — topology, boxes, leaf order — a function of the mesh: two builds (and the devices of one context) hold the same tables,
-    and executed-work counters under device SAH trees are reproducible."""
+    emitted trees — topology, boxes, child order, leaf order — a function of the mesh.  (The SLOT a node gets is still handed out by an
+    atomic counter: two builds number their nodes differently and hold the same trees.)  Two builds walk the same boxes in the same order:
+    the executed-work counters under device SAH trees are reproducible."""
     build, samples = _worlds(name)
     world = build()
     flat, cam = flatten(world), camera_struct(world.camera)
     cfg = RenderConfig(LightSampling(*samples), Tracing(6, 4)).struct()
-    tables, counters = [], []
+    trees, counters = [], []
     for _ in range(3):
         c = _render(flat, cam, cfg, DEVICE_SAH, passes=(1,))
         nodes, root, order, roots, refpos = c.download_trees(len(flat.instances), len(flat.tris), len(flat.tlas_order))
-        tables.append((nodes.tobytes(), root, order.tobytes(), roots.tobytes(), refpos.tobytes()))
+        trees.append(_canonical_trees(nodes, roots[order] if len(order) else roots, refpos))
         c.set_walk_order(2)
         counters.append(c.render_counted(2))
         c.close()
-    assert tables[0] == tables[1] == tables[2]
+    assert trees[0] == trees[1] == trees[2]
     assert counters[0] == counters[1] == counters[2]

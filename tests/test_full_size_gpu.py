@@ -257,3 +257,24 @@ def test_batches_survive_another_hip_user_in_the_process(built, name, pipeline):
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "done graph captures" in r.stdout and "Memory access fault" not in r.stdout + r.stderr, r.stdout[-1500:] + r.stderr[-1500:]
     assert r.stdout.strip().endswith("graph captures 1" if pipeline or name == "E" else "graph captures 0")
+
+
+@pytest.mark.parametrize("name", ["B", "C", "D"])
+def test_heaviest_first_launch_order_is_invisible(built, name, monkeypatch):
+    """The resident kernels start their most expensive units first (DFrame::launch_order: every tile / wave writes what its batch cost, the
+    units are sorted by falling cost after the first batch and every 64th one).  Execution order only: the frames after several batches —
+    the first in unit order, the later ones in cost order — equal those of HIPRZ_HEAVY_FIRST=0 bit for bit, on one stream and on the hosts'
+    two streams."""
+    flat, cam, depth = scene(name)
+    out = []
+    for heavy, devices in (("0", 0), ("1", 0), ("1", [0, 0])):
+        monkeypatch.setenv("HIPRZ_HEAVY_FIRST", heavy)
+        c = Context(devices)
+        c.set_tree(4)
+        c.upload_scene(flat), c.upload_camera(cam), c.set_config(RenderConfig(tracing=Tracing(depth, 4)).struct())
+        c.render(1), c.render(4), c.render(4), c.render(3), c.render(4)
+        assert c.pipeline() == 2   # (resolved with the camera's shard size at the first render)
+        c.tonemap()
+        out.append((digest(c.read_accum()), digest(c.read_rgba8()), digest(c.read_state()["direction"])))
+        c.close()
+    assert out[0] == out[1] == out[2]
