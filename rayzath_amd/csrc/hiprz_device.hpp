@@ -719,6 +719,8 @@ RZ_DEV float any_hit_stack(const DScene& s, uint32_t* lds_column, const Ray& ray
 // have equal trip counts.  Every ray still sees its instances one after another with an updated
 // range, so results equal the sequential walk bit for bit.
 #define RZ_BIN_NONE 0xFFFFFFFFu
+#define RZ_BIN_WIDE 0x80000000u  // item flag: one of the 8 lanes that share a visit of a single-leaf mesh with more than 4 triangles
+RZ_DEV uint32_t octet_min(uint32_t v);  // (defined with the cooperative walk's helpers below)
 struct BinnedLds {  // per-workgroup workspace carved from dynamic LDS (256 lanes)
     float* ray;         // [8][256]  o.xyz d.xyz near far
     uint32_t* hit;      // [5][256]  triangle, external, b1, b2, instance
@@ -803,6 +805,20 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
         else root_missed = true;
     }
     if (tid < 128u) lds.bins[tid] = 0u;
+    // Visits of a mesh that is ONE leaf of more than 4 triangles (a Cornell cube: 12) are shared by 8 lanes: a wave's dense items are a
+    // mix of such visits and of 2-triangle walls, and with one lane per visit the wave's triangle loop ran as long as its longest item
+    // (config B: 10.6 iterations per wave and pass at 21 of 64 lanes).  Bit k of wide_mask: instance k (of the first 64) has such a mesh.
+    unsigned long long wide_mask = 0ull;
+    if (sorted) {
+        const uint32_t k = tid & 63u;
+        bool wide = false;
+        if (k < s.n_instances) {
+            const uint32_t root = __float_as_uint(s.instances[7 * k].w);
+            const uint32_t meta = __float_as_uint(s.nodes[2 * root + 1].w);
+            wide = (meta & HIPRZ_NODE_LEAF) != 0u && (meta & HIPRZ_NODE_COUNT_MASK) > 4u;
+        }
+        wide_mask = __ballot(wide);
+    }
     __syncthreads();
 
     uint32_t guard = 0u;
@@ -870,30 +886,53 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
         uint32_t* bins = lds.bins + (round & 1u) * 64u;
         uint32_t rank = 0u;
         const uint32_t bin = sorted ? cand : 0u;
-        if (cand != RZ_BIN_NONE) rank = atomicAdd(&bins[bin], 1u);
+        const bool wide_item = cand != RZ_BIN_NONE && cand < 64u && ((wide_mask >> cand) & 1ull) != 0ull;
+        if (cand != RZ_BIN_NONE) rank = atomicAdd(&bins[bin], wide_item ? 8u : 1u);  // in lanes: 8 per visit of a wide instance
         __syncthreads();
         const uint32_t lane = tid & 63u;
         const uint32_t c = bins[lane];
-        uint32_t incl = c;
+        // ONE scan for three prefix sums, packed: lanes of the wide bins (bits 0-11: they come first, so every visit's 8 lanes are an aligned
+        // octet), lanes of the other bins (12-20), visits of all bins (21-29: the order when the lanes would not fit the workgroup)
+        const bool wide_bin = ((wide_mask >> lane) & 1ull) != 0ull;
+        uint32_t incl = wide_bin ? (c | ((c >> 3) << 21)) : ((c << 12) | (c << 21));
+        const uint32_t own = incl;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t v = __shfl_up(incl, off);
             if (int(lane) >= off) incl += v;
         }
-        const uint32_t n_items = __shfl(incl, 63);
-        if (n_items == 0u) break;  // workgroup-uniform
-        const uint32_t start = __shfl(incl - c, int(bin & 63u));
-        if (cand != RZ_BIN_NONE) lds.items[start + rank] = (cand << 8) | tid;
+        const uint32_t totals = __shfl(incl, 63);
+        const uint32_t n_visits = totals >> 21;
+        if (n_visits == 0u) break;  // workgroup-uniform
+        const uint32_t wide_lanes = totals & 0xFFFu, narrow_lanes = (totals >> 12) & 0x1FFu;
+        const bool split = wide_lanes != 0u && wide_lanes + narrow_lanes <= 256u;  // workgroup-uniform: else one lane per visit, as before
+        const uint32_t n_items = split ? wide_lanes + narrow_lanes : n_visits;
+        const uint32_t before = __shfl(incl - own, int(bin & 63u));
+        if (cand != RZ_BIN_NONE) {
+            if (split && wide_item) {
+                const uint32_t at = (before & 0xFFFu) + rank;
+#pragma unroll
+                for (uint32_t j = 0; j < 8u; ++j) lds.items[at + j] = RZ_BIN_WIDE | (cand << 8) | tid;
+            } else if (split) {
+                lds.items[wide_lanes + ((before >> 12) & 0x1FFu) + rank] = (cand << 8) | tid;
+            } else {
+                lds.items[(before >> 21) + (wide_item ? rank >> 3 : rank)] = (cand << 8) | tid;
+            }
+        }
         if (tid < 64u) lds.bins[((round + 1u) & 1u) * 64u + tid] = 0u;
         __syncthreads();
 
-        // C. dense: one lane per item (closestIntersection(instance) + (mesh), :299-352).  The lane that
-        //    takes item i rotates with the round and the workgroup, so the busy waves — and with them the
-        //    SIMDs they live on — change from round to round instead of always being waves 0..1.
+        // C. dense: one lane per item (closestIntersection(instance) + (mesh), :299-352) — eight per visit of a wide instance, lane j
+        //    of the octet testing triangles j, j + 8, ... of the mesh's one leaf.  The lane that takes item i rotates with the round and
+        //    the workgroup, so the busy waves — and with them the SIMDs they live on — change from round to round instead of always
+        //    being waves 0..1.
         const uint32_t slot = (tid - ((blockIdx.x + round) & 3u) * 64u) & 255u;
+        uint32_t wide_t = 0xFFFFFFFFu, wide_tri = 0xFFFFFFFFu, wide_src = 0u, wide_inst = 0u;  // this lane's best triangle of a shared visit
+        float wide_b1 = 0.0f, wide_b2 = 0.0f, wide_near = 0.0f, wide_len = 1.0f;
+        bool wide_external = false;
         if (slot < n_items) {
             RZ_PHASE(2);
-            const uint32_t item = lds.items[slot], inst = item >> 8, src = item & 255u;
+            const uint32_t item = lds.items[slot], inst = (item & 0x7FFFFFFFu) >> 8, src = item & 255u;
             WalkRay w;
             w.o = V3(lds.ray[0 * 256 + src], lds.ray[1 * 256 + src], lds.ray[2 * 256 + src]);
             w.d = V3(lds.ray[3 * 256 + src], lds.ray[4 * 256 + src], lds.ray[5 * 256 + src]);
@@ -901,16 +940,54 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
             const InstanceXform x = load_instance_xform(s, inst);
             WalkRay lr;
             const float len = to_local<RCP>(x, w, lr, scene_fast);
-            LdsStack mesh(mesh_column);
-            Hit h;
-            if (closest_in_mesh_stack<COUNT, RCP, false>(s, mesh, x.blas_root, lr, h, cnt)) {  // single-leaf meshes: one box test per visit
-                lds.ray[6 * 256 + src] = lr.near_ / len;
-                lds.ray[7 * 256 + src] = lr.far_ / len;
-                lds.hit[0 * 256 + src] = h.triangle;
-                lds.hit[1 * 256 + src] = h.external ? 1u : 0u;
-                lds.hit[2 * 256 + src] = __float_as_uint(h.bx);
-                lds.hit[3 * 256 + src] = __float_as_uint(h.by);
-                lds.hit[4 * 256 + src] = inst;
+            if (item & RZ_BIN_WIDE) {
+                // the mesh is one leaf: its box once per visit (counted by lane 0 of the octet), then this lane's share of its triangles —
+                // each against the range the visit started with, shortened by this lane's own earlier hits; the octet's minimum below is
+                // what the one-by-one loop ends with (the nearest hit, the first in leaf order among equal distances)
+                const uint32_t j = slot & 7u;
+                const float4 n0 = s.nodes[2 * x.blas_root], n1 = s.nodes[2 * x.blas_root + 1];
+                RZ_PHASE(3);
+                if (j == 0u) { RZ_COUNT(box_tests); }
+                wide_src = src, wide_inst = inst, wide_near = lr.near_, wide_len = len;
+                if (box_hit_unpacked<RCP>(n0, n1, lr)) {
+                    const uint32_t begin = __float_as_uint(n1.z), end = begin + (__float_as_uint(n1.w) & HIPRZ_NODE_COUNT_MASK);
+                    for (uint32_t i = begin + j; i < end; i += 8u) {
+                        const float4 a = s.tris[3 * i], b = s.tris[3 * i + 1], cc = s.tris[3 * i + 2];
+                        float t, b1, b2, det;
+                        RZ_PHASE(4);
+                        RZ_COUNT(tri_tests);
+                        if (tri_hit(xyz(a), xyz(b), xyz(cc), lr, t, b1, b2, det)) {
+                            lr.far_ = t;
+                            wide_t = __float_as_uint(t), wide_tri = i, wide_b1 = b1, wide_b2 = b2, wide_external = det > 0.0f;
+                        }
+                    }
+                }
+            } else {
+                LdsStack mesh(mesh_column);
+                Hit h;
+                if (closest_in_mesh_stack<COUNT, RCP, false>(s, mesh, x.blas_root, lr, h, cnt)) {  // single-leaf meshes: one box test per visit
+                    lds.ray[6 * 256 + src] = lr.near_ / len;
+                    lds.ray[7 * 256 + src] = lr.far_ / len;
+                    lds.hit[0 * 256 + src] = h.triangle;
+                    lds.hit[1 * 256 + src] = h.external ? 1u : 0u;
+                    lds.hit[2 * 256 + src] = __float_as_uint(h.bx);
+                    lds.hit[3 * 256 + src] = __float_as_uint(h.by);
+                    lds.hit[4 * 256 + src] = inst;
+                }
+            }
+        }
+        if (split) {  // workgroup-uniform: the winner of every octet hands the visit's hit to the ray's slot (distances are positive: their bits order like they do)
+            const uint32_t t_min = octet_min(wide_t);
+            const bool nearest = wide_t != 0xFFFFFFFFu && wide_t == t_min;
+            const uint32_t first = octet_min(nearest ? wide_tri : 0xFFFFFFFFu);
+            if (nearest && wide_tri == first) {
+                lds.ray[6 * 256 + wide_src] = wide_near / wide_len;
+                lds.ray[7 * 256 + wide_src] = __uint_as_float(wide_t) / wide_len;
+                lds.hit[0 * 256 + wide_src] = wide_tri;
+                lds.hit[1 * 256 + wide_src] = wide_external ? 1u : 0u;
+                lds.hit[2 * 256 + wide_src] = __float_as_uint(wide_b1);
+                lds.hit[3 * 256 + wide_src] = __float_as_uint(wide_b2);
+                lds.hit[4 * 256 + wide_src] = wide_inst;
             }
         }
         __syncthreads();
@@ -1132,6 +1209,12 @@ RZ_DEV uint32_t quad_min(uint32_t v) {
     uint32_t o = uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0xB1, 0xF, 0xF, false));  // quad_perm:[1,0,3,2]
     v = o < v ? o : v;
     o = uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x4E, 0xF, 0xF, false));           // quad_perm:[2,3,0,1]
+    return o < v ? o : v;
+}
+// ... and over each octet (aligned group of 8 lanes): the quads' minima exchanged across the half row (row_half_mirror: lane i <-> 7 - i)
+RZ_DEV uint32_t octet_min(uint32_t v) {
+    v = quad_min(v);
+    const uint32_t o = uint32_t(__builtin_amdgcn_update_dpp(int(v), int(v), 0x141, 0xF, 0xF, false));
     return o < v ? o : v;
 }
 // How the triangles of the lanes that hold a leaf are dealt out: a holder of c <= 4 triangles fills ONE entry (a quad of lanes), a

@@ -103,6 +103,7 @@ def test_tile_export_of_a_context_with_several_streams(built):
         buf, img = C.c_void_p(), C.c_void_p()
         assert hip.hipMalloc(C.byref(buf), capacity * 16) == 0 and hip.hipMalloc(C.byref(img), want.nbytes) == 0
         hip.hipMemset(img, 0, want.nbytes)
+        hip.hipDeviceSynchronize()   # (the memset is on the null stream; the context's streams are non-blocking and do not wait for it)
         many.export_accum_tiles(buf.value, capacity * 16)
         for k in range(streams):
             many.untile_accum(buf.value + k * part_capacity * 16, rank * streams + k, n_ranks * streams, img.value)

@@ -25,6 +25,7 @@ def _device_buffer(nbytes):
     p = C.c_void_p()
     assert _hip.hipMalloc(C.byref(p), max(nbytes, 16)) == 0
     assert _hip.hipMemset(p, 0, max(nbytes, 16)) == 0
+    assert _hip.hipDeviceSynchronize() == 0   # the memset is queued on the null stream; the contexts' streams are non-blocking and do not wait for it
     return p
 
 
