@@ -927,9 +927,6 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
         //    the workgroup, so the busy waves — and with them the SIMDs they live on — change from round to round instead of always
         //    being waves 0..1.
         const uint32_t slot = (tid - ((blockIdx.x + round) & 3u) * 64u) & 255u;
-        uint32_t wide_t = 0xFFFFFFFFu, wide_tri = 0xFFFFFFFFu, wide_src = 0u, wide_inst = 0u;  // this lane's best triangle of a shared visit
-        float wide_b1 = 0.0f, wide_b2 = 0.0f, wide_near = 0.0f, wide_len = 1.0f;
-        bool wide_external = false;
         if (slot < n_items) {
             RZ_PHASE(2);
             const uint32_t item = lds.items[slot], inst = (item & 0x7FFFFFFFu) >> 8, src = item & 255u;
@@ -948,7 +945,10 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
                 const float4 n0 = s.nodes[2 * x.blas_root], n1 = s.nodes[2 * x.blas_root + 1];
                 RZ_PHASE(3);
                 if (j == 0u) { RZ_COUNT(box_tests); }
-                wide_src = src, wide_inst = inst, wide_near = lr.near_, wide_len = len;
+                uint32_t wide_t = 0xFFFFFFFFu, wide_tri = 0xFFFFFFFFu;  // this lane's best triangle of the shared visit
+                float wide_b1 = 0.0f, wide_b2 = 0.0f;
+                bool wide_external = false;
+                const float visit_near = lr.near_;
                 if (box_hit_unpacked<RCP>(n0, n1, lr)) {
                     const uint32_t begin = __float_as_uint(n1.z), end = begin + (__float_as_uint(n1.w) & HIPRZ_NODE_COUNT_MASK);
                     for (uint32_t i = begin + j; i < end; i += 8u) {
@@ -962,6 +962,20 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
                         }
                     }
                 }
+                // the octet's winner hands the visit's hit to the ray's slot (the 8 lanes of a visit take this branch together; distances
+                // are positive: their bits order like they do)
+                const uint32_t t_min = octet_min(wide_t);
+                const bool nearest = wide_t != 0xFFFFFFFFu && wide_t == t_min;
+                const uint32_t first = octet_min(nearest ? wide_tri : 0xFFFFFFFFu);
+                if (nearest && wide_tri == first) {
+                    lds.ray[6 * 256 + src] = visit_near / len;
+                    lds.ray[7 * 256 + src] = __uint_as_float(wide_t) / len;
+                    lds.hit[0 * 256 + src] = wide_tri;
+                    lds.hit[1 * 256 + src] = wide_external ? 1u : 0u;
+                    lds.hit[2 * 256 + src] = __float_as_uint(wide_b1);
+                    lds.hit[3 * 256 + src] = __float_as_uint(wide_b2);
+                    lds.hit[4 * 256 + src] = inst;
+                }
             } else {
                 LdsStack mesh(mesh_column);
                 Hit h;
@@ -974,20 +988,6 @@ __device__ __forceinline__ int closest_hit_binned(const DScene& s, unsigned char
                     lds.hit[3 * 256 + src] = __float_as_uint(h.by);
                     lds.hit[4 * 256 + src] = inst;
                 }
-            }
-        }
-        if (split) {  // workgroup-uniform: the winner of every octet hands the visit's hit to the ray's slot (distances are positive: their bits order like they do)
-            const uint32_t t_min = octet_min(wide_t);
-            const bool nearest = wide_t != 0xFFFFFFFFu && wide_t == t_min;
-            const uint32_t first = octet_min(nearest ? wide_tri : 0xFFFFFFFFu);
-            if (nearest && wide_tri == first) {
-                lds.ray[6 * 256 + wide_src] = wide_near / wide_len;
-                lds.ray[7 * 256 + wide_src] = __uint_as_float(wide_t) / wide_len;
-                lds.hit[0 * 256 + wide_src] = wide_tri;
-                lds.hit[1 * 256 + wide_src] = wide_external ? 1u : 0u;
-                lds.hit[2 * 256 + wide_src] = __float_as_uint(wide_b1);
-                lds.hit[3 * 256 + wide_src] = __float_as_uint(wide_b2);
-                lds.hit[4 * 256 + wide_src] = wide_inst;
             }
         }
         __syncthreads();
