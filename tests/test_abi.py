@@ -55,3 +55,17 @@ def test_create_fails_loudly_without_a_gpu(built):
     rc = lib.hiprz_create(C.byref(ctx), 0)
     assert rc == _abi.ERR_DEVICE and not ctx
     assert b"HIP device" in lib.hiprz_last_error(None)
+
+
+def test_every_launch_site_registered_its_kernel_and_the_built_files_hold_them(built):
+    """hiprz_kernel_count(): the kernel instantiations the launchers can select, registered when the library was loaded (RZ_LAUNCH); the first
+    hiprz_create on a device resolves each of them in the loaded code objects.  tools/check_kernels.py proves on the built files — no GPU
+    needed — that every host stub has its gfx950 kernel, that no kernel is instantiated in two units and that no object is older than a
+    file it includes; its count is the library's."""
+    import subprocess
+    import sys
+    n = _lib.load().hiprz_kernel_count()
+    assert n >= 200
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_kernels.py")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert int(re.search(r"check_kernels: (\d+) kernel instantiations", out.stdout).group(1)) == n
