@@ -312,6 +312,8 @@ int hiprz_set_shard(hiprz_ctx* ctx, uint32_t rank, uint32_t world);
  * hiprz_read_depth, hiprz_read_state, hiprz_ray_cast and hiprz_pass_count answer for part 0 (the first-pass depth is every part's).
  * A call of hiprz_render(p) therefore adds n * p samples per pixel.  The frame equals the sum of n one-part frames rendered with the
  * seeds seed .. seed + n - 1 — the same for a given n, another one for another n.  Changing the mode restarts accumulation.
+ * HIPRZ_COMPAT_REPROJECTION under this mode: every part keeps the history of its own frame (each holds the whole share), so a restarted
+ * frame starts from the sum of the parts' blended histories — what one part's history is to one part's frame.
  * Processes that sample-shard a frame between them give each context its own `config.seed` (rank * n apart) and reduce the exported
  * accumulators (rayzath_amd/distributed.py: ShardedFrame.reduce, one ncclReduce(sum) per readback). */
 #define HIPRZ_SHARD_TILES 0u
