@@ -368,7 +368,12 @@ int hiprz_set_temporal_blend(hiprz_ctx* ctx, float blend);
  * (bvh_tree_node.hpp:117-215), the anchor of the work counters.  HIPRZ_TREE_SAH: at upload every mesh tree is rebuilt over the same
  * triangles with a binned surface-area heuristic (leaves of at most 8 triangles).  A tree decides which boxes and triangles a ray
  * meets, not what it hits: frames are identical (equally distant triangles are ranked by their position in the reference's visiting
- * order), while the tests per segment drop.  With a rebuilt tree every walk — counted ones too — runs front to back on skip links
+ * order), while the tests per segment drop.  One caveat, and it is the reference's arithmetic: Moeller-Trumbore bumps a determinant
+ * below 1e-7 to 1e-7 (mesh_component.cpp:52-83), so a triangle with an area around 1e-7 and a ray nearly in its plane can report a
+ * hit at a distance that has nothing to do with it — a hit that exists only if that triangle is TESTED, i.e. if the ray meets the
+ * box of the leaf it sits in, and every tree groups leaves differently.  BASELINE's configs A - E have no such triangles (frames equal
+ * under all trees at full size); a 3 M-triangle version of D differs in 39 of 2 073 600 first hits (profiles/r04/tree_dependence_F.txt).
+ * A host that needs the reference's frames on such meshes keeps HIPRZ_TREE_REFERENCE.  With a rebuilt tree every walk — counted ones too — runs front to back on skip links
  * (the scene is not staged in LDS), and the work counters are those of the rebuilt tree.  Takes effect at the next hiprz_upload_scene. */
 #define HIPRZ_TREE_REFERENCE 0u
 #define HIPRZ_TREE_SAH 1u

@@ -122,6 +122,9 @@ CONFIGS = {
     "C": dict(build=lambda: cornell_sphere(1920, 1080, 80), max_depth=8, note="Cornell + 6 240-tri sphere, 1920x1080 depth 8"),
     "D": dict(build=lambda: textured_sphere_scene(1920, 1080, 550), max_depth=8, note="301 400-tri textured sphere, 1920x1080 depth 8"),
     "E": dict(build=lambda: living_room(3840, 2160), max_depth=8, note="living room, lights + glass + scattering, 3840x2160"),
+    # not a BASELINE config: D's scene with ten times the triangles, so that the geometry (3.06 M triangles: 147 MB of intersection records,
+    # 49 MB of walk records) no longer lives in the 32 MB of L2 — what the walks do when nodes and triangles really stream
+    "F": dict(build=lambda: textured_sphere_scene(1920, 1080, 1750), max_depth=8, note="3.06 M-tri textured sphere, 1920x1080 depth 8 (geometry beyond L2; not a BASELINE config)"),
 }
 
 

@@ -63,7 +63,7 @@ def oracle_frame(name):
 
 
 @pytest.mark.parametrize("packaging", ["bare", "shipped"])
-@pytest.mark.parametrize("name,rgb_close,alpha_equal", [("B", 0.999999, 0.999999), ("C", 0.9999, 0.9999), ("D", 0.9997, 0.9997), ("E", 0.992, 0.9994)])
+@pytest.mark.parametrize("name,rgb_close,alpha_equal", [("B", 0.999999, 0.999999), ("C", 0.9999, 0.9999), ("D", 0.9997, 0.9997), ("E", 0.992, 0.9994), ("F", 0.999, 0.999)])
 def test_full_size_frame_against_the_oracle(built, name, packaging, rgb_close, alpha_equal):
     """PASSES = max_depth + 4 passes of the whole frame on the GPU and in the CPU oracle — one first pass, then batches of 8 and 3 cumulative
     passes (the second batch size is new to the context: another graph): every path that survives 8 segments is ended by the depth limit
@@ -94,18 +94,29 @@ def test_full_size_frame_against_the_oracle(built, name, packaging, rgb_close, a
             assert first[total] - first[shadow] == ref_first[total] - ref_first[shadow], total
         for k in ("shadow_rays", "shadow_box_tests", "shadow_tri_tests"):
             assert abs(first[k] - ref_first[k]) <= 1e-5 * max(ref_first[k], 1), k
-        if name in ("B", "C", "D"):
+        if name in ("B", "C", "D", "F"):
             assert first == ref_first
     else:
         k = default_streams(len(flat.spot_lights) + len(flat.direct_lights))
         ctx = Context([0] * k) if k > 1 else Context(0)
         ctx.set_tree(TREE_AUTO)
         ctx.upload_scene(flat), ctx.upload_camera(cam), ctx.set_config(RenderConfig(tracing=Tracing(depth, 8)).struct())
-        assert ctx.device_count() == (1 if name == "E" else 2) and ctx.tree() == (0 if name == "B" else 3)
+        assert ctx.device_count() == (1 if name == "E" else 2) and ctx.tree() == (0 if name == "B" else 3)   # (F: D's scene with 3.06 M triangles)
         ctx.render(1)
     ctx.render(8), ctx.render(PASSES - 9)
     acc, racc = ctx.read_accum(), ref["accum"]
-    assert np.array_equal(ctx.read_depth(), ref["depth"])                       # first-hit distances: no libm on that path
+    if name == "F" and packaging == "shipped":
+        # D's scene with 3.06 M triangles.  On the REFERENCE trees the GPU's first-hit depths equal the oracle's (the bare packaging, above
+        # this branch's else).  On other trees 39 of 2 073 600 differ, and it is the reference's arithmetic, not the walk: Moeller-Trumbore
+        # bumps a determinant below 1e-7 to 1e-7 (mesh_component.cpp:52-83), which for triangles this small (areas ~1e-7) and rays nearly in
+        # their plane yields b1, b2, t that pass every test at a distance that has nothing to do with the triangle (0.04 .. 1.4 in front of a
+        # sphere 2.3 away) — a false hit that exists only if that triangle is TESTED, i.e. if the ray meets the box of the leaf it sits
+        # in, and leaves are grouped differently in every tree (tools/debug_tree_depth.py F: under the reference trees 38 such pixels,
+        # where the device's surface-area trees find the sphere; 1 the other way round).  Configs A - E have no such triangle: their
+        # frames are equal under all trees (test_the_hosts_default_trees_give_the_reference_trees_frames_at_full_size).
+        assert (ctx.read_depth() != ref["depth"]).sum() <= 100
+    else:
+        assert np.array_equal(ctx.read_depth(), ref["depth"])                   # first-hit distances: no libm on that path
     close = (np.abs(acc[..., :3] - racc[..., :3]) <= 1e-3 * np.maximum(np.abs(racc[..., :3]), 1.0)).all(-1).mean()
     same_alpha = (acc[..., 3] == racc[..., 3]).mean()
     exact = (acc == racc).all(-1).mean()
