@@ -514,6 +514,11 @@ int hiprz_pick(hiprz_ctx* ctx, uint32_t x, uint32_t y, int32_t* instance_out, in
 /* Device self-test of the kernels' exact-arithmetic shortcuts (shared-reciprocal division must
  * equal the correctly rounded quotient): runs 262144 * cases_per_thread random cases. */
 int hiprz_selftest(hiprz_ctx* ctx, uint32_t cases_per_thread, uint32_t seed, uint64_t* mismatches, uint64_t* tested);
+/* Device self-test of the ray-order radix sort (hiprz_sort.hip; no reference counterpart — the reference traces pixels in tile order):
+ * sorts the caller's n keys (host array, 1..32 significant bits from bit 0; the sort looks at whole bytes) `repeats` times and checks
+ * on the host that the result is a STABLE permutation in key order and that the sorted keys are the keys in that order.
+ * *errors = violations found, *sort_us = device time of the fastest repeat (HIP events on the context's stream). */
+int hiprz_selftest_sort(hiprz_ctx* ctx, const uint32_t* keys_host, uint32_t n, int key_bits, uint32_t repeats, uint64_t* errors, double* sort_us);
 
 /* --- timing (TimeTable, engine_parts.hpp:34-74; Engine::debugInfo, rayzath.cpp:96-113) --- */
 int hiprz_timings(hiprz_ctx* ctx, char* buf, size_t len);

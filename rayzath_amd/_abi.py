@@ -162,6 +162,7 @@ ENTRY_POINTS = {
     "hiprz_pick": (C.c_int, [P, U32, U32, C.POINTER(I32), C.POINTER(I32)]),
     "hiprz_ray_cast": (C.c_int, [P, U32, U32, C.POINTER(RayCast)]),
     "hiprz_selftest": (C.c_int, [P, U32, U32, C.POINTER(U64), C.POINTER(U64)]),
+    "hiprz_selftest_sort": (C.c_int, [P, C.POINTER(U32), U32, C.c_int, U32, C.POINTER(U64), C.POINTER(C.c_double)]),
     "hiprz_timings": (C.c_int, [P, C.c_char_p, SZ]),
     "hiprz_time_kernels": (C.c_int, [P, C.c_int]),
     "hiprz_kernel_breakdown_ms": (C.c_int, [P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(U32)]),

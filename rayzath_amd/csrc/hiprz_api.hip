@@ -315,9 +315,9 @@ void release_frame(hiprz_frame_state* c) {
     c->hit0.release(), c->hit1.release();
     c->nee.release(), c->prev_accum.release(), c->prev_depth.release();
     c->unit_cost.release(), c->launch_order.release(), c->order_keys.release();
-    c->order_sort.keys_out.release(), c->order_sort.vals_a.release(), c->order_sort.vals_b.release(), c->order_sort.counts.release(), c->order_sort.digit_total.release();
+    c->order_sort.keys_out.release(), c->order_sort.vals_a.release(), c->order_sort.vals_b.release(), c->order_sort.counts.release(), c->order_sort.row_total.release();
     c->sort_keys.release(), c->sort_perm.release();
-    for (auto& t : c->sort_temp) t.keys_out.release(), t.vals_a.release(), t.vals_b.release(), t.counts.release(), t.digit_total.release();
+    for (auto& t : c->sort_temp) t.keys_out.release(), t.vals_a.release(), t.vals_b.release(), t.counts.release(), t.row_total.release();
     c->shadow_keys.release(), c->shadow_perm.release();
     c->image_f4.release(), c->state_md.release(), c->state_ray.release(), c->gather.release(), c->sum_accum.release();
 }
@@ -708,7 +708,7 @@ std::vector<unsigned char> graph_key_of(hiprz_ctx* c, const DFrame& f, uint32_t 
     const DConfig cfg = make_config(c);
     put(&c->dscene, sizeof(DScene)), put(&c->dcamera, sizeof(DCamera)), put(&cfg, sizeof cfg), put(&f, sizeof f);
     for (const auto& t : c->sort_temp) {
-        const void* ptrs[5] = {t.keys_out.ptr, t.vals_a.ptr, t.vals_b.ptr, t.counts.ptr, t.digit_total.ptr};
+        const void* ptrs[5] = {t.keys_out.ptr, t.vals_a.ptr, t.vals_b.ptr, t.counts.ptr, t.row_total.ptr};
         put(ptrs, sizeof ptrs);
     }
     const int settings[] = {c->pipeline, effective_mode(c), c->walk_order, c->trace_waves, int(c->scene_tree), effective_sort_bits(c), int(defer_shadows(c)),
@@ -1326,7 +1326,7 @@ int hiprz_destroy(hiprz_ctx* c) {
     c->hot.release(), c->node_skip.release(), c->nodes64.release(), c->textures.release();
     c->dev_nodes.release(), c->has_mesh.release(), c->build_temp.release(), c->slot_parent.release(), c->ref_to_dev.release(), c->refit_visit.release();
     c->world_items.release(), c->update_tris.release(), c->update_attrs.release();
-    c->build_sort.keys_out.release(), c->build_sort.vals_a.release(), c->build_sort.vals_b.release(), c->build_sort.counts.release(), c->build_sort.digit_total.release();
+    c->build_sort.keys_out.release(), c->build_sort.vals_a.release(), c->build_sort.vals_b.release(), c->build_sort.counts.release(), c->build_sort.row_total.release();
     c->texels.release(), c->spot_lights.release(), c->direct_lights.release();
     release_frame(c);
     c->pass_dev.release(), c->counters_dev.release(), c->pick_dev.release();

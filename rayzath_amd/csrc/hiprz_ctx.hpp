@@ -132,7 +132,7 @@ struct hiprz_frame_state {
     // next trace kernel follows
     hiprz::DeviceArray<uint32_t> sort_keys, sort_perm;
     struct SortTemp {  // ping-pong buffers of one sort; the ray sort and the shadow-ray sort of a pass run side by side, each on its own set
-        hiprz::DeviceArray<uint32_t> keys_out, vals_a, vals_b, counts, digit_total;
+        hiprz::DeviceArray<uint32_t> keys_out, vals_a, vals_b, counts, row_total;
     } sort_temp[2];
     bool sort_beside = false;  // a sort is running on the auxiliary stream: join_sort() before its order is used
     bool perm_valid = false;  // sort_perm holds the order of the NEXT cumulative pass's rays

@@ -7,6 +7,15 @@
 namespace hiprz {
 namespace {
 
+// The two orders a shaded pass needs.  The next pass's ray order is needed by the shadow kernel only when it has no order of its own
+// (HIPRZ_SHADOW_SORT=0); otherwise it is sorted on the auxiliary stream beside the shadow rays' sort and walk, and the main stream
+// picks it up after them (join_sort).  (The shadow rays' sort first and alone, the ray sort beside the walk only: measured on E in
+// round 4 with the runs sort, 41.8 against 41.4 ms per step — two memory-bound sorts share the chip better than a sort and the walk.)
+void sort_after_shading(hiprz_ctx* c, const DFrame& f) {
+    launch_sort(c, f.shadow_key != nullptr);
+    if (f.shadow_key) launch_shadow_sort(c);
+}
+
 template <bool FIRST, bool COUNT>
 void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
     const PassGeometry g = pass_geometry(c);
@@ -18,8 +27,7 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
         // cooperative kernel in their own sorted order; with HIPRZ_COMPAT_SHADOW_COLOR its mask-collecting instantiation (round 4).
         if (lights && defer_shadows(c)) {
             RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_COMPAT_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-            launch_sort(c, f.shadow_key != nullptr);
-            if (f.shadow_key) launch_shadow_sort(c);
+            sort_after_shading(c, f);
             if (c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR)  // coloured masks: the same kernel, its rays go through what they cross and collect the opacity colours
                 RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 3, true>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
             else
@@ -41,10 +49,7 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
     } else if (lights && defer_shadows(c)) {
         // shading without shadow walks, then every shadow ray of the pass in a lean single-wave kernel
         RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
-        // The next pass's ray order: needed by the shadow kernel only when it has no order of its own (HIPRZ_SHADOW_SORT=0) — otherwise
-        // that sort runs on the auxiliary stream beside the shadow-ray sort and walk, and the main stream picks it up after them.
-        launch_sort(c, f.shadow_key != nullptr);
-        if (f.shadow_key) launch_shadow_sort(c);
+        sort_after_shading(c, f);
         const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
         if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) || c->scene_tree != HIPRZ_TREE_REFERENCE) {
             RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 4>), sgrid, sblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);

@@ -282,6 +282,14 @@ class Context:
         self._check(self.lib.hiprz_selftest(self._ctx, cases_per_thread, seed, C.byref(bad), C.byref(n)))
         return bad.value, n.value
 
+    def selftest_sort(self, keys, key_bits=24, repeats=1):
+        """The ray-order radix sort on `keys` (uint32 array): (violations of "stable permutation in key order", device microseconds)."""
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        bad, us = C.c_uint64(), C.c_double()
+        self._check(self.lib.hiprz_selftest_sort(self._ctx, keys.ctypes.data_as(C.POINTER(C.c_uint32)), keys.size, int(key_bits), int(repeats),
+                                                 C.byref(bad), C.byref(us)))
+        return bad.value, us.value
+
     def timings(self):
         buf = C.create_string_buffer(4096)
         self._check(self.lib.hiprz_timings(self._ctx, buf, len(buf)))
