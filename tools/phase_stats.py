@@ -15,6 +15,7 @@ for cfgname in sys.argv[1:] or ["D"]:
         ctx.set_traversal_mode(2), ctx.set_pipeline(1)   # workgroup-binned walk: same step kinds, "round" = one binning round
     else:
         ctx.set_traversal_mode(3), ctx.set_pipeline(1), ctx.set_ray_sort(int(os.environ.get('PHASE_RAY_SORT', '0')))
+    ctx.set_tree(int(os.environ.get('PHASE_TREE', '4')))   # 4: the Engine hosts' default trees
     ctx.upload_scene(flatten(w)); ctx.upload_camera(camera_struct(w.camera)); ctx.set_config(RenderConfig(tracing=Tracing(preset["max_depth"], 8)).struct())
     out = (C.c_uint64 * 16)()
     ctx.render(9); ctx.sync(); ctx.lib.hiprz_read_phase_stats(out)
