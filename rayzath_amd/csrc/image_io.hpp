@@ -7,7 +7,8 @@
 //   PNG  all colour types and bit depths, palette + tRNS, Adam7 interlacing; chunk CRCs are verified; inflate by zlib
 //   BMP  uncompressed 8-bit paletted, 24 and 32 bits per pixel, bottom-up or top-down
 //   TGA  types 2 / 3 / 10 / 11 (true colour or grey, raw or run-length encoded), 8 / 24 / 32 bits, either row order
-//   JPEG baseline / extended sequential (Huffman, 8 bits, grey or YCbCr, any 1-2-4 sampling, restart intervals); progressive refused
+//   JPEG baseline, extended sequential and progressive (Huffman, 8 bits, grey or YCbCr, any 1-2-4 sampling, restart intervals; T.81 Annex G:
+//        spectral selection + successive approximation, a file cut short decodes from the scans it has); arithmetic coding and 12 bits refused
 //   PNM  binary P5 / P6
 // with stb_image's conventions where a file leaves a choice: 16-bit samples keep their high byte, 1/2/4-bit grey is scaled to
 // 0..255, a tRNS colour key becomes alpha 0, JPEG chroma is upsampled with its 3:1 triangle filter and converted with its fixed-point
