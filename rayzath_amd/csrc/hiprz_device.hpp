@@ -103,7 +103,7 @@ struct DScene {
     // ray-direction octants
     const float4* nodes64;
     uint32_t shadow_variant;  // the same for the shadow rays' key (HIPRZ_SHADOW_KEY)
-    uint32_t sort_variant;  // ray_sort_key layout (HIPRZ_SORT_KEY): 0 origin cell then direction, 1 direction then cell, 2 interleaved
+    uint32_t sort_variant;  // ray_sort_key layout (HIPRZ_SORT_KEY): 0 origin cell then direction, 1 direction then cell, 2 interleaved, 3 octahedral direction interleaved with the cell
 };
 
 // Re-point the blob sections at a staged copy (LDS).
@@ -2238,6 +2238,24 @@ RZ_DEV uint32_t ray_sort_key(const DScene& s, v3 o, v3 d, uint32_t variant) {
     const uint32_t qy = uint32_t(fminf(fmaxf(d.y * inv * 3.99f + 4.0f, 0.0f), 7.0f));
     const uint32_t qz = uint32_t(fminf(fmaxf(d.z * inv * 3.99f + 4.0f, 0.0f), 7.0f));
     if (variant == 1u) return (((qx << 6) | (qy << 3) | qz) << 15) | morton;  // direction-major
+    if (variant == 3u) {
+        // the direction on the octahedron — two coordinates of 6 bits in Z-order instead of three of which one is saturated — interleaved
+        // with the origin's cell in a 16^3 grid: 2 direction bits, 3 cell bits, four times, then the direction's last 4 bits.  (Round 4, config E:
+        // trace kernel 2 664 -> 2 558 us against the 6-D code; the same bits direction-first 3 561, cell-first within a level 2 592.)
+        const float l1 = 1.0f / fmaxf(fabsf(d.x) + fabsf(d.y) + fabsf(d.z), 1.0e-30f);
+        float u = d.x * l1, v = d.y * l1;
+        if (d.z < 0.0f) {
+            const float uu = (1.0f - fabsf(v)) * (u < 0.0f ? -1.0f : 1.0f), vv = (1.0f - fabsf(u)) * (v < 0.0f ? -1.0f : 1.0f);
+            u = uu, v = vv;
+        }
+        const uint32_t iu = uint32_t(fminf(fmaxf((u + 1.0f) * 32.0f, 0.0f), 63.0f)), iv = uint32_t(fminf(fmaxf((v + 1.0f) * 32.0f, 0.0f), 63.0f));
+        uint32_t dir = 0u;
+        for (uint32_t b = 0u; b < 6u; ++b) dir |= (((iu >> b) & 1u) << (2u * b)) | (((iv >> b) & 1u) << (2u * b + 1u));
+        const uint32_t coarse = spread3(uint32_t(cx) >> 1) | (spread3(uint32_t(cy) >> 1) << 1) | (spread3(uint32_t(cz) >> 1) << 2);
+        uint32_t key = 0u;
+        for (int b = 3; b >= 0; --b) key = (key << 5) | (((dir >> (2 * b + 4)) & 3u) << 3) | ((coarse >> (3 * b)) & 7u);
+        return (key << 4) | (dir & 15u);
+    }
     if (variant == 2u) {  // 6-D Morton code: 4 bits of each origin cell coordinate and of each direction component, interleaved
         const uint32_t px = uint32_t(cx) >> 1, py = uint32_t(cy) >> 1, pz = uint32_t(cz) >> 1;
         const uint32_t dx = uint32_t(fminf(fmaxf(d.x * inv * 7.99f + 8.0f, 0.0f), 15.0f)), dy = uint32_t(fminf(fmaxf(d.y * inv * 7.99f + 8.0f, 0.0f), 15.0f)),
