@@ -223,10 +223,17 @@ RZ_DEV void shade_and_store(const DScene& s, const DCamera& cam, const DConfig& 
     if constexpr (shadow_mode_defers(SHADOW)) {
         // the shadow rays of this pixel start at the hit point and point at the light the (last) sample chose: rays from one cell to
         // one light walk the same instances.  Pixels without a sample have nothing to walk and sort to the end.
-        if (f.shadow_key)
-            f.shadow_key[p.local] = lds_column.defer_mask ? ray_sort_key(s, V3(lds_column.key_o[0], lds_column.key_o[1], lds_column.key_o[2]),
-                                                                         V3(lds_column.key_dir[0], lds_column.key_dir[1], lds_column.key_dir[2]), s.shadow_variant)
-                                                          : 0x00FFFFFEu;
+        if (f.shadow_key) {
+            uint32_t key = 0x00FFFFFEu;
+            if (lds_column.defer_mask) {
+                key = ray_sort_key(s, V3(lds_column.key_o[0], lds_column.key_o[1], lds_column.key_o[2]),
+                                   V3(lds_column.key_dir[0], lds_column.key_dir[1], lds_column.key_dir[2]), s.shadow_variant & 0xFFu);
+                // pixels with the same set of samples together: the shadow kernel's loop over the sample slots is wave-uniform, and a slot
+                // that only a few of a wave's pixels hold costs the wave a whole walk
+                if (s.shadow_variant & 0x100u) key = ((3u - (lds_column.defer_mask & 3u)) << 22) | (key >> 2);
+            }
+            f.shadow_key[p.local] = key;
+        }
     }
 }
 
