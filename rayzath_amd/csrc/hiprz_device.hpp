@@ -102,7 +102,7 @@ struct DScene {
     // front-to-back mesh walk (hiprz_set_walk_order): 64-B records = node (32 B) + its skip link under each of the 8
     // ray-direction octants
     const float4* nodes64;
-    uint32_t shadow_variant;  // the same for the shadow rays' key (HIPRZ_SHADOW_KEY)
+    uint32_t shadow_variant;  // the same for the shadow rays' key (HIPRZ_SHADOW_KEY); + 0x100: the pixel's set of sample slots leads the key
     uint32_t sort_variant;  // ray_sort_key layout (HIPRZ_SORT_KEY): 0 origin cell then direction, 1 direction then cell, 2 interleaved, 3 octahedral direction interleaved with the cell
 };
 
