@@ -30,6 +30,18 @@ def test_sort_is_a_stable_permutation_in_key_order(built, n):
         assert bad == 0, f"{name}, n={n}: {bad} violations"
 
 
+def test_sort_beyond_one_chunk_of_tile_counts(built):
+    """More than 2 048 tiles of 4 096 keys: the offsets kernel scans a digit's row of tile counts in several chunks and carries the sum on
+    (an 8K frame, or two 4K cameras' worth of rays in one context)."""
+    ctx = Context(0)
+    n = 9_000_001
+    rng = np.random.default_rng(7)
+    for name, keys in (("uniform", rng.integers(0, 1 << 24, n, dtype=np.uint32)),
+                       ("few_digits", (rng.integers(0, 3, n, dtype=np.uint32) * np.uint32(0x00400001)))):
+        bad, us = ctx.selftest_sort(keys, 24)
+        assert bad == 0, f"{name}: {bad} violations"
+
+
 @pytest.mark.parametrize("bits", [1, 8, 9, 16, 24, 25, 32])
 def test_sort_over_every_digit_count(built, bits):
     """1..4 digit passes; keys carry bits above the ones the sort is told about — it looks at whole bytes, the check does too."""
