@@ -1567,11 +1567,12 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     // mesh walk rounds of at most 4 node steps and 8 triangles per lane (measured: D 3 163 -> 2 891 us, C 935 -> 892 us)
     d.walk_k = 4u, d.walk_l = 8u;
     d.walk_h = 65u;  // never: ending the node phase early for a full triangle step measured no gain (D 1 010 vs 999 us)
-    // ray reordering key: where only the closest-hit walk follows the sorted order, direction and origin cell interleaved group best
-    // (config C, the 6-D Morton code: trace kernel 583 -> 503 us; the direction on the octahedron instead of three components of which
-    // one is saturated, round 4: E 2 682 -> 2 558 us, C 324 -> 317); where the deferred shadow rays follow that order too
-    // (HIPRZ_SHADOW_SORT=0) they fan out from the origin cell, so the origin leads (config E: 86.5 ms per step against 92.6)
-    d.sort_variant = (sc->n_spot_lights + sc->n_direct_lights) && c->shadow_sort == 0 ? 0u : 3u;
+    // ray reordering key: where only the closest-hit walk follows the sorted order, the origin's cell interleaved with where the ray is
+    // going groups best (config C, the 6-D Morton code of cell and direction: trace kernel 583 -> 503 us; round 4: the direction on the
+    // octahedron, E 2 682 -> 2 556 us, C 324 -> 316; then the cell where the ray leaves the world box instead of a direction, E -> 2 400,
+    // C -> 299); where the deferred shadow rays follow that order too (HIPRZ_SHADOW_SORT=0) they fan out from the origin cell, so the
+    // origin leads (config E: 86.5 ms per step against 92.6)
+    d.sort_variant = (sc->n_spot_lights + sc->n_direct_lights) && c->shadow_sort == 0 ? 0u : 4u;
     // the shadow rays' key: layout 0 (they fan out from the origin cell), pixels with the same set of sample slots together (+ 0x100: the
     // shadow kernel's loop over the slots is wave-uniform, a slot few of a wave's pixels hold costs the wave a whole walk; E 40.33 -> 39.85 ms)
     d.shadow_variant = 0x100u;
@@ -1671,7 +1672,7 @@ int hiprz_update_shading(hiprz_ctx* c, const hiprz_material* materials, uint32_t
     c->dscene.direct_lights = reinterpret_cast<const float4*>(c->direct_lights.ptr);
     c->dscene.n_spot_lights = n_spot_lights, c->dscene.n_direct_lights = n_direct_lights;
     const bool no_shadow_sort = (n_spot_lights + n_direct_lights) && c->shadow_sort == 0;
-    if (!std::getenv("HIPRZ_SORT_KEY")) c->dscene.sort_variant = no_shadow_sort ? 0u : 3u;
+    if (!std::getenv("HIPRZ_SORT_KEY")) c->dscene.sort_variant = no_shadow_sort ? 0u : 4u;
     invalidate_graphs(c);
     c->reset_pending = true;  // the world changed: accumulation restarts (cpu_engine_renderer.cpp:108-112), for every camera
     for (auto& f : c->parked) f.reset_pending = true;
