@@ -2228,39 +2228,46 @@ RZ_DEV uint32_t spread3(uint32_t v) {  // 5 bits -> every third bit
     v = (v | (v << 2)) & 0x00249249u;
     return v;
 }
+// groups of 3 bits at 3k -> 6k (k = 0..3): the levels of a 12-bit Morton code, three bits apart
+RZ_DEV uint32_t spread_levels(uint32_t v) {
+    v = (v & 0x03Fu) | ((v & 0xFC0u) << 6);
+    return (v & 0x007007u) | ((v & 0x038038u) << 3);
+}
 RZ_DEV uint32_t ray_sort_key(const DScene& s, v3 o, v3 d, uint32_t variant) {
-    const float cx = fminf(fmaxf((o.x - s.bounds_min[0]) * s.bounds_scale[0], 0.0f), 31.0f);
-    const float cy = fminf(fmaxf((o.y - s.bounds_min[1]) * s.bounds_scale[1], 0.0f), 31.0f);
-    const float cz = fminf(fmaxf((o.z - s.bounds_min[2]) * s.bounds_scale[2], 0.0f), 31.0f);
-    const uint32_t morton = spread3(uint32_t(cx)) | (spread3(uint32_t(cy)) << 1) | (spread3(uint32_t(cz)) << 2);
-    const float inv = 1.0f / fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), 1.0e-30f));
-    const uint32_t qx = uint32_t(fminf(fmaxf(d.x * inv * 3.99f + 4.0f, 0.0f), 7.0f));
-    const uint32_t qy = uint32_t(fminf(fmaxf(d.y * inv * 3.99f + 4.0f, 0.0f), 7.0f));
-    const uint32_t qz = uint32_t(fminf(fmaxf(d.z * inv * 3.99f + 4.0f, 0.0f), 7.0f));
-    if (variant == 1u) return (((qx << 6) | (qy << 3) | qz) << 15) | morton;  // direction-major
     if (variant == 4u) {
         // two points instead of a point and a direction: the origin's cell and the cell where the ray LEAVES the world box, 16^3 each,
         // interleaved level by level (3 origin bits, 3 exit bits, four times).  Rays from one cell to one cell form a thin beam whatever
         // the distance between the two, while equal direction codes fan out with it — in a closed room the exit cell is close to what the
         // ray will hit.  Round 4, trace kernel: E 2 556 -> 2 400 us (layout 3), C 316 -> 299; exit bits first inside a level 2 467, bit by
         // bit 2 437, one origin level on top 2 484, 15 + 9 or 9 + 15 bits 2 408 / 2 440 (profiles/r04/ab_sort.txt).
+        // In grid units (the box is [0, 32]^3); approximate reciprocals are good enough — the key only decides WHICH THREAD walks a ray.
+        const float og[3] = {(o.x - s.bounds_min[0]) * s.bounds_scale[0], (o.y - s.bounds_min[1]) * s.bounds_scale[1], (o.z - s.bounds_min[2]) * s.bounds_scale[2]};
+        const float dg[3] = {d.x * s.bounds_scale[0], d.y * s.bounds_scale[1], d.z * s.bounds_scale[2]};
         float t_exit = 3.0e38f;
-        const float dd[3] = {d.x, d.y, d.z}, oo[3] = {o.x, o.y, o.z};
         for (int a = 0; a < 3; ++a) {
-            if (dd[a] == 0.0f || s.bounds_scale[a] == 0.0f) continue;
-            const float lo = s.bounds_min[a], hi = lo + 32.0f / s.bounds_scale[a];
-            t_exit = fminf(t_exit, fmaxf(((dd[a] > 0.0f ? hi : lo) - oo[a]) / dd[a], 0.0f));
+            const float t = ((dg[a] > 0.0f ? 32.0f : 0.0f) - og[a]) * __builtin_amdgcn_rcpf(dg[a]);
+            t_exit = fminf(t_exit, dg[a] != 0.0f ? fmaxf(t, 0.0f) : 3.0e38f);
         }
-        if (t_exit > 1.0e37f) t_exit = 0.0f;
-        const float ex = fminf(fmaxf((o.x + d.x * t_exit - s.bounds_min[0]) * s.bounds_scale[0], 0.0f), 31.0f);
-        const float ey = fminf(fmaxf((o.y + d.y * t_exit - s.bounds_min[1]) * s.bounds_scale[1], 0.0f), 31.0f);
-        const float ez = fminf(fmaxf((o.z + d.z * t_exit - s.bounds_min[2]) * s.bounds_scale[2], 0.0f), 31.0f);
-        const uint32_t oc = spread3(uint32_t(cx) >> 1) | (spread3(uint32_t(cy) >> 1) << 1) | (spread3(uint32_t(cz) >> 1) << 2);
-        const uint32_t ec = spread3(uint32_t(ex) >> 1) | (spread3(uint32_t(ey) >> 1) << 1) | (spread3(uint32_t(ez) >> 1) << 2);
-        uint32_t key = 0u;
-        for (int b = 3; b >= 0; --b) key = (key << 6) | (((oc >> (3 * b)) & 7u) << 3) | ((ec >> (3 * b)) & 7u);
-        return key;
+        if (!(t_exit < 1.0e37f)) t_exit = 0.0f;
+        uint32_t oi[3], ei[3];
+        for (int a = 0; a < 3; ++a) {
+            oi[a] = uint32_t(fminf(fmaxf(og[a], 0.0f), 31.0f)) >> 1;
+            ei[a] = uint32_t(fminf(fmaxf(og[a] + dg[a] * t_exit, 0.0f), 31.0f)) >> 1;
+        }
+        // x, y, z of both points side by side (exit in bits 0..3, origin in 4..7: spread3 takes 8 bits), then the levels three bits apart
+        const uint32_t mx = spread3((oi[0] << 4) | ei[0]), my = spread3((oi[1] << 4) | ei[1]), mz = spread3((oi[2] << 4) | ei[2]);
+        const uint32_t both = mx | (my << 1) | (mz << 2);  // exit code in bits 0..11, origin code in bits 12..23
+        return (spread_levels(both >> 12) << 3) | spread_levels(both & 0xFFFu);
     }
+    const float cx = fminf(fmaxf((o.x - s.bounds_min[0]) * s.bounds_scale[0], 0.0f), 31.0f);
+    const float cy = fminf(fmaxf((o.y - s.bounds_min[1]) * s.bounds_scale[1], 0.0f), 31.0f);
+    const float cz = fminf(fmaxf((o.z - s.bounds_min[2]) * s.bounds_scale[2], 0.0f), 31.0f);
+    const uint32_t morton = spread3(uint32_t(cx)) | (spread3(uint32_t(cy)) << 1) | (spread3(uint32_t(cz)) << 2);
+    const float inv = __builtin_amdgcn_rcpf(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), 1.0e-30f)));  // (approximate: the key only decides which thread walks a ray)
+    const uint32_t qx = uint32_t(fminf(fmaxf(d.x * inv * 3.99f + 4.0f, 0.0f), 7.0f));
+    const uint32_t qy = uint32_t(fminf(fmaxf(d.y * inv * 3.99f + 4.0f, 0.0f), 7.0f));
+    const uint32_t qz = uint32_t(fminf(fmaxf(d.z * inv * 3.99f + 4.0f, 0.0f), 7.0f));
+    if (variant == 1u) return (((qx << 6) | (qy << 3) | qz) << 15) | morton;  // direction-major
     if (variant == 3u) {
         // the direction on the octahedron — two coordinates of 6 bits in Z-order instead of three of which one is saturated — interleaved
         // with the origin's cell in a 16^3 grid: 2 direction bits, 3 cell bits, four times, then the direction's last 4 bits.  (Round 4, config E:
