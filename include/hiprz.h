@@ -435,7 +435,7 @@ int hiprz_set_lds_scene(hiprz_ctx* ctx, int mode);
 int hiprz_set_pipeline(hiprz_ctx* ctx, int pipeline);
 int hiprz_pipeline(hiprz_ctx* ctx, int* effective_pipeline_out); /* valid after hiprz_upload_scene */
 /* Reorder rays between passes (split pipeline): the shade kernel emits a sort key per pixel (cell of the next
- * ray's origin + quantised direction), a device radix sort turns the keys into a permutation, and the trace kernel
+ * ray's origin interleaved with the cell where that ray leaves the world box), a device radix sort turns the keys into a permutation, and the trace kernel
  * walks the rays in that order so that a wave's rays visit the same nodes.  -1 = automatic (on for scenes that are
  * not staged in LDS and have many instances), 0 = off, 1 = on.  Only the assignment of rays to threads changes; results are identical. */
 int hiprz_set_ray_sort(hiprz_ctx* ctx, int mode);
