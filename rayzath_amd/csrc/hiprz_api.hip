@@ -1573,9 +1573,10 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     // C -> 299); where the deferred shadow rays follow that order too (HIPRZ_SHADOW_SORT=0) they fan out from the origin cell, so the
     // origin leads (config E: 86.5 ms per step against 92.6)
     d.sort_variant = (sc->n_spot_lights + sc->n_direct_lights) && c->shadow_sort == 0 ? 0u : 4u;
-    // the shadow rays' key: layout 0 (they fan out from the origin cell), pixels with the same set of sample slots together (+ 0x100: the
-    // shadow kernel's loop over the slots is wave-uniform, a slot few of a wave's pixels hold costs the wave a whole walk; E 40.33 -> 39.85 ms)
-    d.shadow_variant = 0x100u;
+    // the shadow rays' key: the pixel's set of sample slots (+ 0x100: the shadow kernel's loop over the slots is wave-uniform, a slot few of a
+    // wave's pixels hold costs the wave a whole walk; E 40.33 -> 39.85 ms), then the light the ray goes to and the origin's cell in a 64^3
+    // grid (+ 0x400; E 38.5 -> 37.8 ms against layout 0 — cell, then direction —, which was the best of the layouts: the rays fan out from the cell)
+    d.shadow_variant = 0x500u;
     if (const char* v = std::getenv("HIPRZ_SHADOW_KEY")) d.shadow_variant = uint32_t(std::atoi(v));
     if (const char* v = std::getenv("HIPRZ_SORT_KEY")) d.sort_variant = uint32_t(std::atoi(v));
     // The world and instance levels of the cooperative walks ("while-while" one and two levels above the mesh walk; the order in which a

@@ -102,7 +102,7 @@ struct DScene {
     // front-to-back mesh walk (hiprz_set_walk_order): 64-B records = node (32 B) + its skip link under each of the 8
     // ray-direction octants
     const float4* nodes64;
-    uint32_t shadow_variant;  // the same for the shadow rays' key (HIPRZ_SHADOW_KEY); + 0x100: the pixel's set of sample slots leads the key
+    uint32_t shadow_variant;  // the same for the shadow rays' key (HIPRZ_SHADOW_KEY); + 0x100: the pixel's set of sample slots leads the key; + 0x400: the light the ray goes to, then the origin's cell in a 64^3 grid, instead of a layout
     uint32_t sort_variant;  // ray_sort_key layout (HIPRZ_SORT_KEY): 0 origin cell then direction, 1 direction then cell, 2 interleaved, 3 octahedral direction interleaved with the cell, 4 origin cell interleaved with the cell where the ray leaves the world box
 };
 
@@ -1719,6 +1719,7 @@ struct ShadowCtx {
     mutable uint32_t defer_mask = 0u;  // bit k: sample slot k holds a shadow ray
     mutable float key_dir[3] = {0.0f, 0.0f, 0.0f};  // direction of the shadow ray in the highest slot (spot samples come last) and the
     mutable float key_o[3] = {0.0f, 0.0f, 0.0f};    // rays' common origin: what the pixel's shadow sort key is made of
+    mutable uint32_t key_light = 0u;                // ... and the light that ray goes to (spot light i: i, direct light i: 4 + i)
     mutable bool defer_done = false;   // the segment went through directIllumination
     mutable col4 defer_a{0.0f, 0.0f, 0.0f, 0.0f}, defer_b{0.0f, 0.0f, 0.0f, 0.0f};  // final += (direct * a) * b
 };
@@ -2000,13 +2001,14 @@ RZ_DEV v3 sample_direction(v3 ray_d, uint32_t& ray_material, Surface& sf, Rng& r
     return vO;
 }
 
-RZ_DEV void defer_sample(const ShadowCtx& sc, uint32_t slot, const Ray& sr, col4 term) {
+RZ_DEV void defer_sample(const ShadowCtx& sc, uint32_t slot, const Ray& sr, col4 term, uint32_t light = 0u) {
     sc.nee[4u + 2u * slot] = make_float4(sr.d.x, sr.d.y, sr.d.z, sr.far_);
     sc.nee[5u + 2u * slot] = make_float4(term.r, term.g, term.b, term.a);
     sc.nee[1] = make_float4(sr.o.x, sr.o.y, sr.o.z, 0.0f);
     if ((1u << slot) > sc.defer_mask) {
         sc.key_dir[0] = sr.d.x, sc.key_dir[1] = sr.d.y, sc.key_dir[2] = sr.d.z;
         sc.key_o[0] = sr.o.x, sc.key_o[1] = sr.o.y, sc.key_o[2] = sr.o.z;
+        sc.key_light = light;
     }
     sc.defer_mask |= 1u << slot;
 }
@@ -2054,7 +2056,7 @@ RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const Shado
             sr.o = point, sr.d = normalized(vPL), sr.near_ = 0.0f, sr.far_ = RZ_FLT_MAX;
             const col4 term = (from_u8(__float_as_uint(l1.x)) * bc) * radiance;
             if constexpr (shadow_mode_defers(MODE)) {
-                defer_sample(lds_column, i, sr, term);
+                defer_sample(lds_column, i, sr, term, 4u + li);
             } else {
                 col4 V_PL;
                 if constexpr (MODE == RZ_SHADOW_COMPAT)
@@ -2113,7 +2115,7 @@ RZ_DEV col4 direct_illumination(const DScene& s, const DConfig& cfg, const Shado
             sr.o = point, sr.d = normalized(vPL), sr.near_ = 0.0f, sr.far_ = dPL;
             const col4 term = (from_u8(__float_as_uint(l2.x)) * bc) * radiance;
             if constexpr (shadow_mode_defers(MODE)) {
-                defer_sample(lds_column, cfg.direct_samples + i, sr, term);
+                defer_sample(lds_column, cfg.direct_samples + i, sr, term, li);
             } else {
                 col4 V_PL;
                 if constexpr (MODE == RZ_SHADOW_COMPAT)
