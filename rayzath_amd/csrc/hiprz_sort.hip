@@ -1,6 +1,7 @@
 // hiprz_sort.hip — ray reordering between passes, hand-written (no library kernels on the path).
 //
-// The shade kernel leaves a 24-bit key per pixel (cell of the next ray's origin + its direction, hiprz_device.hpp: ray_sort_key); a
+// The shade kernel leaves a 24-bit key per pixel (the cell of the next ray's origin interleaved with the cell where it leaves the world box,
+// hiprz_device.hpp: ray_sort_key); a
 // least-significant-digit radix sort over the key bits that matter (16 or 24, 8 bits per pass) turns the keys into the permutation the
 // next trace kernel follows.  The deferred shadow rays get a permutation from their own keys the same way.
 // (Gathering the rays themselves into sorted order — a contiguous 32-byte-per-ray stream for the trace kernel — was measured and
