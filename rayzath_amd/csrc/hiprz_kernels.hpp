@@ -516,6 +516,25 @@ __global__ void __launch_bounds__(64, MINW) rz_trace_coop_kernel(const DScene s,
     flush_counters<COUNT>(f, 0u, cnt);
 }
 
+// rz_trace_coop_kernel with the wave-level walk (hiprz_device.hpp: closest_hit_packet): rays in sorted order — one origin cell, one cell
+// where they leave the world box — and the camera rays of an 8 x 8 block reach the kernel as beams.  No LDS.
+template <bool FIRST, bool COUNT, int MINW>
+__global__ void __launch_bounds__(64, MINW) rz_trace_packet_kernel(const DScene s, const DCamera cam, const DFrame f) {
+    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+    Counters cnt;
+    Ray ray;
+    const PixelId p = trace_ray_of_slot<FIRST>(f, cam, slot, ray);
+    Hit hit;
+    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
+    int found = 0;
+    if (s.n_instances != 0u) found = closest_hit_packet<COUNT, RZ_TRACE_SHARED_RCP != 0>(s, p.active, ray, hit, cnt);
+    if (p.active) {
+        f.hit0[p.local] = make_float4(ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
+        f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
+    }
+    flush_counters<COUNT>(f, 0u, cnt);
+}
+
 // The same walk for the CUDA-compat integrator (hiprz_set_mode): with HIPRZ_COMPAT_SCATTERING the medium the ray travels in may end the
 // segment before any surface does (Material::applyScattering, cuda_material.cuh:141-159) — the distance is the FIRST draw of the
 // segment's random stream (cuda_world.cuh:91-100), taken here as the walk's range and taken again by the shade kernel.
@@ -719,6 +738,64 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_coop_kernel(const DScene s
     flush_counters<COUNT>(f, 0u, cnt);
 }
 
+
+// rz_shadow_coop_kernel with the wave-level walk (hiprz_device.hpp: any_hit_packet): the shadow rays' sorted order hands a wave 64 rays
+// from one cell towards one light.  Sums, order and accumulation are those of rz_shadow_kernel; no LDS.
+template <bool FIRST, bool COUNT, int MINW>
+__global__ void __launch_bounds__(64, MINW) rz_shadow_packet_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f) {
+    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
+    const uint32_t* order = f.shadow_perm ? f.shadow_perm : f.perm;
+    const PixelId p = pixel_of_local(f, cam, order ? order[slot] : slot);
+    Counters cnt;
+    float4 base = make_float4(0.0f, 0.0f, 0.0f, 0.0f), o = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint32_t bits = 0u;
+    const float4* rec = f.nee + size_t(p.local) * f.nee_quads;
+    if (p.active) {
+        base = rec[0];
+        bits = __float_as_uint(base.w);
+        if (bits & 2u) o = rec[1];
+    }
+    const uint32_t mask = (bits & 2u) ? bits >> 2 : 0u;
+    col4 direct_total = splat(0.0f), spot_total = splat(0.0f);
+    const uint32_t n_samples = cfg.direct_samples + cfg.spot_samples;
+    for (uint32_t k = 0u; k < n_samples; ++k) {  // wave-uniform
+        const bool has = (mask & (1u << k)) != 0u;
+        if (!__any(has)) continue;
+        float4 d = make_float4(0.0f, 0.0f, 1.0f, 0.0f), t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (has) d = rec[4u + 2u * k], t = rec[5u + 2u * k];
+        Ray sr;
+        sr.o = V3(o.x, o.y, o.z), sr.d = V3(d.x, d.y, d.z), sr.near_ = 0.0f, sr.far_ = d.w;
+        col4 V_PL = splat(0.0f);
+        if (s.n_instances != 0u) V_PL = splat(any_hit_packet<COUNT, RZ_SHADE_SHARED_RCP != 0>(s, has, sr, cnt));
+        else if (has) { RZ_COUNT(shadow_rays); }
+        if (has) {
+            const col4 term = (col4{t.x, t.y, t.z, t.w} * V_PL) * V_PL.a;
+            if (k < cfg.direct_samples) direct_total = direct_total + term;
+            else spot_total = spot_total + term;
+        }
+    }
+    if (p.active) {
+        const bool path_continues = (bits & 1u) != 0u;
+        col4 final_color{base.x, base.y, base.z, 0.0f};
+        if (bits & 2u) {
+            col4 dt = splat(0.0f), st = splat(0.0f);
+            if (s.n_direct_lights != 0u) dt = div_scalar(direct_total, float(cfg.direct_samples) / float(s.n_direct_lights));
+            if (s.n_spot_lights != 0u) st = div_scalar(spot_total, float(cfg.spot_samples) / float(s.n_spot_lights));
+            const col4 direct = dt + st;
+            const float4 a = rec[2], b = rec[3];
+            final_color = final_color + (direct * col4{a.x, a.y, a.z, a.w}) * col4{b.x, b.y, b.z, b.w};
+        }
+        col4 value;
+        if constexpr (FIRST) {
+            value = col4{final_color.r, final_color.g, final_color.b, float(!path_continues)};
+        } else {
+            const float4 acc = f.accum[p.local];
+            value = col4{acc.x + final_color.r, acc.y + final_color.g, acc.z + final_color.b, acc.w + float(!path_continues)};
+        }
+        f.accum[p.local] = make_float4(value.r, value.g, value.b, value.a);
+    }
+    flush_counters<COUNT>(f, 0u, cnt);
+}
 
 // ---- CUDA-compat mode (hiprz_set_mode, hiprz_compat.hpp): one fused kernel per pass, scene in global memory ----
 // Order of the random draws as in the CUDA engine: the medium's scattering distance first (cuda_material.cuh:146-148), then

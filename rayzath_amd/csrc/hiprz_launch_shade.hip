@@ -16,6 +16,16 @@ void sort_after_shading(hiprz_ctx* c, const DFrame& f) {
     if (f.shadow_key) launch_shadow_sort(c);
 }
 
+// The deferred shadow rays in their own sorted order (slot set, light, origin cell) reach the kernel as BEAMS — 64 rays from one cell towards
+// one light — and the wave walks the trees for all of them at once (rz_shadow_packet_kernel; round 4, config E: shadow kernel 1 449 ->
+// about 1 160 us, step 37.5 -> 35.2 ms, identical frames).  Not for counted passes (the work counters are anchored on the per-lane walks)
+// and not where the shadow rays follow the next pass's ray order (HIPRZ_SHADOW_SORT=0: no beams).  HIPRZ_SHADOW_PACKET=0: the cooperative walk.
+template <bool COUNT>
+bool shadow_beams(const hiprz_ctx* c, const DFrame& f) {
+    static const bool enabled = [] { const char* e = std::getenv("HIPRZ_SHADOW_PACKET"); return !e || std::atoi(e) != 0; }();
+    return !COUNT && enabled && f.shadow_key != nullptr;
+}
+
 template <bool FIRST, bool COUNT>
 void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
     const PassGeometry g = pass_geometry(c);
@@ -30,6 +40,8 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
             sort_after_shading(c, f);
             if (c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR)  // coloured masks: the same kernel, its rays go through what they cross and collect the opacity colours
                 RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 3, true>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
+            else if (shadow_beams<COUNT>(c, f))
+                RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), 0, c->stream, c->dscene, c->dcamera, cfg, f);
             else
                 RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
             join_sort(c);
@@ -51,7 +63,9 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
         RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
         sort_after_shading(c, f);
         const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
-        if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) || c->scene_tree != HIPRZ_TREE_REFERENCE) {
+        if (shadow_beams<COUNT>(c, f)) {
+            RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, 4>), sgrid, sblock, 0, c->stream, c->dscene, c->dcamera, cfg, f);
+        } else if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) || c->scene_tree != HIPRZ_TREE_REFERENCE) {
             RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 4>), sgrid, sblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
         } else {
             const bool big_trees = c->trace_waves > 0 ? c->trace_waves >= 6 : c->n_nodes > kLatencyBoundNodes;
