@@ -1780,128 +1780,6 @@ RZ_DEV float any_hit_packet(const DScene& s, bool active, const Ray& ray, Counte
     return occluded ? 0.0f : 1.0f;
 }
 
-// The closest-hit walk for a wave whose 64 rays form a beam (rays in sorted order: one origin cell, one cell where they leave the world box;
-// camera rays of an 8 x 8 block): the wave walks the trees as in any_hit_packet.  The world tree in the reference's order (the order in
-// which a ray meets its instances is part of its arithmetic); a mesh front to back for the octant of the wave's first entering lane — every
-// lane gets the hits of a per-lane walk in that order: a lane tests a box against the range it holds at that moment, sits out a subtree
-// whose box it misses, tests a leaf's triangles one by one in leaf order, and among equal distances the triangle the reference meets
-// first wins (tri_hit_ordered on the reference positions), so the order only decides how early the range shrinks.
-template <bool COUNT, bool RCP>
-RZ_DEV int closest_hit_packet(const DScene& s, bool active, Ray& ray, Hit& hit, Counters& cnt) {
-    const bool scene_fast = s.fast_div != 0u;
-    WalkRay g;
-    g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
-    prepare<RCP>(g, scene_fast);
-    bool live = active, root_missed = false, wblocked = false;
-    uint32_t wresume = 0u, guard = 0u;
-    uint32_t n = s.tlas_root;
-    while (n != RZ_END && __any(live)) {  // wave-uniform
-        RZ_GUARD(guard);
-        if (wblocked && wresume == n) wblocked = false;
-        float4 n0, n1;
-        uint32_t link;
-        fetch_node_ordered(s, n, 0u, n0, n1, link);
-        link = uint32_t(__builtin_amdgcn_readfirstlane(int(link)));
-        bool hit_box = false;
-        if (live && !wblocked) {
-            RZ_PHASE(0);
-            RZ_COUNT(box_tests);
-            hit_box = box_hit_unpacked<RCP>(n0, n1, g);
-            if (!hit_box) {
-                if (n == s.tlas_root) root_missed = true, live = false;  // root box missed (cpu_engine_kernel.cpp:283)
-                wblocked = true, wresume = link;
-            }
-        }
-        if (!__any(hit_box)) {
-            n = link;
-            continue;
-        }
-        const uint32_t begin = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(n1.z)))), meta = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(n1.w))));
-        if (!(meta & HIPRZ_NODE_LEAF)) {
-            n = begin;
-            continue;
-        }
-        const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
-        for (uint32_t i = begin; i < end; ++i) {  // the leaf's instances, in the reference's order
-            const uint32_t inst = uint32_t(__builtin_amdgcn_readfirstlane(int(s.tlas_order[i])));
-            float4 ib0, ib1;
-            load_instance_box(s, inst, ib0, ib1);
-            bool enter = false;
-            if (hit_box) {
-                RZ_PHASE(1);
-                RZ_COUNT(box_tests);
-                enter = box_hit_unpacked<RCP>(ib0, ib1, g);
-            }
-            const unsigned long long entering = __ballot(enter);
-            if (entering == 0ull) continue;
-            const InstanceXform x = load_instance_xform(s, inst);
-            WalkRay lr;
-            lr.o = lr.d = lr.y = V3(0.0f, 0.0f, 0.0f), lr.near_ = lr.far_ = 0.0f, lr.fast = true;
-            float len = 1.0f;
-            if (enter) {
-                RZ_PHASE(2);
-                len = to_local<RCP>(x, g, lr, scene_fast);
-            }
-            // the mesh front to back as the wave's first entering lane sees it
-            const uint32_t oct = uint32_t(__builtin_amdgcn_readlane(int(octant_of(lr.d)), int(__builtin_ctzll(entering))));
-            bool found = false, mblocked = false;
-            uint32_t held_ref = 0u, mresume = 0u;
-            uint32_t m = uint32_t(__builtin_amdgcn_readfirstlane(int(x.blas_root)));
-            while (m != RZ_END) {  // wave-uniform
-                RZ_GUARD(guard);
-                if (mblocked && mresume == m) mblocked = false;
-                float4 m0, m1;
-                uint32_t mlink;
-                fetch_node_ordered(s, m, oct, m0, m1, mlink);
-                mlink = uint32_t(__builtin_amdgcn_readfirstlane(int(mlink)));
-                bool mhit = false;
-                if (enter && !mblocked) {
-                    RZ_PHASE(3);
-                    RZ_COUNT(box_tests);
-                    mhit = box_hit_filtered<RCP>(m0, m1, lr);
-                    if (!mhit) mblocked = true, mresume = mlink;
-                }
-                if (!__any(mhit)) {
-                    m = mlink;
-                    continue;
-                }
-                const uint32_t mbegin = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(m1.z)))), mmeta = uint32_t(__builtin_amdgcn_readfirstlane(int(__float_as_uint(m1.w))));
-                if (!(mmeta & HIPRZ_NODE_LEAF)) {
-                    m = mbegin + ((oct >> (mmeta >> HIPRZ_NODE_PTYPE_SHIFT)) & 1u);  // the nearer child first
-                    continue;
-                }
-                const uint32_t tend = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
-                for (uint32_t tj = mbegin; tj < tend; ++tj) {
-                    const float4 ta = s.tris[3 * tj], tb = s.tris[3 * tj + 1], tc = s.tris[3 * tj + 2];
-                    if (mhit) {
-                        float t, b1, b2, det;
-                        RZ_PHASE(4);
-                        RZ_COUNT(tri_tests);
-                        const uint32_t refpos = __float_as_uint(tc.w);
-                        if (tri_hit_ordered(xyz(ta), xyz(tb), xyz(tc), lr, found && refpos < held_ref, t, b1, b2, det)) {
-                            lr.far_ = t;
-                            hit.triangle = tj;
-                            hit.external = det > 0.0f;
-                            hit.bx = b1, hit.by = b2;
-                            found = true, held_ref = refpos;
-                        }
-                    }
-                }
-                m = mlink;
-            }
-            if (found) {
-                hit.instance = int32_t(inst);
-                g.near_ = lr.near_ / len;
-                g.far_ = lr.far_ / len;
-            }
-        }
-        n = link;
-    }
-    ray.near_ = g.near_, ray.far_ = g.far_;
-    if (!active || root_missed) return 0;
-    return hit.instance >= 0 ? 2 : 1;
-}
-
 template <int MODE, bool COUNT, bool RCP>
 RZ_DEV int closest_hit(const DScene& s, uint32_t* lds_column, Ray& ray, Hit& hit, Counters& cnt) {
     hit.instance = -1;

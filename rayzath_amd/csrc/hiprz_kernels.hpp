@@ -516,25 +516,6 @@ __global__ void __launch_bounds__(64, MINW) rz_trace_coop_kernel(const DScene s,
     flush_counters<COUNT>(f, 0u, cnt);
 }
 
-// rz_trace_coop_kernel with the wave-level walk (hiprz_device.hpp: closest_hit_packet): rays in sorted order — one origin cell, one cell
-// where they leave the world box — and the camera rays of an 8 x 8 block reach the kernel as beams.  No LDS.
-template <bool FIRST, bool COUNT, int MINW>
-__global__ void __launch_bounds__(64, MINW) rz_trace_packet_kernel(const DScene s, const DCamera cam, const DFrame f) {
-    const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
-    Counters cnt;
-    Ray ray;
-    const PixelId p = trace_ray_of_slot<FIRST>(f, cam, slot, ray);
-    Hit hit;
-    hit.instance = -1, hit.triangle = 0u, hit.bx = hit.by = 0.0f, hit.external = true;
-    int found = 0;
-    if (s.n_instances != 0u) found = closest_hit_packet<COUNT, RZ_TRACE_SHARED_RCP != 0>(s, p.active, ray, hit, cnt);
-    if (p.active) {
-        f.hit0[p.local] = make_float4(ray.far_, hit.bx, hit.by, __uint_as_float(hit.triangle));
-        f.hit1[p.local] = (uint32_t(hit.instance) & 0x1FFFFFFFu) | (uint32_t(found) << 29) | (hit.external ? 0x80000000u : 0u);
-    }
-    flush_counters<COUNT>(f, 0u, cnt);
-}
-
 // The same walk for the CUDA-compat integrator (hiprz_set_mode): with HIPRZ_COMPAT_SCATTERING the medium the ray travels in may end the
 // segment before any surface does (Material::applyScattering, cuda_material.cuh:141-159) — the distance is the FIRST draw of the
 // segment's random stream (cuda_world.cuh:91-100), taken here as the walk's range and taken again by the shade kernel.

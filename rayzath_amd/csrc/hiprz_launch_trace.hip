@@ -23,12 +23,6 @@ void launch_trace_t(hiprz_ctx* c, const DFrame& f) {
             // fetches and take a fifth wave at the price of 52 B of scratch (D: 1 014 -> 964 us; C 342 -> 351, E 3 082 -> 3 279 us)
             const int waves = c->trace_waves > 0 ? c->trace_waves : (c->n_nodes > kLatencyBoundNodes ? 5 : 4);
             const bool one_leaf_world = c->dscene.n_instances != 0u && c->flat_world;  // (the general world level costs D's 5-wave build 3.5 %, C's 4-wave build 0.5 %)
-            static const int packet = [] { const char* e = std::getenv("HIPRZ_TRACE_PACKET"); return e ? std::atoi(e) : 0; }();
-            if (packet && !COUNT && (FIRST || f.perm)) {  // experiment: the wave-level walk for rays that come as beams
-                if (packet >= 6) RZ_LAUNCH((rz_trace_packet_kernel<FIRST, COUNT, 6>), grid, block, 0, c->stream, c->dscene, c->dcamera, f);
-                else RZ_LAUNCH((rz_trace_packet_kernel<FIRST, COUNT, 4>), grid, block, 0, c->stream, c->dscene, c->dcamera, f);
-                return;
-            }
             if (waves == 5 && one_leaf_world) RZ_LAUNCH((rz_trace_coop_kernel<FIRST, COUNT, 5, true>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
             else if (waves == 5) RZ_LAUNCH((rz_trace_coop_kernel<FIRST, COUNT, 5>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
             else if (waves >= 6) RZ_LAUNCH((rz_trace_coop_kernel<FIRST, COUNT, 6>), grid, block, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, f);
