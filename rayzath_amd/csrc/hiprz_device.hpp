@@ -1685,11 +1685,11 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
 // loads, the box in scalar registers); every lane that is still undecided and has passed all of the node's ancestors tests the box
 // against its own ray; the wave enters the node if any lane does, and a lane that misses it sits out until the walk reaches the node's skip
 // link — the next node outside the subtree — so a lane tests exactly the boxes and triangles the per-lane walk in that order tests for its
-// ray: the same verdicts (a shadow ray's range is fixed, the answer does not depend on the order or on other rays).  No stack, no LDS, no
-// divergence: loops and branches are wave-uniform, lanes only differ in predicates.  What it costs is the UNION of the lanes' walks —
+// ray: the same verdicts (a shadow ray's range is fixed, the answer does not depend on the order or on other rays).  No stack, no
+// divergence: loops and branches are wave-uniform, lanes only differ in predicates; 2 KiB of LDS per wave (`rays`: [2][64] f4) for the triangle phase.  What it costs is the UNION of the lanes' walks —
 // close to one lane's walk for a beam, far more for rays that have nothing in common.
 template <bool COUNT, bool RCP>
-RZ_DEV float any_hit_packet(const DScene& s, bool active, const Ray& ray, Counters& cnt) {
+RZ_DEV float any_hit_packet(const DScene& s, RZ_LDS f4* rays, bool active, const Ray& ray, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
@@ -1707,6 +1707,7 @@ RZ_DEV float any_hit_packet(const DScene& s, bool active, const Ray& ray, Counte
         link = uint32_t(__builtin_amdgcn_readfirstlane(int(link)));
         bool hit = false;
         if (live && !wblocked) {
+            RZ_PHASE(0);
             RZ_COUNT(box_tests);
             RZ_COUNT(shadow_box_tests);
             hit = box_hit_unpacked<RCP>(n0, n1, g);
@@ -1728,6 +1729,7 @@ RZ_DEV float any_hit_packet(const DScene& s, bool active, const Ray& ray, Counte
             load_instance_box(s, inst, ib0, ib1);
             bool enter = false;
             if (live && hit) {
+                RZ_PHASE(1);
                 RZ_COUNT(box_tests);
                 RZ_COUNT(shadow_box_tests);
                 enter = box_hit_unpacked<RCP>(ib0, ib1, g);
@@ -1736,7 +1738,10 @@ RZ_DEV float any_hit_packet(const DScene& s, bool active, const Ray& ray, Counte
             const InstanceXform x = load_instance_xform(s, inst);
             WalkRay lr;
             lr.o = lr.d = lr.y = V3(0.0f, 0.0f, 0.0f), lr.near_ = lr.far_ = 0.0f, lr.fast = true;
-            if (enter) to_local<RCP>(x, g, lr, scene_fast);
+            if (enter) {
+                RZ_PHASE(2);
+                to_local<RCP>(x, g, lr, scene_fast);
+            }
             uint32_t m = uint32_t(__builtin_amdgcn_readfirstlane(int(x.blas_root))), mresume = 0u;
             bool mblocked = false;
             while (m != RZ_END && __any(enter && live)) {  // wave-uniform
@@ -1748,6 +1753,7 @@ RZ_DEV float any_hit_packet(const DScene& s, bool active, const Ray& ray, Counte
                 mlink = uint32_t(__builtin_amdgcn_readfirstlane(int(mlink)));
                 bool mhit = false;
                 if (enter && live && !mblocked) {
+                    RZ_PHASE(3);
                     RZ_COUNT(box_tests);
                     RZ_COUNT(shadow_box_tests);
                     mhit = box_hit_filtered<RCP>(m0, m1, lr);
@@ -1762,16 +1768,42 @@ RZ_DEV float any_hit_packet(const DScene& s, bool active, const Ray& ray, Counte
                     m = mbegin;  // (the order of octant 0: the lower child first)
                     continue;
                 }
-                const uint32_t tend = mbegin + (mmeta & HIPRZ_NODE_COUNT_MASK);
-                for (uint32_t tj = mbegin; tj < tend; ++tj) {
-                    const float4 ta = s.tris[3 * tj], tb = s.tris[3 * tj + 1], tc = s.tris[3 * tj + 2];
-                    if (mhit && live) {
+                // The leaf's triangles: (ray, triangle) pairs dealt over all 64 lanes.  The lanes that passed the leaf's box put their mesh-space
+                // rays into LDS by rank; lane q of a step tests triangle q mod c for the ray of rank q div c; a ballot brings the verdicts
+                // back, and a ray is occluded if any of its c testers hit.  (One triangle at a time for the lanes of the leaf ran at 15 lanes.)
+                const uint32_t c = mmeta & HIPRZ_NODE_COUNT_MASK;
+                const bool owner = mhit && live;
+                const unsigned long long owners = __ballot(owner);
+                const uint32_t pairs = uint32_t(__popcll(owners)) * c, r = rank_in(owners);
+                if (owner) {
+                    RZ_PHASE(4);
+                    rays[r] = F4(lr.o.x, lr.o.y, lr.o.z, lr.near_), rays[64u + r] = F4(lr.d.x, lr.d.y, lr.d.z, lr.far_);
+                }
+                rz_wave_sync();
+                const float rcp_c = __builtin_amdgcn_rcpf(float(c));
+                const uint32_t lane = lane_id();
+                for (uint32_t base = 0u; base < pairs; base += 64u) {  // wave-uniform
+                    const uint32_t q = base + lane;
+                    bool pair_hit = false;
+                    if (q < pairs) {
+                        const uint32_t of = uint32_t((float(q) + 0.5f) * rcp_c), tri = mbegin + (q - of * c);  // q div c, q mod c (exact: c < 64, q < 4096)
+                        const f4 r0 = rays[of], r1 = rays[64u + of];
+                        WalkRay hr;
+                        hr.o = V3(r0.x, r0.y, r0.z), hr.d = V3(r1.x, r1.y, r1.z), hr.near_ = r0.w, hr.far_ = r1.w;
+                        const float4 ta = s.tris[3 * tri], tb = s.tris[3 * tri + 1], tc = s.tris[3 * tri + 2];
                         float t, b1, b2, det;
                         RZ_COUNT(tri_tests);
                         RZ_COUNT(shadow_tri_tests);
-                        if (tri_hit(xyz(ta), xyz(tb), xyz(tc), lr, t, b1, b2, det)) live = false, occluded = true;  // (:465: any hit occludes)
+                        pair_hit = tri_hit(xyz(ta), xyz(tb), xyz(tc), hr, t, b1, b2, det);
+                    }
+                    const unsigned long long verdicts = __ballot(pair_hit);
+                    if (owner) {  // my testers are pairs r * c .. r * c + c - 1; those of this step sit in bits first - base .. of `verdicts`
+                        const uint32_t first = r * c, last = first + c;
+                        const uint32_t lo = first > base ? first - base : 0u, hi = last < base + 64u ? (last > base ? last - base : 0u) : 64u;
+                        if (lo < hi && ((verdicts >> lo) & (hi - lo >= 64u ? ~0ull : ((1ull << (hi - lo)) - 1ull))) != 0ull) live = false, occluded = true;  // (:465: any hit occludes)
                     }
                 }
+                rz_wave_sync();
                 m = mlink;
             }
         }

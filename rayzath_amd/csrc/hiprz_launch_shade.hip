@@ -41,7 +41,7 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
             if (c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR)  // coloured masks: the same kernel, its rays go through what they cross and collect the opacity colours
                 RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 3, true>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
             else if (shadow_beams<COUNT>(c, f))
-                RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), 0, c->stream, c->dscene, c->dcamera, cfg, f);
+                RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), 2048, c->stream, c->dscene, c->dcamera, cfg, f);
             else
                 RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
             join_sort(c);
@@ -64,7 +64,7 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
         sort_after_shading(c, f);
         const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
         if (shadow_beams<COUNT>(c, f)) {
-            RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, 4>), sgrid, sblock, 0, c->stream, c->dscene, c->dcamera, cfg, f);
+            RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, 4>), sgrid, sblock, 2048, c->stream, c->dscene, c->dcamera, cfg, f);
         } else if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) || c->scene_tree != HIPRZ_TREE_REFERENCE) {
             RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 4>), sgrid, sblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
         } else {
@@ -88,3 +88,12 @@ void launch_shade(hiprz_ctx* c, const DFrame& f, bool first, bool counted) {
 }
 
 }  // namespace hiprz
+
+#ifdef RZ_PHASE_STATS  // diagnostic build (tools/phase_stats.py): wave-level executions / active lanes of the shadow rays' wave-level walk
+extern "C" int hiprz_read_shadow_phase_stats(unsigned long long out[16]) {
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(hiprz::rz_phase), 128);
+    unsigned long long zero[16] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(hiprz::rz_phase), zero, 128);
+    return 0;
+}
+#endif

@@ -25,4 +25,10 @@ for cfgname in sys.argv[1:] or ["D"]:
     for k, name in enumerate(NAMES):
         n, lanes = out[2 * k], out[2 * k + 1]
         print(f"  {name:28s} wave executions {n:12d} ({n / waves:8.1f} per wave)  lanes {lanes:13d}  mean active lanes {lanes / max(n, 1):5.1f}")
+    if hasattr(ctx.lib, "hiprz_read_shadow_phase_stats") and os.environ.get("PHASE_SHADOW"):   # library built with -DRZ_PHASE_STATS in the shade unit too
+        ctx.lib.hiprz_read_shadow_phase_stats(out); ctx.render(1); ctx.sync(); ctx.lib.hiprz_read_shadow_phase_stats(out)
+        print("  shadow rays, wave-level walk (any_hit_packet):")
+        for k, name in enumerate(NAMES[:5]):
+            n, lanes = out[2 * k], out[2 * k + 1]
+            print(f"  {name:28s} wave executions {n:12d} ({n / waves:8.1f} per wave)  lanes {lanes:13d}  mean active lanes {lanes / max(n, 1):5.1f}")
     ctx.close()
