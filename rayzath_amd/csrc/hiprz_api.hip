@@ -711,7 +711,7 @@ std::vector<unsigned char> graph_key_of(hiprz_ctx* c, const DFrame& f, uint32_t 
         const void* ptrs[5] = {t.keys_out.ptr, t.vals_a.ptr, t.vals_b.ptr, t.counts.ptr, t.row_total.ptr};
         put(ptrs, sizeof ptrs);
     }
-    const int settings[] = {c->pipeline, effective_mode(c), c->walk_order, c->trace_waves, int(c->scene_tree), effective_sort_bits(c), int(defer_shadows(c)),
+    const int settings[] = {c->pipeline, effective_mode(c), c->walk_order, c->trace_waves, int(c->scene_tree), effective_sort_bits(c), int(defer_shadows(c)), int(c->shadow_packet),
                             int(use_lds_scene(c)), int(c->flat_world), c->nolight_kernels, int(c->n_textures), int(c->n_nodes), int(c->xcd_swizzle),
                             int(sort_enabled(c)), c->shadow_sort, c->batch_waves, int(c->stack_entries), int(n_passes), int(c->n_local_tiles)};
     put(settings, sizeof settings);
@@ -1198,6 +1198,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     if (const char* w = std::getenv("HIPRZ_BATCH_WAVES")) c->batch_waves = std::atoi(w);
     if (const char* w = std::getenv("HIPRZ_NOLIGHT_KERNELS")) c->nolight_kernels = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SORT_BITS")) c->sort_bits = std::min(24, std::max(0, std::atoi(w)));
+    if (const char* w = std::getenv("HIPRZ_SHADOW_PACKET")) c->shadow_packet = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SHADOW_SORT")) c->shadow_sort = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_WAVE_RESIDENT_MAX")) c->wave_resident_max = uint32_t(std::max(0, std::atoi(w)));
     c->device = device_id;

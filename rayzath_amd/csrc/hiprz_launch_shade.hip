@@ -22,8 +22,7 @@ void sort_after_shading(hiprz_ctx* c, const DFrame& f) {
 // and not where the shadow rays follow the next pass's ray order (HIPRZ_SHADOW_SORT=0: no beams).  HIPRZ_SHADOW_PACKET=0: the cooperative walk.
 template <bool COUNT>
 bool shadow_beams(const hiprz_ctx* c, const DFrame& f) {
-    static const bool enabled = [] { const char* e = std::getenv("HIPRZ_SHADOW_PACKET"); return !e || std::atoi(e) != 0; }();
-    return !COUNT && enabled && f.shadow_key != nullptr;
+    return !COUNT && c->shadow_packet && f.shadow_key != nullptr;
 }
 
 template <bool FIRST, bool COUNT>

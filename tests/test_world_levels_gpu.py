@@ -29,7 +29,7 @@ def _world(n_instances, lights, seed):
 
 
 def _frames(flat, cam, cfg, monkeypatch, env=None, **settings):
-    for k in ("HIPRZ_WORLD_ADVANCE", "HIPRZ_WALK_ADVANCE"):
+    for k in ("HIPRZ_WORLD_ADVANCE", "HIPRZ_WALK_ADVANCE", "HIPRZ_SHADOW_PACKET"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
@@ -58,6 +58,9 @@ def test_walk_levels_over_world_trees_of_many_shapes(built, monkeypatch, n_insta
                            "host SAH trees": dict(tree=1), "device trees, Morton order": dict(tree=2), "device SAH trees": dict(tree=3),
                            "the hosts' default trees": dict(tree=4)}.items():
         _same(reference, _frames(flat, cam, cfg, monkeypatch, **settings), name)
+    if lights:       # the shadow rays walked lane by lane (cooperative walk) instead of by the wave (rz_shadow_packet_kernel, the default)
+        for tree in (0, 3):
+            _same(reference, _frames(flat, cam, cfg, monkeypatch, env={"HIPRZ_SHADOW_PACKET": "0"}, pipeline=1, lds_scene=0, tree=tree), f"cooperative shadow walk, tree {tree}")
     if not lights:   # the per-wave resident kernel (scenes without lights)
         _same(reference, _frames(flat, cam, cfg, monkeypatch, pipeline=2, lds_scene=0, tree=3), "per-wave resident kernel")
     for world_advance, walk_advance in (("0", "0"), ("1", "3"), ("64", "64")):
