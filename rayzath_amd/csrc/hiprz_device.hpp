@@ -1786,7 +1786,8 @@ RZ_DEV float any_hit_packet(const DScene& s, RZ_LDS f4* rays, bool active, const
                     const uint32_t q = base + lane;
                     bool pair_hit = false;
                     if (q < pairs) {
-                        const uint32_t of = uint32_t((float(q) + 0.5f) * rcp_c), tri = mbegin + (q - of * c);  // q div c, q mod c (exact: c < 64, q < 4096)
+                        // q div c, q mod c: by reciprocal where that is exact beyond doubt ((q + 0.5) / c is at least 0.5 / c away from an integer)
+                        const uint32_t of = c <= 256u ? uint32_t((float(q) + 0.5f) * rcp_c) : q / c, tri = mbegin + (q - of * c);
                         const f4 r0 = rays[of], r1 = rays[64u + of];
                         WalkRay hr;
                         hr.o = V3(r0.x, r0.y, r0.z), hr.d = V3(r1.x, r1.y, r1.z), hr.near_ = r0.w, hr.far_ = r1.w;
