@@ -1686,15 +1686,20 @@ RZ_DEV float any_hit_coop(const DScene& s, const CoopLds& lds, bool active, cons
 // against its own ray; the wave enters the node if any lane does, and a lane that misses it sits out until the walk reaches the node's skip
 // link — the next node outside the subtree — so a lane tests exactly the boxes and triangles the per-lane walk in that order tests for its
 // ray: the same verdicts (a shadow ray's range is fixed, the answer does not depend on the order or on other rays).  No stack, no
-// divergence: loops and branches are wave-uniform, lanes only differ in predicates; 2 KiB of LDS per wave (`rays`: [2][64] f4) for the triangle phase.  What it costs is the UNION of the lanes' walks —
+// divergence: loops and branches are wave-uniform, lanes only differ in predicates; 2 KiB of LDS per wave (`rays`: [2][64] f4; MASK: 3 KiB) for the triangle phase.  What it costs is the UNION of the lanes' walks —
 // close to one lane's walk for a beam, far more for rays that have nothing in common.
-template <bool COUNT, bool RCP>
-RZ_DEV float any_hit_packet(const DScene& s, RZ_LDS f4* rays, bool active, const Ray& ray, Counters& cnt) {
+// MASK (HIPRZ_COMPAT_SHADOW_COLOR): the ray goes THROUGH the triangles it crosses and the result is the product of their opacity colours, as in
+// any_hit_coop_mask; a tester that hits leaves its triangle's colour in LDS (`rays` + 128: one f4 per pair of a step), the ray's lane multiplies its
+// pairs' colours in leaf order and stops below alpha 1e-4.  The factors are those of the other walks, their order is this walk's: products agree
+// to rounding.
+template <bool COUNT, bool RCP, bool MASK = false>
+RZ_DEV col4 any_hit_packet(const DScene& s, RZ_LDS f4* rays, bool active, const Ray& ray, bool filtering, Counters& cnt) {
     const bool scene_fast = s.fast_div != 0u;
     WalkRay g;
     g.o = ray.o, g.d = ray.d, g.near_ = ray.near_, g.far_ = ray.far_;
     prepare<RCP>(g, scene_fast);
     bool live = active, occluded = false, wblocked = false;
+    col4 shadow = splat(1.0f);  // (MASK)
     uint32_t wresume = 0u, guard = 0u;
     if (active) { RZ_COUNT(shadow_rays); }
     uint32_t n = s.tlas_root;
@@ -1796,13 +1801,30 @@ RZ_DEV float any_hit_packet(const DScene& s, RZ_LDS f4* rays, bool active, const
                         RZ_COUNT(tri_tests);
                         RZ_COUNT(shadow_tri_tests);
                         pair_hit = tri_hit(xyz(ta), xyz(tb), xyz(tc), hr, t, b1, b2, det);
+                        if constexpr (MASK) {
+                            if (pair_hit) {
+                                const col4 crossing = compat_crossing_color<COUNT>(s, inst, tri, __float_as_uint(ta.w), b1, b2, filtering, cnt);
+                                rays[128u + lane] = F4(crossing.r, crossing.g, crossing.b, crossing.a);
+                            }
+                        }
                     }
+                    if constexpr (MASK) rz_wave_sync();
                     const unsigned long long verdicts = __ballot(pair_hit);
                     if (owner) {  // my testers are pairs r * c .. r * c + c - 1; those of this step sit in bits first - base .. of `verdicts`
                         const uint32_t first = r * c, last = first + c;
                         const uint32_t lo = first > base ? first - base : 0u, hi = last < base + 64u ? (last > base ? last - base : 0u) : 64u;
-                        if (lo < hi && ((verdicts >> lo) & (hi - lo >= 64u ? ~0ull : ((1ull << (hi - lo)) - 1ull))) != 0ull) live = false, occluded = true;  // (:465: any hit occludes)
+                        if constexpr (MASK) {
+                            for (uint32_t k = lo; k < hi; ++k)
+                                if ((verdicts >> k) & 1ull) {
+                                    const f4 cr = rays[128u + k];
+                                    shadow = shadow * col4{cr.x, cr.y, cr.z, cr.w};
+                                }
+                            if (shadow.a < 1.0e-4f) live = false;  // nothing gets through any more (cuda_instance.cuh: the walk returns)
+                        } else {
+                            if (lo < hi && ((verdicts >> lo) & (hi - lo >= 64u ? ~0ull : ((1ull << (hi - lo)) - 1ull))) != 0ull) live = false, occluded = true;  // (:465: any hit occludes)
+                        }
                     }
+                    if constexpr (MASK) rz_wave_sync();  // the next step rewrites the colours
                 }
                 rz_wave_sync();
                 m = mlink;
@@ -1810,7 +1832,8 @@ RZ_DEV float any_hit_packet(const DScene& s, RZ_LDS f4* rays, bool active, const
         }
         n = link;
     }
-    return occluded ? 0.0f : 1.0f;
+    if constexpr (MASK) return shadow;
+    return splat(occluded ? 0.0f : 1.0f);
 }
 
 template <int MODE, bool COUNT, bool RCP>

@@ -722,9 +722,9 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_coop_kernel(const DScene s
 
 // rz_shadow_coop_kernel with the wave-level walk (hiprz_device.hpp: any_hit_packet): the shadow rays' sorted order hands a wave 64 rays
 // from one cell towards one light.  Sums, order and accumulation are those of rz_shadow_kernel.
-template <bool FIRST, bool COUNT, int MINW>
+template <bool FIRST, bool COUNT, int MINW, bool MASK = false>
 __global__ void __launch_bounds__(64, MINW) rz_shadow_packet_kernel(const DScene s, const DCamera cam, const DConfig cfg, const DFrame f) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];  // 2 KiB: the rays of a leaf's triangle phase
+    extern __shared__ __attribute__((aligned(16))) unsigned char rz_lds[];  // 2 KiB: the rays of a leaf's triangle phase (MASK: + 1 KiB, the crossed triangles' colours)
     const uint32_t slot = blockIdx.x * 64u + threadIdx.x;
     const uint32_t* order = f.shadow_perm ? f.shadow_perm : f.perm;
     const PixelId p = pixel_of_local(f, cam, order ? order[slot] : slot);
@@ -747,8 +747,8 @@ __global__ void __launch_bounds__(64, MINW) rz_shadow_packet_kernel(const DScene
         if (has) d = rec[4u + 2u * k], t = rec[5u + 2u * k];
         Ray sr;
         sr.o = V3(o.x, o.y, o.z), sr.d = V3(d.x, d.y, d.z), sr.near_ = 0.0f, sr.far_ = d.w;
-        col4 V_PL = splat(0.0f);
-        if (s.n_instances != 0u) V_PL = splat(any_hit_packet<COUNT, RZ_SHADE_SHARED_RCP != 0>(s, (RZ_LDS f4*)rz_lds, has, sr, cnt));
+        col4 V_PL = splat(MASK ? 1.0f : 0.0f);
+        if (s.n_instances != 0u) V_PL = any_hit_packet<COUNT, RZ_SHADE_SHARED_RCP != 0, MASK>(s, (RZ_LDS f4*)rz_lds, has, sr, MASK && (cfg.flags & HIPRZ_COMPAT_FILTERING) != 0u, cnt);
         else if (has) { RZ_COUNT(shadow_rays); }
         if (has) {
             const col4 term = (col4{t.x, t.y, t.z, t.w} * V_PL) * V_PL.a;

@@ -37,7 +37,9 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
         if (lights && defer_shadows(c)) {
             RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_COMPAT_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
             sort_after_shading(c, f);
-            if (c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR)  // coloured masks: the same kernel, its rays go through what they cross and collect the opacity colours
+            if ((c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR) && shadow_beams<COUNT>(c, f))  // coloured masks: the rays go through what they cross and collect the opacity colours
+                RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, 4, true>), dim3(c->n_local_tiles * 4u), dim3(64), 3072, c->stream, c->dscene, c->dcamera, cfg, f);
+            else if (c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR)
                 RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 3, true>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
             else if (shadow_beams<COUNT>(c, f))
                 RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), 2048, c->stream, c->dscene, c->dcamera, cfg, f);
