@@ -4,6 +4,10 @@
 #include "hiprz_ctx.hpp"
 #include "hiprz_kernels.hpp"
 
+#ifndef RZ_PACKET_MINW
+#define RZ_PACKET_MINW 4  // waves per SIMD the wave-level shadow walk's register budget is cut for (it takes 90 VGPRs: 5 waves)
+#endif
+
 namespace hiprz {
 namespace {
 
@@ -38,11 +42,11 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
             RZ_LAUNCH((rz_shade_kernel<FIRST, COUNT, false, RZ_SHADOW_COMPAT_DEFER>), grid, block, 0, c->stream, c->dscene, c->dcamera, cfg, f, 0u);
             sort_after_shading(c, f);
             if ((c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR) && shadow_beams<COUNT>(c, f))  // coloured masks: the rays go through what they cross and collect the opacity colours
-                RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, 4, true>), dim3(c->n_local_tiles * 4u), dim3(64), 3072, c->stream, c->dscene, c->dcamera, cfg, f);
+                RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, RZ_PACKET_MINW, true>), dim3(c->n_local_tiles * 4u), dim3(64), 3072, c->stream, c->dscene, c->dcamera, cfg, f);
             else if (c->mode_flags & HIPRZ_COMPAT_SHADOW_COLOR)
                 RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 3, true>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
             else if (shadow_beams<COUNT>(c, f))
-                RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), 2048, c->stream, c->dscene, c->dcamera, cfg, f);
+                RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, RZ_PACKET_MINW>), dim3(c->n_local_tiles * 4u), dim3(64), 2048, c->stream, c->dscene, c->dcamera, cfg, f);
             else
                 RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 4>), dim3(c->n_local_tiles * 4u), dim3(64), CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
             join_sort(c);
@@ -65,7 +69,7 @@ void launch_shade_t(hiprz_ctx* c, const DFrame& f) {
         sort_after_shading(c, f);
         const dim3 sgrid(c->n_local_tiles * 4u), sblock(64);
         if (shadow_beams<COUNT>(c, f)) {
-            RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, 4>), sgrid, sblock, 2048, c->stream, c->dscene, c->dcamera, cfg, f);
+            RZ_LAUNCH((rz_shadow_packet_kernel<FIRST, COUNT, RZ_PACKET_MINW>), sgrid, sblock, 2048, c->stream, c->dscene, c->dcamera, cfg, f);
         } else if ((COUNT ? c->walk_order == 2 : c->walk_order != 0) || c->scene_tree != HIPRZ_TREE_REFERENCE) {
             RZ_LAUNCH((rz_shadow_coop_kernel<FIRST, COUNT, 4>), sgrid, sblock, CoopLds::kBytes, c->stream, c->dscene, c->dcamera, cfg, f);
         } else {
