@@ -1198,7 +1198,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     if (const char* w = std::getenv("HIPRZ_BATCH_WAVES")) c->batch_waves = std::atoi(w);
     if (const char* w = std::getenv("HIPRZ_NOLIGHT_KERNELS")) c->nolight_kernels = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SORT_BITS")) c->sort_bits = std::min(24, std::max(0, std::atoi(w)));
-    if (const char* w = std::getenv("HIPRZ_SHADOW_PACKET")) c->shadow_packet = std::atoi(w) != 0;
+    if (const char* w = std::getenv("HIPRZ_SHADOW_PACKET")) c->shadow_packet = std::atoi(w);
     if (const char* w = std::getenv("HIPRZ_SHADOW_SORT")) c->shadow_sort = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_WAVE_RESIDENT_MAX")) c->wave_resident_max = uint32_t(std::max(0, std::atoi(w)));
     c->device = device_id;

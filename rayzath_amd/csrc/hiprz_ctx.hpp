@@ -236,7 +236,7 @@ struct hiprz_ctx : hiprz_frame_state {
     int nolight_kernels = 1;  // scenes without lights use the instantiations without next-event estimation (HIPRZ_NOLIGHT_KERNELS=0: the general ones)
     bool flat_world = false;  // the uploaded world tree is one leaf of at most 8 instances: the binned walk tests their boxes up front (MODE 4)
     int sort_bits = 0;    // most significant key bits the radix sorts look at; 0 = by frame size (HIPRZ_SORT_BITS)
-    bool shadow_packet = true;  // sorted shadow rays are walked by the wave (rz_shadow_packet_kernel); HIPRZ_SHADOW_PACKET=0: the cooperative walk
+    int shadow_packet = -1;  // sorted shadow rays walked by the wave (rz_shadow_packet_kernel): -1 where the beams are narrow enough (launch_shade), 0 never, 1 always (HIPRZ_SHADOW_PACKET)
     int shadow_sort = 1;  // HIPRZ_SHADOW_SORT=0: the shadow kernel follows the next pass's ray order instead
     int sort_rays = -1;  // -1 auto (on for scenes walked with MODE 3), 0 off, 1 on
     bool defer_shadow_rays = true;  // HIPRZ_DEFER_SHADOWS=0: walk them inside the shade kernel

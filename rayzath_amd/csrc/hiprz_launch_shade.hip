@@ -23,10 +23,14 @@ void sort_after_shading(hiprz_ctx* c, const DFrame& f) {
 // The deferred shadow rays in their own sorted order (slot set, light, origin cell) reach the kernel as BEAMS — 64 rays from one cell towards
 // one light — and the wave walks the trees for all of them at once (rz_shadow_packet_kernel; round 4, config E: shadow kernel 1 449 ->
 // about 1 160 us, step 37.5 -> 35.2 ms, identical frames).  Not for counted passes (the work counters are anchored on the per-lane walks)
-// and not where the shadow rays follow the next pass's ray order (HIPRZ_SHADOW_SORT=0: no beams).  HIPRZ_SHADOW_PACKET=0: the cooperative walk.
+// not where the shadow rays follow the next pass's ray order (HIPRZ_SHADOW_SORT=0: no beams), and not for small frames of many instances (wide
+// beams: below).  HIPRZ_SHADOW_PACKET=0 / 1: never / always.
 template <bool COUNT>
 bool shadow_beams(const hiprz_ctx* c, const DFrame& f) {
-    return !COUNT && c->shadow_packet && f.shadow_key != nullptr;
+    if (COUNT || c->shadow_packet == 0 || f.shadow_key == nullptr) return false;
+    // how narrow the beams are goes with the rays per light and cell: the living room at 40 instances 1.09x (4K) / 1.06x (1080p) / 1.05x (960 x 540) /
+    // 0.97x (480 x 270) of the cooperative walk's pass, at 300 instances 0.98x (1080p) / 0.88x (480 x 270) — tools/ab_shadow_walks.py
+    return c->shadow_packet > 0 || size_t(c->n_local_tiles) * 256u >= size_t(8192) * c->dscene.n_instances;
 }
 
 template <bool FIRST, bool COUNT>

@@ -58,9 +58,10 @@ def test_walk_levels_over_world_trees_of_many_shapes(built, monkeypatch, n_insta
                            "host SAH trees": dict(tree=1), "device trees, Morton order": dict(tree=2), "device SAH trees": dict(tree=3),
                            "the hosts' default trees": dict(tree=4)}.items():
         _same(reference, _frames(flat, cam, cfg, monkeypatch, **settings), name)
-    if lights:       # the shadow rays walked lane by lane (cooperative walk) instead of by the wave (rz_shadow_packet_kernel, the default)
+    if lights:       # the shadow rays walked by the wave (rz_shadow_packet_kernel: what big frames get) and lane by lane (the cooperative walk)
         for tree in (0, 3):
-            _same(reference, _frames(flat, cam, cfg, monkeypatch, env={"HIPRZ_SHADOW_PACKET": "0"}, pipeline=1, lds_scene=0, tree=tree), f"cooperative shadow walk, tree {tree}")
+            for packet in ("1", "0"):
+                _same(reference, _frames(flat, cam, cfg, monkeypatch, env={"HIPRZ_SHADOW_PACKET": packet}, pipeline=1, lds_scene=0, tree=tree), f"shadow walk: packet {packet}, tree {tree}")
     if not lights:   # the per-wave resident kernel (scenes without lights)
         _same(reference, _frames(flat, cam, cfg, monkeypatch, pipeline=2, lds_scene=0, tree=3), "per-wave resident kernel")
     for world_advance, walk_advance in (("0", "0"), ("1", "3"), ("64", "64")):
