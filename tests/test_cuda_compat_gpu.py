@@ -105,7 +105,10 @@ def _shadow_scene(with_sheet):
     return world
 
 
-def test_coloured_shadows():
+@pytest.mark.parametrize("shadow_walk", ["1", "0"])
+def test_coloured_shadows(monkeypatch, shadow_walk):
+    """... through both shadow walks: by the wave (rz_shadow_packet_kernel<..., MASK>, what big frames get) and lane by lane (rz_shadow_coop_kernel<..., MASK>)."""
+    monkeypatch.setenv("HIPRZ_SHADOW_PACKET", shadow_walk)
     open_, _, _ = _render(_shadow_scene(False), COMPAT_SHADOW_COLOR, 1, 1)
     opaque, _, _ = _render(_shadow_scene(True), 0, 1, 1)
     tinted, depth, _ = _render(_shadow_scene(True), COMPAT_SHADOW_COLOR, 1, 1)

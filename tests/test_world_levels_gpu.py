@@ -83,3 +83,5 @@ def test_compat_integrator_over_every_kind_of_tree(built, monkeypatch, flags):
         _same(reference, _frames(flat, cam, cfg, monkeypatch, mode=flags, tree=tree), f"tree {tree}")
     _same(reference, _frames(flat, cam, cfg, monkeypatch, env={"HIPRZ_WORLD_ADVANCE": "0", "HIPRZ_WALK_ADVANCE": "0"}, mode=flags, tree=3), "levels off")
     _same(reference, _frames(flat, cam, cfg, monkeypatch, mode=flags, pipeline=0), "one fused kernel per pass")
+    for packet in ("1", "0"):   # the shadow rays walked by the wave (what big frames get; with flag 4 its mask-collecting instantiation) / lane by lane
+        _same(reference, _frames(flat, cam, cfg, monkeypatch, env={"HIPRZ_SHADOW_PACKET": packet}, mode=flags, tree=3), f"shadow walk: packet {packet}")
