@@ -14,7 +14,7 @@ namespace {
 // The two orders a shaded pass needs.  The next pass's ray order is needed by the shadow kernel only when it has no order of its own
 // (HIPRZ_SHADOW_SORT=0); otherwise it is sorted on the auxiliary stream beside the shadow rays' sort and walk, and the main stream
 // picks it up after them (join_sort).  (The shadow rays' sort first and alone, the ray sort beside the walk only: measured on E in
-// round 4 with the runs sort, 41.8 against 41.4 ms per step — two memory-bound sorts share the chip better than a sort and the walk.)
+// round 4 with the runs sort, 41.8 against 41.4 ms per step, and again beside the wave-level shadow walk, 35.05 against 34.5 — two memory-bound sorts share the chip better than a sort and the walk.)
 void sort_after_shading(hiprz_ctx* c, const DFrame& f) {
     launch_sort(c, f.shadow_key != nullptr);
     if (f.shadow_key) launch_shadow_sort(c);
