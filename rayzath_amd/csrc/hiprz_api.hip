@@ -1327,6 +1327,7 @@ int hiprz_destroy(hiprz_ctx* c) {
     c->hot.release(), c->node_skip.release(), c->nodes64.release(), c->textures.release();
     c->dev_nodes.release(), c->has_mesh.release(), c->build_temp.release(), c->slot_parent.release(), c->ref_to_dev.release(), c->refit_visit.release();
     c->world_items.release(), c->update_tris.release(), c->update_attrs.release();
+    c->shadow_nodes64.release(), c->shadow_order.release();
     c->build_sort.keys_out.release(), c->build_sort.vals_a.release(), c->build_sort.vals_b.release(), c->build_sort.counts.release(), c->build_sort.row_total.release();
     c->texels.release(), c->spot_lights.release(), c->direct_lights.release();
     release_frame(c);
@@ -1337,6 +1338,10 @@ int hiprz_destroy(hiprz_ctx* c) {
 }
 
 const char* hiprz_last_error(const hiprz_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+namespace {
+int build_shadow_world_tree(hiprz_ctx* c, const std::vector<hiprz_instance>& dinst, DScene& d);
+}
 
 int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
     if (!c) return HIPRZ_ERR_INVALID;
@@ -1629,6 +1634,16 @@ int hiprz_upload_scene(hiprz_ctx* c, const hiprz_scene* sc) {
         for (const auto& m : c->device_meshes) emitted += m.n_slots;
         c->n_nodes = emitted;
     }
+    {   // the shadow rays' own world tree over the instances of the world tree (those with a mesh)
+        std::vector<uint8_t> member(sc->n_instances ? sc->n_instances : 1u, 0);
+        for (uint32_t k = 0; k < sc->n_tlas_order; ++k)
+            if (sc->tlas_order[k] < sc->n_instances) member[sc->tlas_order[k]] = 1;
+        c->world_members.clear();
+        for (uint32_t i = 0; i < sc->n_instances; ++i)
+            if (member[i]) c->world_members.push_back(i);
+        const int src = build_shadow_world_tree(c, dinstances, d);
+        if (src != HIPRZ_OK) return src;
+    }
     c->have_scene = true;
     resolve_pipeline(c);
     c->reset_pending = true;  // world changed => accumulation restarts (cpu_engine_renderer.cpp:108-112), for every camera
@@ -1692,6 +1707,94 @@ int scene_lost(hiprz_ctx* c, int rc) {
     invalidate_graphs(c);
     return rc;
 }
+// The shadow rays' own world tree.  anyIntersection's answer does not depend on the order in which a ray meets the instances, so the
+// wave-level shadow walk (any_hit_packet) need not follow the reference's world tree — built for another purpose: leaves of several
+// instances, met in one fixed sequence — and takes a binned-free surface-area tree over the instances' world boxes instead: binary, one
+// instance per leaf, the leaf's box being the instance's own (interleaved) box bit for bit, so that the leaf's test is the instance's
+// test.  Built on the host from the instance records the device holds (`dinst`: boxes interleaved like nodes), at every upload and every
+// hiprz_update_instances: n log^2 n for n instances, 64-byte walk records with the octant-0 skip links the wave-level walk follows,
+// root in record 0.  Buffers are sized once per scene (2 n records), so the DScene a captured graph holds stays valid across updates.
+int build_shadow_world_tree(hiprz_ctx* c, const std::vector<hiprz_instance>& dinst, DScene& d) {
+    d.shadow_nodes64 = nullptr, d.shadow_order = nullptr, d.shadow_root = RZ_END;
+    static const bool enabled = [] { const char* e = std::getenv("HIPRZ_SHADOW_TREE"); return !e || std::atoi(e) != 0; }();
+    const std::vector<uint32_t>& members = c->world_members;
+    if (!enabled || members.empty()) return HIPRZ_OK;
+    struct Box {
+        float mn[3], mx[3];
+    };
+    auto box_of = [&](uint32_t i) {
+        const hiprz_instance& in = dinst[i];
+        float max_y;
+        std::memcpy(&max_y, &in.pad2, 4);
+        return Box{{in.bb_min[0], in.bb_min[2], in.bb_max[0]}, {in.bb_min[1], max_y, in.bb_max[1]}};
+    };
+    auto grow = [](Box& b, const Box& o) {
+        for (int a = 0; a < 3; ++a) b.mn[a] = std::min(b.mn[a], o.mn[a]), b.mx[a] = std::max(b.mx[a], o.mx[a]);
+    };
+    auto area = [](const Box& b) {
+        const float x = b.mx[0] - b.mn[0], y = b.mx[1] - b.mn[1], z = b.mx[2] - b.mn[2];
+        return x * y + y * z + z * x;
+    };
+    const uint32_t n = uint32_t(members.size());
+    std::vector<uint32_t> order(members), rec(size_t(2u * n) * 16u, RZ_END), sorted, best;
+    std::vector<float> left_area;
+    struct Task {
+        uint32_t node, lo, hi, link;
+    };
+    std::vector<Task> stack{{0u, 0u, n, RZ_END}};
+    uint32_t next_free = 1u;
+    while (!stack.empty()) {
+        const Task t = stack.back();
+        stack.pop_back();
+        Box b = box_of(order[t.lo]);
+        for (uint32_t k = t.lo + 1u; k < t.hi; ++k) grow(b, box_of(order[k]));
+        const float interleaved[6] = {b.mn[0], b.mx[0], b.mn[1], b.mx[1], b.mn[2], b.mx[2]};
+        uint32_t* r = &rec[size_t(t.node) * 16u];
+        std::memcpy(r, interleaved, 24);
+        for (int o = 0; o < 8; ++o) r[8 + o] = t.link;  // (only the wave-level walk follows this tree: the order of octant 0 under every octant)
+        const uint32_t len = t.hi - t.lo;
+        if (len == 1u) {
+            r[6] = t.lo, r[7] = HIPRZ_NODE_LEAF | 1u;
+            continue;
+        }
+        // the cheapest cut of the instances sorted by box centre along one of the axes: area(left) * |left| + area(right) * |right|
+        float best_cost = 3.0e38f;
+        uint32_t best_axis = 0u, best_cut = len / 2u;
+        for (uint32_t axis = 0; axis < 3u; ++axis) {
+            sorted.assign(order.begin() + t.lo, order.begin() + t.hi);
+            std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t x, uint32_t y) {
+                const Box bx = box_of(x), by = box_of(y);
+                return bx.mn[axis] + bx.mx[axis] < by.mn[axis] + by.mx[axis];
+            });
+            left_area.assign(len, 0.0f);
+            Box acc = box_of(sorted[0]);
+            for (uint32_t k = 1u; k < len; ++k) left_area[k] = area(acc), grow(acc, box_of(sorted[k]));  // area of the first k
+            acc = box_of(sorted[len - 1u]);
+            for (uint32_t k = len - 1u; k >= 1u; --k) {  // cut before position k
+                const float cost = left_area[k] * float(k) + area(acc) * float(len - k);
+                if (cost < best_cost) best_cost = cost, best_axis = axis, best_cut = k, best = sorted;
+                grow(acc, box_of(sorted[k - 1u]));
+            }
+        }
+        if (best.size() != len) best.assign(order.begin() + t.lo, order.begin() + t.hi);
+        std::copy(best.begin(), best.end(), order.begin() + t.lo);
+        best.clear();
+        const uint32_t first = next_free;
+        next_free += 2u;
+        r[6] = first, r[7] = (2u - best_axis) << HIPRZ_NODE_PTYPE_SHIFT;  // the lower child along the axis first
+        stack.push_back({first + 1u, t.lo + best_cut, t.hi, t.link});
+        stack.push_back({first, t.lo, t.lo + best_cut, first + 1u});
+    }
+    (void)hipSetDevice(c->device);
+    RZ_HIP(c, c->shadow_nodes64.resize(rec.size()));
+    RZ_HIP(c, c->shadow_order.resize(n));
+    RZ_HIP(c, hipStreamSynchronize(c->stream));
+    RZ_HIP(c, hipMemcpy(c->shadow_nodes64.ptr, rec.data(), rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RZ_HIP(c, hipMemcpy(c->shadow_order.ptr, order.data(), size_t(n) * sizeof(uint32_t), hipMemcpyHostToDevice));
+    d.shadow_nodes64 = reinterpret_cast<const float4*>(c->shadow_nodes64.ptr), d.shadow_order = c->shadow_order.ptr, d.shadow_root = 0u;
+    return HIPRZ_OK;
+}
+
 int restart_after_geometry_change(hiprz_ctx* c) {
     c->reset_pending = true;  // the world changed: accumulation restarts (cpu_engine_renderer.cpp:108-112), for every camera
     for (auto& f : c->parked) f.reset_pending = true;
@@ -1794,6 +1897,10 @@ int hiprz_update_instances(hiprz_ctx* c, const hiprz_instance* instances, uint32
     if (c->n_tlas_order) {
         const int rc = device_build_world_tree(c, !std::getenv("HIPRZ_TRUST_DEVICE_TREES"));
         if (rc != HIPRZ_OK) return scene_lost(c, rc);  // the new instance records and a world tree nobody proved are on the device
+    }
+    {
+        const int src = build_shadow_world_tree(c, c->device_instances, c->dscene);  // the instances moved: the shadow rays' tree over them again
+        if (src != HIPRZ_OK) return scene_lost(c, src);
     }
     return restart_after_geometry_change(c);
 }

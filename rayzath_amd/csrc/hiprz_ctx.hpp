@@ -216,6 +216,8 @@ struct hiprz_ctx : hiprz_frame_state {
     hiprz::DeviceArray<hiprz_tri> update_tris;
     hiprz::DeviceArray<hiprz_tri_attr> update_attrs;
     hiprz_frame_state::SortTemp build_sort;
+    hiprz::DeviceArray<uint32_t> shadow_nodes64, shadow_order;  // the shadow rays' own world tree (build_shadow_world_tree)
+    std::vector<uint32_t> world_members;                         // the instances of the world tree (those with a mesh), by rising id
     std::vector<hiprz::DeviceMesh> device_meshes;
     std::vector<uint32_t> instance_mesh;          // instance -> index into device_meshes (RZ_END: no mesh)
     std::vector<hiprz_instance> device_instances; // the instance records as the device holds them (hiprz_update_instances keeps what it does not replace)

@@ -103,6 +103,11 @@ struct DScene {
     // ray-direction octants
     const float4* nodes64;
     uint32_t shadow_variant;  // the same for the shadow rays' key (HIPRZ_SHADOW_KEY); + 0x100: the pixel's set of sample slots leads the key; + 0x400: the light the ray goes to, then the origin's cell in a 64^3 grid, instead of a layout
+    // the shadow rays' own world tree (hiprz_api.hip: build_shadow_world_tree): 64-byte walk records, the instance ids its leaves index, its root
+    // (record 0) or RZ_END: none — the walks then take the reference's world tree
+    const float4* shadow_nodes64;
+    const uint32_t* shadow_order;
+    uint32_t shadow_root;
     uint32_t sort_variant;  // ray_sort_key layout (HIPRZ_SORT_KEY): 0 origin cell then direction, 1 direction then cell, 2 interleaved, 3 octahedral direction interleaved with the cell, 4 origin cell interleaved with the cell where the ray leaves the world box
 };
 
@@ -1702,14 +1707,19 @@ RZ_DEV col4 any_hit_packet(const DScene& s, RZ_LDS f4* rays, bool active, const 
     col4 shadow = splat(1.0f);  // (MASK)
     uint32_t wresume = 0u, guard = 0u;
     if (active) { RZ_COUNT(shadow_rays); }
-    uint32_t n = s.tlas_root;
+    // The world level: a shadow ray's answer does not depend on the order in which it meets the instances, so where the context has
+    // built one the walk takes the shadow rays' OWN world tree — a surface-area tree over the instances' boxes with one instance per leaf,
+    // whose leaf box IS the instance's box (the leaf's test is the instance's test) — instead of the reference's.
+    const bool own = s.shadow_root != RZ_END;
+    const float4* world = own ? s.shadow_nodes64 : s.nodes64;
+    const uint32_t* world_order = own ? s.shadow_order : s.tlas_order;
+    uint32_t n = own ? s.shadow_root : s.tlas_root;
     while (n != RZ_END && __any(live)) {  // wave-uniform
         RZ_GUARD(guard);
         if (wblocked && wresume == n) wblocked = false;
-        float4 n0, n1;
-        uint32_t link;
-        fetch_node_ordered(s, n, 0u, n0, n1, link);
-        link = uint32_t(__builtin_amdgcn_readfirstlane(int(link)));
+        const float4* rec = world + 4 * size_t(n);
+        const float4 n0 = rec[0], n1 = rec[1];
+        const uint32_t link = uint32_t(__builtin_amdgcn_readfirstlane(int(reinterpret_cast<const uint32_t*>(rec + 2)[0])));
         bool hit = false;
         if (live && !wblocked) {
             RZ_PHASE(0);
@@ -1729,11 +1739,11 @@ RZ_DEV col4 any_hit_packet(const DScene& s, RZ_LDS f4* rays, bool active, const 
         }
         const uint32_t end = begin + (meta & HIPRZ_NODE_COUNT_MASK);
         for (uint32_t i = begin; i < end && __any(live); ++i) {  // the leaf's instances, in the reference's order
-            const uint32_t inst = uint32_t(__builtin_amdgcn_readfirstlane(int(s.tlas_order[i])));
-            float4 ib0, ib1;
-            load_instance_box(s, inst, ib0, ib1);
-            bool enter = false;
-            if (live && hit) {
+            const uint32_t inst = uint32_t(__builtin_amdgcn_readfirstlane(int(world_order[i])));
+            bool enter = live && hit;  // (own tree: the leaf's box was the instance's)
+            if (!own && enter) {
+                float4 ib0, ib1;
+                load_instance_box(s, inst, ib0, ib1);
                 RZ_PHASE(1);
                 RZ_COUNT(box_tests);
                 RZ_COUNT(shadow_box_tests);
