@@ -1199,6 +1199,7 @@ int hiprz_create(hiprz_ctx** out, int device_id) {
     if (const char* w = std::getenv("HIPRZ_NOLIGHT_KERNELS")) c->nolight_kernels = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SORT_BITS")) c->sort_bits = std::min(24, std::max(0, std::atoi(w)));
     if (const char* w = std::getenv("HIPRZ_SHADOW_PACKET")) c->shadow_packet = std::atoi(w);
+    if (const char* w = std::getenv("HIPRZ_SHADOW_TREE")) c->shadow_tree = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_SHADOW_SORT")) c->shadow_sort = std::atoi(w) != 0;
     if (const char* w = std::getenv("HIPRZ_WAVE_RESIDENT_MAX")) c->wave_resident_max = uint32_t(std::max(0, std::atoi(w)));
     c->device = device_id;
@@ -1716,9 +1717,8 @@ int scene_lost(hiprz_ctx* c, int rc) {
 // root in record 0.  Buffers are sized once per scene (2 n records), so the DScene a captured graph holds stays valid across updates.
 int build_shadow_world_tree(hiprz_ctx* c, const std::vector<hiprz_instance>& dinst, DScene& d) {
     d.shadow_nodes64 = nullptr, d.shadow_order = nullptr, d.shadow_root = RZ_END;
-    static const bool enabled = [] { const char* e = std::getenv("HIPRZ_SHADOW_TREE"); return !e || std::atoi(e) != 0; }();
     const std::vector<uint32_t>& members = c->world_members;
-    if (!enabled || members.empty()) return HIPRZ_OK;
+    if (!c->shadow_tree || members.empty()) return HIPRZ_OK;
     struct Box {
         float mn[3], mx[3];
     };

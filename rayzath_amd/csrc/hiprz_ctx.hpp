@@ -238,6 +238,7 @@ struct hiprz_ctx : hiprz_frame_state {
     int nolight_kernels = 1;  // scenes without lights use the instantiations without next-event estimation (HIPRZ_NOLIGHT_KERNELS=0: the general ones)
     bool flat_world = false;  // the uploaded world tree is one leaf of at most 8 instances: the binned walk tests their boxes up front (MODE 4)
     int sort_bits = 0;    // most significant key bits the radix sorts look at; 0 = by frame size (HIPRZ_SORT_BITS)
+    bool shadow_tree = true;  // the wave-level shadow walk takes a world tree of its own (build_shadow_world_tree); HIPRZ_SHADOW_TREE=0: the reference's
     int shadow_packet = -1;  // sorted shadow rays walked by the wave (rz_shadow_packet_kernel): -1 where the beams are narrow enough (launch_shade), 0 never, 1 always (HIPRZ_SHADOW_PACKET)
     int shadow_sort = 1;  // HIPRZ_SHADOW_SORT=0: the shadow kernel follows the next pass's ray order instead
     int sort_rays = -1;  // -1 auto (on for scenes walked with MODE 3), 0 off, 1 on

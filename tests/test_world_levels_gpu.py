@@ -29,7 +29,7 @@ def _world(n_instances, lights, seed):
 
 
 def _frames(flat, cam, cfg, monkeypatch, env=None, **settings):
-    for k in ("HIPRZ_WORLD_ADVANCE", "HIPRZ_WALK_ADVANCE", "HIPRZ_SHADOW_PACKET"):
+    for k in ("HIPRZ_WORLD_ADVANCE", "HIPRZ_WALK_ADVANCE", "HIPRZ_SHADOW_PACKET", "HIPRZ_SHADOW_TREE"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, v)
@@ -62,6 +62,8 @@ def test_walk_levels_over_world_trees_of_many_shapes(built, monkeypatch, n_insta
         for tree in (0, 3):
             for packet in ("1", "0"):
                 _same(reference, _frames(flat, cam, cfg, monkeypatch, env={"HIPRZ_SHADOW_PACKET": packet}, pipeline=1, lds_scene=0, tree=tree), f"shadow walk: packet {packet}, tree {tree}")
+            # ... by the wave on the reference's world tree instead of the shadow rays' own (build_shadow_world_tree)
+            _same(reference, _frames(flat, cam, cfg, monkeypatch, env={"HIPRZ_SHADOW_PACKET": "1", "HIPRZ_SHADOW_TREE": "0"}, pipeline=1, lds_scene=0, tree=tree), f"wave-level walk on the reference's world tree, tree {tree}")
     if not lights:   # the per-wave resident kernel (scenes without lights)
         _same(reference, _frames(flat, cam, cfg, monkeypatch, pipeline=2, lds_scene=0, tree=3), "per-wave resident kernel")
     for world_advance, walk_advance in (("0", "0"), ("1", "3"), ("64", "64")):
@@ -85,3 +87,38 @@ def test_compat_integrator_over_every_kind_of_tree(built, monkeypatch, flags):
     _same(reference, _frames(flat, cam, cfg, monkeypatch, mode=flags, pipeline=0), "one fused kernel per pass")
     for packet in ("1", "0"):   # the shadow rays walked by the wave (what big frames get; with flag 4 its mask-collecting instantiation) / lane by lane
         _same(reference, _frames(flat, cam, cfg, monkeypatch, env={"HIPRZ_SHADOW_PACKET": packet}, mode=flags, tree=3), f"shadow walk: packet {packet}")
+
+
+def test_moved_instances_move_the_shadow_rays_world_tree(built, monkeypatch):
+    """hiprz_update_instances rebuilds the shadow rays' own world tree (build_shadow_world_tree) with the reference's: a scene with lights whose
+    instances moved on the device == a fresh upload of the moved world, with the shadow rays walked by the wave on that tree."""
+    monkeypatch.setenv("HIPRZ_SHADOW_PACKET", "1")
+    def build(moved):
+        world = _world(17, True, seed=31)
+        if moved:
+            for k, inst in enumerate(world.instances[2:12]):
+                inst.position = (np.asarray(inst.position, dtype=np.float32) + np.array([0.3 * ((k % 3) - 1), 0.15, -0.2 * (k % 2)], dtype=np.float32)).astype(np.float32)
+        return world
+    before, after = build(False), build(True)
+    flat0, flat1, cam = flatten(before), flatten(after), camera_struct(before.camera)
+    cfg = RenderConfig(LightSampling(2, 1), Tracing(5, 4)).struct()
+    out = []
+    for moved_on_device in (True, False):
+        c = Context(0)
+        c.set_tree(3), c.set_pipeline(1), c.set_lds_scene(0)     # TREE_DEVICE_SAH: what hiprz_update_instances needs
+        c.upload_scene(flat0 if moved_on_device else flat1), c.upload_camera(cam), c.set_config(cfg)
+        if moved_on_device:
+            c.render(2)
+            c.update_instances(flat1.instances)
+        for n in (1, 4, 3):
+            c.render(n)
+        out.append((c.read_accum().copy(), c.read_depth().copy()))
+        c.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    still = Context(0)
+    still.set_tree(3), still.set_pipeline(1), still.set_lds_scene(0)
+    still.upload_scene(flat0), still.upload_camera(cam), still.set_config(cfg)
+    for n in (1, 4, 3):
+        still.render(n)
+    assert not np.array_equal(still.read_accum(), out[0][0])      # the move is visible
+    still.close()
