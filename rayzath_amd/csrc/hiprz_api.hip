@@ -1718,7 +1718,7 @@ int scene_lost(hiprz_ctx* c, int rc) {
 int build_shadow_world_tree(hiprz_ctx* c, const std::vector<hiprz_instance>& dinst, DScene& d) {
     d.shadow_nodes64 = nullptr, d.shadow_order = nullptr, d.shadow_root = RZ_END;
     const std::vector<uint32_t>& members = c->world_members;
-    if (!c->shadow_tree || members.empty()) return HIPRZ_OK;
+    if (!c->shadow_tree || members.empty() || members.size() > 4096u) return HIPRZ_OK;  // (the host build is n log^2 n per upload AND per instance update: beyond a few thousand instances the walk keeps the reference's tree)
     struct Box {
         float mn[3], mx[3];
     };
